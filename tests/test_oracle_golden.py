@@ -1,0 +1,187 @@
+"""Pin the CPU oracle (oracle/tinynerf_oracle.py) to golden vectors captured from the
+imported reference (oracle/make_goldens.py).  Integer / index / sampled-coordinate
+outputs are compared bit-exactly; MLP-class floating point within 1e-5."""
+import numpy as np
+import pytest
+
+from oracle import tinynerf_oracle as orc
+from conftest import load_golden
+
+TOL = 1e-5
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+def sub(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("name", ["G1_march_aabb", "G1b_march_aabb_asym"])
+def test_march_aabb_bit_exact(name):
+    g = load_golden(name)
+    t, dl = orc.march_aabb(g["rays_o"], g["rays_d"], g["aabb"], int(g["n_samples"]), float(g["near"]), float(g["far"]))
+    assert bits(orc.aabb_step_size(g["aabb"], int(g["n_samples"]))) == bits(g["step_size"])
+    assert np.array_equal(bits(t), bits(g["t"]))
+    assert np.array_equal(bits(dl), bits(g["delta"]))
+    if "coords" in g:
+        pts = (g["rays_o"][:, None] + (g["rays_d"][:, None] * t[..., None]).astype(np.float32)).astype(np.float32)
+        c, m = orc.contract_aabb(pts, g["aabb"])
+        assert np.array_equal(bits(c), bits(g["coords"]))
+        assert np.array_equal(m, g["mask"])
+        assert not g["mask"][2].any()          # the ray that misses the box
+
+
+@pytest.mark.parametrize("S", [8, 200, 1000])
+def test_march_unbounded_bit_exact(S):
+    g = load_golden(f"G2_unbounded_S{S}")
+    t, dl = orc.unbounded_table(S, float(g["near"]), float(g["uniform_range"]))
+    assert np.array_equal(bits(t), bits(g["t_row"]))
+    assert np.array_equal(bits(dl), bits(g["delta_row"]))
+    o, d = g["rays_o"], g["rays_d"]
+    pts = (o[:, None] + (d[:, None] * t[None, :, None]).astype(np.float32)).astype(np.float32)
+    c, m = orc.contract_mip360(pts, float("inf"))
+    assert m is None
+    assert np.array_equal(bits(c), bits(g["coords_inf"]))
+    c2, _ = orc.contract_mip360(pts, 2)
+    np.testing.assert_allclose(c2, g["coords_l2"], rtol=0, atol=2e-7)
+    if S == 8:   # SURVEY probe values
+        np.testing.assert_allclose(orc.unbounded_table(8, 0.1, 1.0)[0],
+                                   [.1, .325, .55, .775, 1, 1.2429, 1.6385, 2.4529], atol=2e-4)
+
+
+def test_occupancy_query_bit_exact():
+    g = load_golden("G3_occupancy_query")
+    v = orc.trilinear_zeros_align(g["grid"], g["coords"])
+    assert np.array_equal(bits(v), bits(g["values"]))
+    assert np.array_equal(orc.occupancy_query(g["grid"], g["coords"], float(g["threshold"])), g["occupied"])
+
+
+def test_occupancy_reference_known_answer():
+    """reference tests/test_core.py:5-38 -- zero where x >= 64; occupied iff x == 32."""
+    g = load_golden("G3b_reference_known_answer")
+    grid = np.ones((128, 128, 128), np.float32)
+    grid[:, :, 64:] = 0
+    occ = orc.occupancy_query(grid, g["coords"], float(g["threshold"]))
+    assert np.array_equal(occ, g["occupied"])
+    assert list(occ) == [True] * 4 + [False] * 4
+
+
+def test_ray_provider_aabb_bit_exact():
+    g = load_golden("G4_ray_provider_aabb")
+    kw = dict(marcher="aabb", contraction="aabb", grid=g["grid"], threshold=float(g["threshold"]),
+              n_samples=int(g["n_samples"]), near=float(g["near"]), aabb=g["aabb"])
+    p, info = orc.ray_provider(g["rays_o"], g["rays_d"], **kw)
+    assert info.dtype == np.int32 and np.array_equal(info, g["info"])
+    assert np.array_equal(bits(p), bits(g["packed"]))
+    p, info = orc.ray_provider(g["rays_o"], g["rays_d"], jitter=g["jitter"], **kw)
+    assert np.array_equal(info, g["info_jit"])
+    assert np.array_equal(bits(p), bits(g["packed_jit"]))
+    assert (g["info"][:, 1] == 0).any() and (g["info"][:, 1] > 0).any()   # ragged incl. empty rays
+
+
+def test_ray_provider_unbounded_bit_exact():
+    g = load_golden("G4b_ray_provider_unbounded")
+    kw = dict(marcher="unbounded", contraction="mip360", grid=g["grid"], threshold=float(g["threshold"]),
+              n_samples=int(g["n_samples"]), near=float(g["near"]), uniform_range=float(g["uniform_range"]))
+    p, info = orc.ray_provider(g["rays_o"], g["rays_d"], **kw)
+    assert np.array_equal(info, g["info"])
+    assert np.array_equal(bits(p), bits(g["packed"]))
+    p, info = orc.ray_provider(g["rays_o"], g["rays_d"], jitter=g["jitter"], **kw)
+    assert np.array_equal(info, g["info_jit"])
+    assert np.array_equal(bits(p), bits(g["packed_jit"]))
+
+
+def test_occupancy_update():
+    g = load_golden("G5_occupancy_update")
+    fm = orc.mlp_layers(sub(g, "fm."), "net.net.")
+    od = orc.mlp_layers(sub(g, "od."), "net.net.")
+    nf = g["fm.encoding.freqs"].shape[0]
+    sigma_fn = lambda x: orc.sigma_decoder(orc.vanilla_features(x, fm, nf), od)
+    grid0 = np.ones(g["grid_after_1"].shape, np.float32)
+    grid1, mean1 = orc.occupancy_update(grid0, sigma_fn, float(g["step_size"]), float(g["base_threshold"]),
+                                        float(g["decay"]), 1.0, g["jitters"])
+    # cells are exactly 1 or decay; a flip needs alpha within ~1e-6 of the threshold
+    assert (grid1 != g["grid_after_1"]).mean() < 2e-3
+    assert abs(mean1 - float(g["mean_after_1"])) < 2e-3
+    assert 0 < (grid1 == 1).mean() < 1
+
+
+def test_posenc():
+    g = load_golden("G6_posenc")
+    for F in (3, 8, 10):
+        assert np.array_equal(bits(orc.posenc_freqs(F)), bits(g[f"freqs{F}"]))
+        np.testing.assert_allclose(orc.posenc(g["x"], F), g[f"enc{F}"], rtol=0, atol=TOL)
+    assert orc.posenc(g["x4"], 4).shape == tuple(g["enc4"])
+
+
+def test_kplanes_plane_arange():
+    g = load_golden("G7a_plane_arange")
+    out = orc.bilinear_zeros_align(g["plane"][0], g["xy"])
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out[:5, 0], [0, 4, 10, 14, 7], atol=1e-6)      # SURVEY probe
+
+
+def test_kplanes_field():
+    g = load_golden("G7b_kplanes_field")
+    planes = [[g[f"plane_{s}_{p}"] for p in range(3)] for s in range(3)]
+    np.testing.assert_allclose(orc.kplanes_features(g["x"], planes), g["feat"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(orc.kplanes_loss_tv(planes), float(g["loss_tv"]), rtol=1e-5)
+    np.testing.assert_allclose(orc.kplanes_loss_l1(planes), float(g["loss_l1"]), rtol=1e-5)
+
+
+def test_vanilla_heads():
+    g = load_golden("G8_vanilla_heads")
+    fm = orc.mlp_layers(sub(g, "fm."), "net.net.")
+    od = orc.mlp_layers(sub(g, "od."), "net.net.")
+    cd = orc.mlp_layers(sub(g, "cd."), "net.net.")
+    feat = orc.vanilla_features(g["x"], fm, g["fm.encoding.freqs"].shape[0])
+    np.testing.assert_allclose(feat, g["feat"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(orc.sigma_decoder(feat, od), g["sigma"], rtol=1e-5, atol=TOL)
+    np.testing.assert_allclose(orc.color_decoder(feat, g["dirs"], cd, 8), g["rgb"], rtol=0, atol=TOL)
+    g2 = load_golden("G8b_decoders_96")
+    od = orc.mlp_layers(sub(g2, "od."), "net.net.")
+    cd = orc.mlp_layers(sub(g2, "cd."), "net.net.")
+    np.testing.assert_allclose(orc.sigma_decoder(g2["feat"], od), g2["sigma"], rtol=1e-5, atol=TOL)
+    np.testing.assert_allclose(orc.color_decoder(g2["feat"], g2["dirs"], cd, 8), g2["rgb"], rtol=0, atol=TOL)
+
+
+def _renderer_fns(sd):
+    planes = [[sd[f"feature_module.planes.{s}.{p}.plane"] for p in range(3)] for s in range(3)]
+    od = orc.mlp_layers(sub(sd, "sigma_decoder."), "net.net.")
+    cd = orc.mlp_layers(sub(sd, "rgb_decoder."), "net.net.")
+    return (lambda x: orc.kplanes_features(x, planes), lambda f: orc.sigma_decoder(f, od),
+            lambda f, d: orc.color_decoder(f, d, cd, 8))
+
+
+def test_renderer_end_to_end():
+    g = load_golden("G9_renderer_kplanes")
+    ffn, sfn, cfn = _renderer_fns(sub(g, "sd."))
+    sig = sfn(ffn(g["packed"][:, :3])).ravel()
+    np.testing.assert_allclose(sig, g["sigma"], rtol=2e-5, atol=TOL)
+    assert int(g["n_terminated"]) > 0
+    out = orc.render(g["packed"], g["info"], ffn, sfn, cfn, g["bg"])
+    np.testing.assert_allclose(out, g["rendered"], rtol=0, atol=TOL)
+    out = orc.render(g["packed"], g["info"], ffn, sfn, cfn, None)
+    np.testing.assert_allclose(out, g["rendered_nobg"], rtol=0, atol=TOL)
+    e = load_golden("G9b_renderer_empty")
+    out = orc.render(np.zeros((0, 7), np.float32), np.zeros((g["info"].shape[0], 2), np.int32), ffn, sfn, cfn, e["bg"])
+    np.testing.assert_allclose(out, e["rendered_empty"], rtol=0, atol=0)
+
+
+def test_cobafa():
+    g = load_golden("G11_cobafa")
+    sd = sub(g, "sd.")
+    basis = [sd[f"basis_grids.{i}.grid"] for i in range(3)]
+    mlp = orc.mlp_layers(sd, "mlp.net.")
+    feat = orc.cobafa_features(g["x"], basis, sd["coef_grid.grid"], g["freqs"], mlp)
+    np.testing.assert_allclose(feat, g["feat"], rtol=0, atol=TOL)
+
+
+def test_ray_generation_fixture():
+    g = load_golden("G12_rays_fixture")
+    o, d = orc.generate_rays(g["cameras"][0], float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]), int(g["w"]), int(g["h"]))
+    np.testing.assert_allclose(d[::25, ::25], g["rays_d_0"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(o[::25, ::25], g["rays_o_0"], rtol=0, atol=0)
+    assert abs(float(g["fx"]) - 277.78) < 0.01          # SURVEY probe: focal of the 200x200 fixture

@@ -1,0 +1,202 @@
+/* tinynerf_hip.h -- C ABI of libtinynerf_hip.so, the MI355X (gfx950) implementation of the
+ * tinynerf ray-marching hot path.
+ *
+ * This is the drop-in boundary.  In the reference the native boundary is a pybind11 module
+ * JIT-built at import time (reference src/core.py:7) with exactly two entry points,
+ *     compute_weights_fwd(sigmas, steps, info, threshold) -> weights      (src/cuda.cu:66-95)
+ *     compute_weights_bwd(sigmas, steps, info, weights, grad) -> grad_sig (src/cuda.cu:97-132)
+ * Everything else on the path is ATen calls made from src/core.py and src/models.py; this
+ * library gives each of those call sites one entry point as well (the cited file:line is
+ * what the function replaces).
+ *
+ * Conventions
+ *  - plain C: raw device pointers + sizes, no torch types; `stream` is a hipStream_t passed as
+ *    void* (NULL = the null stream).  All work is enqueued asynchronously on that stream.
+ *  - every function returns 0 on success, a negative TN_E_* code for a rejected argument, or a
+ *    positive hipError_t; tn_last_error_string() describes the last failure of the calling thread.
+ *  - the caller owns every buffer.  The library never allocates, frees or retains a pointer and
+ *    keeps no mutable global state, so calls are re-entrant (the autograd engine calls the
+ *    backward entry points from its own thread, reference src/core.py:203-207).
+ *  - all tensors are dense row-major fp32 unless stated; `info` is int32 [n_rays,2] = (start,count)
+ *    per ray, the reference's packing_info (src/core.py:165-188); rays own disjoint ranges.
+ */
+#ifndef TINYNERF_HIP_H
+#define TINYNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_ABI_VERSION 1
+
+enum {
+    TN_OK = 0,
+    TN_E_NULL = -1,      /* a required pointer is NULL */
+    TN_E_SIZE = -2,      /* negative / inconsistent / unsupported size */
+    TN_E_CONFIG = -3,    /* unsupported enum or layer configuration */
+    TN_E_ALIGN = -4      /* pointer not aligned as the entry point requires */
+};
+
+const char *tn_last_error_string(void);
+int tn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * a17  NeRF volume-rendering weights            (reference src/cuda.cu:3-58, core.py:192-207)
+ * fwd: per ray T=1; w_k = T*(1-exp(-sigma_k*step_k)); T *= exp(..) while T > threshold; every
+ *      sample of the ray after termination gets 0 (the kernel writes the whole range, `weights`
+ *      does not need to be zeroed).  bwd: cuda.cu:49-56, no early termination.
+ * ------------------------------------------------------------------------------------------ */
+int tn_weights_fwd(const float *sigmas, const float *steps, const int32_t *info, float threshold,
+                   float *weights, int64_t n_samples, int64_t n_rays, void *stream);
+int tn_weights_bwd(const float *sigmas, const float *steps, const int32_t *info,
+                   const float *weights, const float *grad_weights, float *grad_sigmas,
+                   int64_t n_samples, int64_t n_rays, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a18  per-ray compositing                                     (reference core.py:256-265)
+ * rendered[r] = sum_k w_k rgb_k (+ bg*(1-sum_k w_k) if bg != NULL); opacity[r] optional.
+ * bwd: grad_rgbs[k] = w_k*g[r];  grad_weights[k] = <rgb_k, g[r]> - <bg, g[r]>.
+ * ------------------------------------------------------------------------------------------ */
+int tn_composite_fwd(const float *rgbs, const float *weights, const int32_t *info, const float *bg,
+                     float *rendered, float *opacity, int64_t n_samples, int64_t n_rays, void *stream);
+int tn_composite_bwd(const float *rgbs, const float *weights, const int32_t *info, const float *bg,
+                     const float *grad_rendered, float *grad_rgbs, float *grad_weights,
+                     int64_t n_samples, int64_t n_rays, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a5/a6  occupancy grid                                        (reference core.py:93-156)
+ * grid is fp32 [D,H,W]; coords[...,0] indexes W (x), 1 -> H (y), 2 -> D (z), in [-1,1].
+ * ------------------------------------------------------------------------------------------ */
+/* core.py:147-156: out[i] = trilinear(grid, coords[i]) > threshold, bit-exact w.r.t. ATen's
+ * grid_sampler_3d (align_corners=True, zeros padding).  values (optional) receives the taps. */
+int tn_occupancy_query(const float *grid, int D, int H, int W, const float *coords, int64_t n,
+                       float threshold, uint8_t *out, float *values, void *stream);
+/* core.py:136: jittered voxel centres of depth slice `slice`: out[h*W+w] =
+ * -1 + 2*((w,h,slice) + jitter)/(D,H,W) (the reference divides the flipped (x,y,z) index by the
+ * un-flipped size vector; reproduced).  jitter [H,W,3] may be NULL: then a counter-based RNG
+ * keyed by (seed, slice, h, w, c) supplies U[0,1). */
+int tn_occupancy_slice_coords(int D, int H, int W, int slice, const float *jitter, uint64_t seed,
+                              float *coords, void *stream);
+/* core.py:138-143: alpha = 1-exp(-sigma*step); grid = alpha > thr ? 1 : decay*grid, over `n`
+ * consecutive cells starting at grid_cells. */
+int tn_occupancy_apply(float *grid_cells, const float *sigmas, int64_t n, float step_size,
+                       float threshold, float decay, void *stream);
+/* core.py:121-123,144: stats[0] = sum(grid) (fp64), stats[1] = #(grid > threshold) as fp64.
+ * stats is a device buffer of 2 doubles, overwritten. */
+int tn_occupancy_stats(const float *grid, int64_t n, float threshold, double *stats, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a1-a4, a7  ray marching + sample packing                    (reference core.py:11-88,158-188)
+ * ------------------------------------------------------------------------------------------ */
+enum { TN_MARCH_AABB = 0, TN_MARCH_UNBOUNDED = 1 };
+enum { TN_CONTRACT_AABB = 0, TN_CONTRACT_MIP360_INF = 1, TN_CONTRACT_MIP360_L2 = 2 };
+
+typedef struct tn_sampler_desc {
+    int32_t marcher;          /* TN_MARCH_*    (core.py:36-88)                               */
+    int32_t contraction;      /* TN_CONTRACT_* (core.py:11-31)                               */
+    int32_t n_samples;        /* candidates per ray S                                        */
+    int32_t grid_d, grid_h, grid_w;
+    float aabb[6];            /* lo xyz, hi xyz (marcher AABB and/or contraction AABB)       */
+    float near, far;          /* AABB marcher clamp (core.py:81)                             */
+    float step_size;          /* AABB marcher: ||hi-lo||/S as computed by the caller (fp32)  */
+    float threshold;          /* occupancy threshold min(base, mean) (core.py:125-127)       */
+    const float *t_table;     /* unbounded marcher: t[S] and delta[S] (core.py:52-58)        */
+    const float *delta_table;
+    const float *grid;        /* occupancy grid [D,H,W]                                      */
+    const float *jitter;      /* training: U[0,1) [R,S] (core.py:173) or NULL                */
+    uint64_t seed;            /* training with jitter==NULL && use_rng: counter-based RNG    */
+    int32_t use_rng;
+    int32_t reserved;
+} tn_sampler_desc;
+
+/* Stand-alone marcher / contraction calls (core.py:47-59,72-88 and core.py:15-31) with the same
+ * arithmetic as the fused sampler: t,delta [R,S]; coords_out [n,3], mask [n] (AABB only, else NULL). */
+int tn_march_rays(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,
+                  float *t_values, float *step_sizes, void *stream);
+int tn_contract(const tn_sampler_desc *desc, const float *coords, int64_t n, float *coords_out,
+                uint8_t *mask, void *stream);
+
+/* pass 1: per-ray occupancy bitmask ([R, ceil(S/64)] uint64) and kept-sample count. */
+int tn_sample_mask(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d,
+                   int64_t n_rays, uint64_t *maskbits, int32_t *counts, void *stream);
+/* pass 2: info[r] = (exclusive_scan(counts)[r] + base_offset[0], counts[r]); total[0] = sum.
+ * base_offset (device int32, may be NULL = 0) implements run.py:231 `info[:,0] += current_size`. */
+int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32_t *base_offset,
+                   int32_t *info, int32_t *total, void *stream);
+/* pass 3: packed[start_r - base + j] = (contracted xyz, ray dir, step) for the j-th set bit
+ * (core.py:182-186).  ray_ids (optional) receives the ray index of every packed sample. */
+int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d,
+                   int64_t n_rays, const uint64_t *maskbits, const int32_t *info,
+                   const int32_t *base_offset, float *packed, int32_t *ray_ids, int64_t capacity,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a9  positional encoding                                      (reference models.py:30-39)
+ * out[n, c*2F + f] = sin(x[n,c]*freqs[f]), out[n, c*2F + F + f] = cos(..)
+ * ------------------------------------------------------------------------------------------ */
+int tn_posenc_fwd(const float *x, int64_t n, int n_channels, const float *freqs, int n_freqs,
+                  float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a10-a14  fused MLP heads on fp32 MFMA                        (reference models.py:7-89)
+ * One launch evaluates  act_out( W_L ... relu(W_1 relu(W_0 enc(x) + b_0) + b_1) ... + b_L ).
+ * Weights are torch nn.Linear layout [out,in] row-major.
+ * ------------------------------------------------------------------------------------------ */
+enum { TN_ACT_NONE = 0, TN_ACT_EXP_M1 = 1 /* exp(y-1), models.py:74 */, TN_ACT_SIGMOID = 2 };
+enum { TN_ENC_NONE = 0,
+       TN_ENC_POSENC = 1,       /* input = PE_F(x[:, :3])                      (models.py:67)    */
+       TN_ENC_DIR_CAT = 2 };    /* input = cat[PE_F(dirs), dirs, x]            (models.py:87)    */
+#define TN_MLP_MAX_LAYERS 12
+
+typedef struct tn_mlp_desc {
+    int32_t n_layers;                         /* number of Linear layers (>= 1)               */
+    int32_t in_dim;                           /* width of x (before encoding)                 */
+    int32_t dims[TN_MLP_MAX_LAYERS + 1];      /* dims[0] = encoded input width, dims[l+1] = out of layer l */
+    int32_t encoding;                         /* TN_ENC_*                                     */
+    int32_t n_freqs;                          /* F for the encodings                          */
+    int32_t out_activation;                   /* TN_ACT_*                                     */
+    int32_t reserved;
+    const float *weights[TN_MLP_MAX_LAYERS];  /* [dims[l+1], dims[l]]                         */
+    const float *biases[TN_MLP_MAX_LAYERS];   /* [dims[l+1]]                                  */
+} tn_mlp_desc;
+
+/* y [n, dims[n_layers]] = MLP(x [n,in_dim], aux [n,3] (dirs for TN_ENC_DIR_CAT, else NULL)).
+ * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */
+int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
+               float *pre_act, void *stream);
+/* Backward of tn_mlp_fwd: recomputes the hidden activations, accumulates (+=) weight/bias
+ * gradients into grad_weights[l]/grad_biases[l] (same shapes; must be initialised by the caller)
+ * and writes grad_x [n,in_dim] when non-NULL (TN_ENC_POSENC: no grad_x, coords carry no grad;
+ * TN_ENC_DIR_CAT: gradient w.r.t. the feature part x only). */
+int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y,
+               int64_t n, float *const *grad_weights, float *const *grad_biases, float *grad_x,
+               void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a15/a16  K-Planes feature field                              (reference models.py:93-163)
+ * Planes are stored channel-last: plane[s][p] is fp32 [H_s, W_s, C] (torch memory_format
+ * channels_last of the reference's [1,C,H,W] parameter, so the state_dict shape is unchanged).
+ * feat[n, s*C + c] = prod_p bilinear(plane[s][p], x[n, pair_p])[c], pairs (0,1),(0,2),(1,2).
+ * ------------------------------------------------------------------------------------------ */
+#define TN_KPLANES_MAX_SCALES 4
+typedef struct tn_kplanes_desc {
+    int32_t n_scales;
+    int32_t channels;                               /* C, multiple of 4, <= 32              */
+    int32_t height[TN_KPLANES_MAX_SCALES];
+    int32_t width[TN_KPLANES_MAX_SCALES];
+    const float *planes[TN_KPLANES_MAX_SCALES][3];  /* [H,W,C] each                          */
+} tn_kplanes_desc;
+
+/* x has row stride x_stride floats (7 when reading packed_samples directly, 3 for [n,3]). */
+int tn_kplanes_fwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
+                   float *feat, void *stream);
+/* grad_planes[s][p] ([H,W,C], += via atomics; caller initialises) from grad_feat [n, S*C]. */
+int tn_kplanes_bwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
+                   const float *grad_feat, float *const (*grad_planes)[3], void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYNERF_HIP_H */

@@ -1,0 +1,81 @@
+"""CPU checks of the drop-in boundary: the library builds, loads, and exports every symbol that
+include/tinynerf_hip.h declares; descriptor structs have the C layout; the product has no CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tinynerf_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tinynerf_amd import build
+    path = build.build(verbose=False)
+    return ctypes.CDLL(path)
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_reference_boundary():
+    names = declared_functions()
+    assert "tn_weights_fwd" in names and "tn_weights_bwd" in names      # cuda.cu:134-137
+    assert len(names) >= 15
+
+
+def test_every_declared_symbol_is_exported(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.tn_abi_version() == 1
+
+
+def test_struct_layouts_match_c(tmp_path):
+    """sizeof/offsetof of the ctypes mirrors == what a C compiler sees."""
+    from tinynerf_amd import _lib as L
+    prog = tmp_path / "layout.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tinynerf_hip.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tn_sampler_desc), offsetof(tn_sampler_desc, t_table),'
+                    'offsetof(tn_sampler_desc, seed), sizeof(tn_mlp_desc), offsetof(tn_mlp_desc, weights),'
+                    'offsetof(tn_mlp_desc, biases), sizeof(tn_kplanes_desc), offsetof(tn_kplanes_desc, planes));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(L.SamplerDesc), L.SamplerDesc.t_table.offset, L.SamplerDesc.seed.offset,
+            ctypes.sizeof(L.MlpDesc), L.MlpDesc.weights.offset, L.MlpDesc.biases.offset,
+            ctypes.sizeof(L.KPlanesDesc), L.KPlanesDesc.planes.offset]
+    assert got == want
+
+
+def test_argument_errors_are_reported(lib):
+    lib.tn_last_error_string.restype = ctypes.c_char_p
+    rc = lib.tn_weights_fwd(None, None, None, ctypes.c_float(1e-4), None, ctypes.c_int64(4), ctypes.c_int64(2), None)
+    assert rc == -1 and b"null" in lib.tn_last_error_string()
+    rc = lib.tn_weights_fwd(None, None, None, ctypes.c_float(1e-4), None, ctypes.c_int64(-1), ctypes.c_int64(2), None)
+    assert rc == -2
+
+
+def test_no_cpu_path():
+    """CPU tensors are rejected like the reference's CHECK_CUDA (cuda.cu:62) -- no fallback."""
+    from tinynerf_amd import core
+    with pytest.raises(RuntimeError):
+        core.NerfWeights.apply(torch.rand(4), torch.rand(4), torch.tensor([[0, 4]], dtype=torch.int32), 1e-4)
+    g = core.OccupancyGrid(8, 0.1)
+    with pytest.raises(RuntimeError):
+        g(torch.zeros(3, 3))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "tinynerf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)

@@ -1,0 +1,276 @@
+"""GPU parity tests of the renderer core (tinynerf_amd.core -> libtinynerf_hip.so) against the CPU
+oracle and the golden vectors captured from the reference.  Integer / index work and sampled
+coordinates: bit-exact.  Floating point: 1e-5 (north star), tolerance stated per assert."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import tinynerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-5
+
+
+def cu(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).to(DEV)
+
+
+def bits(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+def core():
+    from tinynerf_amd import core as c
+    return c
+
+
+def ragged(rng, n_rays, max_len, p_empty=0.1):
+    cnt = rng.integers(1, max_len + 1, n_rays).astype(np.int32)
+    cnt[rng.random(n_rays) < p_empty] = 0
+    start = (np.cumsum(cnt) - cnt).astype(np.int32)
+    return np.stack([start, cnt], -1), int(cnt.sum())
+
+
+def danger_rays(s, d, info, thr, rel=1e-4):
+    """rays whose transmittance passes within `rel` of the threshold: the termination index there
+    depends on the last ulp of exp(), which no two libm/GPU implementations share."""
+    bad = np.zeros(info.shape[0], bool)
+    for r, (a, c) in enumerate(info):
+        T = np.concatenate([[1.0], np.cumprod(np.exp(-s[a:a + c].astype(np.float64) * d[a:a + c]))])
+        bad[r] = (np.abs(T - thr) < rel * thr).any()
+    return bad
+
+
+# ------------------------------------------------------------------ weights (a17)
+@pytest.mark.parametrize("max_len,n_rays", [(40, 300), (1024, 64), (3000, 5)])
+def test_weights_fwd_bwd_vs_oracle(max_len, n_rays):
+    rng = np.random.default_rng(max_len)
+    info, n = ragged(rng, n_rays, max_len)
+    s = (rng.random(n) * (60.0 if max_len > 100 else 30.0)).astype(np.float32)
+    d = (rng.random(n) * (0.01 if max_len > 100 else 0.08) + 0.001).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    w_ref = orc.weights_fwd(s, d, info, 1e-4)
+    st = cu(s).requires_grad_(True)
+    w = core().NerfWeights.apply(st, cu(d), cu(info, torch.int32), 1e-4)
+    ok = ~np.repeat(danger_rays(s, d, info, 1e-4), info[:, 1])
+    np.testing.assert_allclose(w.detach().cpu().numpy()[ok], w_ref[ok], rtol=0, atol=1e-6)
+    assert (w_ref == 0).any() and np.array_equal((w.detach().cpu().numpy() == 0)[ok], (w_ref == 0)[ok])
+    w.backward(cu(g))
+    gs_ref = orc.weights_bwd(s, d, info, w_ref, g)
+    np.testing.assert_allclose(st.grad.cpu().numpy()[ok], gs_ref[ok], rtol=1e-4, atol=TOL)
+
+
+def test_weights_edge_cases():
+    c = core()
+    # empty ray list, all-empty rays, single-sample ray
+    w = c.NerfWeights.apply(torch.rand(0, device=DEV), torch.rand(0, device=DEV), torch.zeros((3, 2), dtype=torch.int32, device=DEV), 1e-4)
+    assert w.numel() == 0
+    info = torch.tensor([[0, 1], [1, 0], [1, 2]], dtype=torch.int32, device=DEV)
+    s = torch.tensor([2.0, 3.0, 1.0], device=DEV); d = torch.tensor([0.5, 0.25, 0.1], device=DEV)
+    w = c.NerfWeights.apply(s, d, info, 1e-4).cpu().numpy()
+    np.testing.assert_allclose(w[0], 1 - np.exp(-1.0), rtol=1e-6)
+    np.testing.assert_allclose(w[2], np.exp(-0.75) * (1 - np.exp(-0.1)), rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        c.NerfWeights.apply(s, d, info.long(), 1e-4)          # info must be int32 (cuda.cu:89)
+
+
+def test_weights_full_size_properties():
+    """BASELINE size (N = 2^20): sum_k w_k = 1 - T_end and w >= 0, checked without the oracle."""
+    rng = np.random.default_rng(0)
+    info, n = ragged(rng, 8192, 256, 0.05)
+    s = torch.rand(n, device=DEV) * 20; d = torch.full((n,), 0.005, device=DEV)
+    it = cu(info, torch.int32)
+    w = core().NerfWeights.apply(s, d, it, 0.0)
+    seg = torch.repeat_interleave(torch.arange(info.shape[0], device=DEV), it[:, 1].long())
+    opac = torch.zeros(info.shape[0], device=DEV, dtype=torch.float64).index_add_(0, seg, w.double())
+    logT = torch.zeros(info.shape[0], device=DEV, dtype=torch.float64).index_add_(0, seg, (-s * d).double())
+    np.testing.assert_allclose(opac.cpu().numpy(), (1 - torch.exp(logT)).cpu().numpy(), atol=2e-5)
+    assert (w >= 0).all()
+
+
+# ------------------------------------------------------------------ composite (a18)
+def test_composite_fwd_bwd_vs_oracle():
+    rng = np.random.default_rng(7)
+    info, n = ragged(rng, 200, 90)
+    rgb = rng.random((n, 3)).astype(np.float32); w = (rng.random(n) * 0.05).astype(np.float32)
+    w[rng.random(n) < 0.3] = 0
+    bg = np.array([1.0, 0.5, 0.25], np.float32)
+    from tinynerf_amd.core import _Composite
+    for b in (bg, None):
+        rt, wt = cu(rgb).requires_grad_(True), cu(w).requires_grad_(True)
+        out = _Composite.apply(rt, wt, cu(info, torch.int32), None if b is None else cu(b))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), orc.composite(rgb * (w[:, None] != 0), w, info, b), atol=TOL)
+        go = rng.standard_normal((info.shape[0], 3)).astype(np.float32)
+        out.backward(cu(go))
+        seg = np.repeat(np.arange(info.shape[0]), info[:, 1])
+        np.testing.assert_allclose(rt.grad.cpu().numpy(), w[:, None] * go[seg], atol=TOL)
+        gw = ((rgb * (w[:, None] != 0)) * go[seg]).sum(-1) - (0 if b is None else (b[None] * go[seg]).sum(-1))
+        np.testing.assert_allclose(wt.grad.cpu().numpy(), gw, atol=TOL)
+
+
+# ------------------------------------------------------------------ marchers / contractions (a1-a4)
+def test_march_aabb_bit_exact():
+    c = core()
+    for name in ("G1_march_aabb", "G1b_march_aabb_asym"):
+        g = load_golden(name)
+        m = c.RayMarcherAABB(cu(g["aabb"]), int(g["n_samples"]), float(g["near"]), float(g["far"]))
+        assert bits(m.step_size) == bits(g["step_size"])
+        t, dl = m(cu(g["rays_o"]), cu(g["rays_d"]))
+        assert np.array_equal(bits(t), bits(g["t"])) and np.array_equal(bits(dl), bits(g["delta"]))
+        if "coords" in g:
+            pts = cu(g["rays_o"])[:, None, :] + cu(g["rays_d"])[:, None, :] * t[..., None]
+            cc, mask = c.ContractionAABB(cu(g["aabb"]))(pts)
+            assert np.array_equal(mask.cpu().numpy(), g["mask"])
+            assert np.array_equal(bits(cc), bits(g["coords"]))
+
+
+@pytest.mark.parametrize("S", [8, 200, 1000])
+def test_march_unbounded(S):
+    c = core()
+    g = load_golden(f"G2_unbounded_S{S}")
+    m = c.RayMarcherUnbounded(S, float(g["near"]), 1e5, float(g["uniform_range"]))
+    t, dl = m(cu(g["rays_o"]), cu(g["rays_d"]))
+    assert t.shape == (g["rays_o"].shape[0], S)
+    # torch.linspace on the device rounds differently from the CPU kernel (both are "torch"): 1-ulp class
+    np.testing.assert_allclose(t[0].cpu().numpy(), g["t_row"], rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(dl[0].cpu().numpy(), g["delta_row"], rtol=2e-3, atol=2e-6)
+    # contraction itself is bit-exact when fed identical points
+    tt = cu(g["t_row"])
+    pts = cu(g["rays_o"])[:, None, :] + cu(g["rays_d"])[:, None, :] * tt[None, :, None]
+    cc, mask = c.ContractionMip360(float("inf"))(pts)
+    assert mask is None and np.array_equal(bits(cc), bits(g["coords_inf"]))
+    cc2, _ = c.ContractionMip360(2)(pts)
+    np.testing.assert_allclose(cc2.cpu().numpy(), g["coords_l2"], atol=2e-7)
+
+
+# ------------------------------------------------------------------ occupancy (a5, a6)
+def test_occupancy_query_bit_exact():
+    c = core()
+    g = load_golden("G3_occupancy_query")
+    og = c.OccupancyGrid(list(g["grid"].shape), 1 / 1024.).to(DEV)
+    og.grid.copy_(cu(g["grid"]))
+    og.mean = float(g["grid"].mean())
+    assert og.threshold == pytest.approx(float(g["threshold"]))
+    assert np.array_equal(og(cu(g["coords"])).cpu().numpy(), g["occupied"])
+    # raw interpolated values through the C ABI: bit-exact vs ATen's CPU grid_sampler_3d
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    vals = torch.empty(g["coords"].shape[0], device=DEV)
+    D, H, W = g["grid"].shape
+    L.call("tn_occupancy_query", vals.device, L.ptr(og.grid), C.c_int(D), C.c_int(H), C.c_int(W), L.ptr(cu(g["coords"])),
+           C.c_int64(vals.numel()), C.c_float(0.01), C.c_void_p(None), L.ptr(vals))
+    assert np.array_equal(bits(vals), bits(g["values"]))
+
+
+def test_occupancy_reference_known_answer():
+    """reference tests/test_core.py:5-38."""
+    c = core()
+    g = load_golden("G3b_reference_known_answer")
+    og = c.OccupancyGrid(128, 1 / 1024.).to(DEV)
+    og.grid[:, :, 64:] = 0.
+    assert og.grid.sum().item() >= og.grid.numel() / 3. and og.grid.sum().item() <= 2. * og.grid.numel() / 3.
+    assert np.array_equal(og(cu(g["coords"])).cpu().numpy(), g["occupied"])
+    assert og.occupancy() == pytest.approx(0.5)
+
+
+def test_occupancy_update_vs_golden():
+    c = core()
+    from tinynerf_amd import models
+    g = load_golden("G5_occupancy_update")
+    fm = models.VanillaFeatureMLP(4, 32, 2); od = models.VanillaOpacityDecoder(32)
+    fm.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("fm.")})
+    od.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("od.")})
+    fm.to(DEV); od.to(DEV)
+    og = c.OccupancyGrid(list(g["grid_after_1"].shape), float(g["step_size"]), float(g["base_threshold"]), float(g["decay"])).to(DEV)
+    og.update(lambda x: od(fm(x)), jitters=cu(g["jitters"]))
+    got = og.grid.cpu().numpy()
+    assert (got != g["grid_after_1"]).mean() < 2e-3          # a flip needs alpha within ~1e-6 of thr
+    assert og.mean == pytest.approx(float(g["mean_after_1"]), abs=2e-3)
+    assert og.occupancy() == pytest.approx(float(g["occupancy_after_1"]), abs=2e-3)
+    og.update(lambda x: od(fm(x)))                            # device-RNG path runs
+    assert 0 < og.occupancy() < 1
+
+
+# ------------------------------------------------------------------ RayProvider (a7)
+def _provider(g, kind):
+    c = core()
+    og = c.OccupancyGrid(list(g["grid"].shape), 1 / 1024.).to(DEV)
+    og.grid.copy_(cu(g["grid"]))
+    og.mean = float(g["threshold"]) if float(g["threshold"]) < 0.01 else 1.0
+    S = int(g["n_samples"])
+    if kind == "aabb":
+        aabb = cu(g["aabb"])
+        return c.RayProvider(og, c.ContractionAABB(aabb), c.RayMarcherAABB(aabb, S, float(g["near"])))
+    m = c.RayMarcherUnbounded(S, float(g["near"]), 1e5, float(g["uniform_range"]))
+    t, dl = orc.unbounded_table(S, float(g["near"]), float(g["uniform_range"]))
+    m._tables[str(torch.device(DEV, torch.cuda.current_device()))] = (cu(t), cu(dl))    # CPU-linspace table for bit parity
+    return c.RayProvider(og, c.ContractionMip360(float("inf")), m)
+
+
+@pytest.mark.parametrize("name,kind", [("G4_ray_provider_aabb", "aabb"), ("G4b_ray_provider_unbounded", "unbounded")])
+def test_ray_provider_bit_exact(name, kind):
+    g = load_golden(name)
+    rp = _provider(g, kind)
+    o, d = cu(g["rays_o"]), cu(g["rays_d"])
+    packed, info = rp(o, d, training=False)
+    assert info.dtype == torch.int32 and np.array_equal(info.cpu().numpy(), g["info"])
+    assert np.array_equal(bits(packed), bits(g["packed"]))
+    packed, info, ids = rp(o, d, training=True, jitter=cu(g["jitter"]), return_ray_ids=True)
+    assert np.array_equal(info.cpu().numpy(), g["info_jit"])
+    assert np.array_equal(bits(packed), bits(g["packed_jit"]))
+    assert np.array_equal(ids.cpu().numpy(), np.repeat(np.arange(info.shape[0]), g["info_jit"][:, 1]))
+    # device-RNG jitter: same structure, different draws
+    p2, i2 = rp(o, d, training=True)
+    assert i2.shape == info.shape and p2.shape[1] == 7 and int(i2[:, 1].sum()) == p2.shape[0]
+
+
+def test_ray_provider_large_vs_oracle():
+    """config-3 geometry at a size the oracle finishes in seconds: 800x800-style rays, 128^3 grid with
+    an occupied ball, S = 256."""
+    c = core()
+    rng = np.random.default_rng(11)
+    R, S = 2048, 256
+    o = rng.standard_normal((R, 3)); o = (o / np.linalg.norm(o, axis=1, keepdims=True) * 4.0311).astype(np.float32)
+    d = -o + 0.4 * rng.standard_normal((R, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, 128, dtype=np.float32)] * 3, indexing="ij")
+    decay = np.float32(0.01 ** (1 / 16))
+    grid = np.where(xx ** 2 + yy ** 2 + zz ** 2 < 0.25, np.float32(1), decay ** rng.integers(1, 24, (128,) * 3)).astype(np.float32)
+    aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
+    jit = rng.random((R, S)).astype(np.float32)
+    p_ref, i_ref = orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=0.01, n_samples=S,
+                                    near=0.1, aabb=aabb, jitter=jit)
+    og = c.OccupancyGrid(128, 1 / 1024.).to(DEV); og.grid.copy_(cu(grid))
+    rp = c.RayProvider(og, c.ContractionAABB(cu(aabb)), c.RayMarcherAABB(cu(aabb), S, 0.1))
+    p, i = rp(cu(o), cu(d), training=True, jitter=cu(jit))
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.array_equal(bits(p), bits(p_ref))
+    assert 0.02 < p.shape[0] / (R * S) < 0.9
+
+
+def test_ray_provider_full_size_properties():
+    """BASELINE config-3 size (S = 1024, B = 1024 x 8 loader batches): structure invariants."""
+    c = core()
+    R, S = 8192, 1024
+    o = torch.nn.functional.normalize(torch.randn(R, 3, device=DEV), dim=-1) * 4.0311
+    d = torch.nn.functional.normalize(-o + 0.3 * torch.randn(R, 3, device=DEV), dim=-1)
+    aabb = torch.tensor([[-1.5] * 3, [1.5] * 3], device=DEV)
+    og = c.OccupancyGrid(128, 1 / 1024.).to(DEV)
+    og.grid[:, :, 64:] = 0.
+    rp = c.RayProvider(og, c.ContractionAABB(aabb), c.RayMarcherAABB(aabb, S, 0.1))
+    p, i = rp(o, d, training=True)
+    cnt = i[:, 1].long()
+    assert int(cnt.sum()) == p.shape[0] and (cnt <= S).all()
+    assert torch.equal(i[:, 0].long(), torch.cumsum(cnt, 0) - cnt)             # exclusive scan
+    assert (p[:, :3].abs() <= 1).all() and (p[:, 0] <= 1e-2).all()             # occupied half only (x<0 + interp margin)
+    assert torch.equal(p[:, 3:6], torch.repeat_interleave(d, cnt, 0))          # dirs repeated per ray
+    assert (p[:, 6] == float(rp.ray_marcher.step_size)).all()
+    # idempotence: same seedless inference call twice -> identical packing
+    p1, i1 = rp(o, d, training=False); p2, i2 = rp(o, d, training=False)
+    assert torch.equal(p1, p2) and torch.equal(i1, i2)
+    # empty input
+    p0, i0 = rp(o[:0], d[:0], training=False)
+    assert p0.shape == (0, 7) and i0.shape == (0, 2)

@@ -1,0 +1,106 @@
+"""ctypes binding of libtinynerf_hip.so (C ABI: include/tinynerf_hip.h).
+
+The product path has no CPU fallback: if the library is missing the first call raises
+``RuntimeError``.  torch is only used for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinynerf_hip.so")
+
+TN_MLP_MAX_LAYERS = 12
+TN_KPLANES_MAX_SCALES = 4
+
+MARCH_AABB, MARCH_UNBOUNDED = 0, 1
+CONTRACT_AABB, CONTRACT_MIP360_INF, CONTRACT_MIP360_L2 = 0, 1, 2
+ACT_NONE, ACT_EXP_M1, ACT_SIGMOID = 0, 1, 2
+ENC_NONE, ENC_POSENC, ENC_DIR_CAT = 0, 1, 2
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [
+        ("marcher", C.c_int32), ("contraction", C.c_int32), ("n_samples", C.c_int32),
+        ("grid_d", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
+        ("aabb", C.c_float * 6), ("near", C.c_float), ("far", C.c_float),
+        ("step_size", C.c_float), ("threshold", C.c_float),
+        ("t_table", C.c_void_p), ("delta_table", C.c_void_p), ("grid", C.c_void_p), ("jitter", C.c_void_p),
+        ("seed", C.c_uint64), ("use_rng", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("in_dim", C.c_int32), ("dims", C.c_int32 * (TN_MLP_MAX_LAYERS + 1)),
+        ("encoding", C.c_int32), ("n_freqs", C.c_int32), ("out_activation", C.c_int32), ("reserved", C.c_int32),
+        ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
+    ]
+
+
+class KPlanesDesc(C.Structure):
+    _fields_ = [
+        ("n_scales", C.c_int32), ("channels", C.c_int32),
+        ("height", C.c_int32 * TN_KPLANES_MAX_SCALES), ("width", C.c_int32 * TN_KPLANES_MAX_SCALES),
+        ("planes", (C.c_void_p * 3) * TN_KPLANES_MAX_SCALES),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernels were not built. Run `python -m tinynerf_amd.build` "
+                "(needs hipcc). tinynerf_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.tn_last_error_string.restype = C.c_char_p
+    return _lib
+
+
+def check(rc: int, fn: str) -> None:
+    if rc != 0:
+        msg = lib().tn_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{fn} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(None) if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> torch.device:
+    """Mirror of the reference's CHECK_CUDA / CHECK_CONTIGUOUS (src/cuda.cu:62-64)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
+        if not t.is_contiguous():
+            raise RuntimeError("tinynerf_amd: tensor must be contiguous")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("tinynerf_amd: tensors are on different devices")
+    assert dev is not None
+    return dev
+
+
+def call(name: str, device: torch.device, *args) -> None:
+    """Invoke entry point `name` on `device`'s current stream (appended as the last argument)."""
+    fn = getattr(lib(), name)
+    with torch.cuda.device(device):
+        rc = fn(*args, stream(device))
+    check(rc, name)

@@ -1,0 +1,425 @@
+"""Renderer core with the API of the reference's ``src/core.py``, backed by HIP kernels.
+
+Same class names, constructor signatures and call conventions as the reference so that a
+``train.py``-style harness can switch imports; every tensor operation goes through
+``libtinynerf_hip.so`` (C ABI ``include/tinynerf_hip.h``) on the current HIP stream.  There is no
+CPU path: CPU tensors raise ``RuntimeError`` exactly like the reference's ``CHECK_CUDA``.
+
+Reference map: ContractionMip360/AABB core.py:11-31, RayMarcherUnbounded/AABB core.py:36-88,
+OccupancyGrid core.py:93-156, RayProvider core.py:158-188, NerfWeights core.py:192-207,
+NerfRenderer core.py:209-267.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from functools import cached_property
+from typing import Any, Callable, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+def _fill_aabb(desc: L.SamplerDesc, aabb: torch.Tensor) -> None:
+    vals = [float(v) for v in aabb.detach().to("cpu", torch.float32).reshape(-1).tolist()]
+    for i in range(6):
+        desc.aabb[i] = vals[i]
+
+
+# --------------------------------------------------------------------------------------------
+# contractions (reference core.py:11-31)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ContractionMip360:
+    order: float | int = float("inf")
+
+    def _code(self) -> int:
+        if math.isinf(float(self.order)):
+            return L.CONTRACT_MIP360_INF
+        if float(self.order) == 2.0:
+            return L.CONTRACT_MIP360_L2
+        raise NotImplementedError("ContractionMip360 supports order inf and 2")
+
+    def _describe(self, desc: L.SamplerDesc) -> None:
+        desc.contraction = self._code()
+
+    @torch.no_grad()
+    def __call__(self, coords: torch.Tensor) -> Tuple[torch.Tensor, None]:
+        """Mip-NeRF 360 contraction, halved into [-1,1] (core.py:15-20)."""
+        desc = L.SamplerDesc(n_samples=1)
+        self._describe(desc)
+        x = _f32c(coords)
+        dev = L.require_cuda(x)
+        out = torch.empty_like(x)
+        L.call("tn_contract", dev, C.byref(desc), L.ptr(x), C.c_int64(x.numel() // 3), L.ptr(out), C.c_void_p(None))
+        return out, None
+
+
+@dataclass
+class ContractionAABB:
+    aabb: torch.Tensor  # [2,3]
+
+    def _describe(self, desc: L.SamplerDesc) -> None:
+        desc.contraction = L.CONTRACT_AABB
+        _fill_aabb(desc, self.aabb)
+
+    @torch.no_grad()
+    def __call__(self, coords: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Map the box to [-1,1]^3 and flag points inside it (core.py:26-31)."""
+        desc = L.SamplerDesc(n_samples=1)
+        self._describe(desc)
+        x = _f32c(coords)
+        dev = L.require_cuda(x)
+        out = torch.empty_like(x)
+        mask = torch.empty(x.shape[:-1], dtype=torch.uint8, device=dev)
+        L.call("tn_contract", dev, C.byref(desc), L.ptr(x), C.c_int64(x.numel() // 3), L.ptr(out), L.ptr(mask))
+        return out, mask.bool()
+
+
+Contraction = ContractionMip360 | ContractionAABB
+
+
+# --------------------------------------------------------------------------------------------
+# ray marchers (reference core.py:36-88)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class RayMarcherUnbounded:
+    n_samples: int = 200
+    near: float = 0.
+    far: float = 1e5
+    uniform_range: float = 1.
+    _tables: dict = field(default_factory=dict, repr=False, compare=False)
+
+    @cached_property
+    def step_size(self) -> float:
+        return self.uniform_range / self.n_samples
+
+    def _table(self, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """t[S], delta[S] of core.py:52-55.  The table is built once per device with
+        torch.linspace (a torch primitive whose rounding the reference inherits as well)."""
+        key = str(device)
+        if key not in self._tables:
+            S = self.n_samples
+            u = torch.linspace(0., 1. - (1. / (S + 2)), S + 1, device=device)
+            fu = torch.where(u < 0.5, 2 * u, 1 / (2 - 2 * u))
+            t = fu * self.uniform_range + self.near
+            self._tables[key] = (t[:-1].contiguous(), (t[1:] - t[:-1]).contiguous())
+        return self._tables[key]
+
+    def _describe(self, desc: L.SamplerDesc, device: torch.device) -> None:
+        t, dl = self._table(device)
+        desc.marcher = L.MARCH_UNBOUNDED
+        desc.n_samples = self.n_samples
+        desc.t_table = t.data_ptr()
+        desc.delta_table = dl.data_ptr()
+
+    @torch.no_grad()
+    def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        dev = L.require_cuda(_f32c(rays_o))
+        t, dl = self._table(dev)
+        n = rays_o.size(0)
+        return torch.broadcast_to(t, (n, self.n_samples)), torch.broadcast_to(dl, (n, self.n_samples))
+
+
+@dataclass
+class RayMarcherAABB:
+    aabb: torch.Tensor
+    n_samples: int = 200
+    near: float = 0.
+    far: float = 1e5
+
+    @cached_property
+    def step_size(self) -> torch.Tensor:
+        # 0-dim fp32 tensor like the reference (core.py:68-70)
+        return torch.norm(self.aabb[1] - self.aabb[0]) / self.n_samples
+
+    def _describe(self, desc: L.SamplerDesc, device: torch.device) -> None:
+        desc.marcher = L.MARCH_AABB
+        desc.n_samples = self.n_samples
+        desc.near = self.near
+        desc.far = self.far
+        desc.step_size = float(self.step_size)
+        _fill_aabb(desc, self.aabb)
+
+    @torch.no_grad()
+    def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        o, d = _f32c(rays_o), _f32c(rays_d)
+        dev = L.require_cuda(o, d)
+        desc = L.SamplerDesc()
+        self._describe(desc, dev)
+        n = o.size(0)
+        t = torch.empty((n, self.n_samples), device=dev)
+        dl = torch.empty_like(t)
+        L.call("tn_march_rays", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(n), L.ptr(t), L.ptr(dl))
+        return t, dl
+
+
+RayMarcher = RayMarcherUnbounded | RayMarcherAABB
+
+
+# --------------------------------------------------------------------------------------------
+# occupancy grid (reference core.py:93-156)
+# --------------------------------------------------------------------------------------------
+class OccupancyGrid(torch.nn.Module):
+    def __init__(
+        self,
+        size: List[int] | int,  # [depth, height, width]
+        step_size: float,
+        threshold: float = 0.01,
+        decay: float = 0.95,
+    ):
+        super().__init__()
+        size = list(size) if isinstance(size, (list, tuple)) else [size, size, size]
+        self.decay = decay
+        self.step_size = step_size
+        self.base_threshold = threshold
+        self.grid: torch.Tensor
+        self.register_buffer("grid", torch.ones(size, dtype=torch.float))
+        self.size = torch.tensor(size, dtype=torch.float)
+        self.mean = 1.
+        self._dims = tuple(int(s) for s in size)
+
+    @property
+    def threshold(self) -> float:
+        return min(self.base_threshold, self.mean)
+
+    @property
+    def device(self) -> torch.device:
+        return self.grid.device
+
+    def _stats(self) -> Tuple[float, float]:
+        dev = L.require_cuda(self.grid)
+        stats = torch.empty(2, dtype=torch.float64, device=dev)
+        L.call("tn_occupancy_stats", dev, L.ptr(self.grid), C.c_int64(self.grid.numel()),
+               C.c_float(self.threshold), L.ptr(stats))
+        s, c = stats.tolist()
+        return s, c
+
+    @torch.no_grad()
+    def occupancy(self) -> float:
+        """Fraction of cells above the threshold (core.py:121-123)."""
+        return self._stats()[1] / self.grid.numel()
+
+    @torch.no_grad()
+    def update(self, sigma_fn: Callable[[torch.Tensor], torch.Tensor], jitters: Optional[torch.Tensor] = None,
+               slices_per_call: Optional[int] = None):
+        """Decay/refresh sweep of core.py:133-145.
+
+        Voxel centres are jittered on the device by a counter-based RNG seeded from torch's
+        generator (``jitters`` [D,H,W,3] overrides it for parity runs).  The threshold is constant
+        during a sweep, so slices are independent: ``slices_per_call`` of them are evaluated by one
+        ``sigma_fn`` call (default: as many as give <= 2^21 points) instead of one call per slice.
+        """
+        D, H, W = self._dims
+        dev = L.require_cuda(self.grid)
+        thr = float(self.threshold)
+        step = float(self.step_size)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        per = slices_per_call or max(1, min(D, (1 << 21) // (H * W)))
+        coords = torch.empty((per * H * W, 3), device=dev)
+        for i0 in range(0, D, per):
+            n_sl = min(per, D - i0)
+            for j in range(n_sl):
+                jit = None if jitters is None else _f32c(jitters[i0 + j]).to(dev)
+                L.call("tn_occupancy_slice_coords", dev, C.c_int(D), C.c_int(H), C.c_int(W), C.c_int(i0 + j),
+                       L.ptr(jit), C.c_uint64(seed), C.c_void_p(coords.data_ptr() + j * H * W * 12))
+            pts = coords[: n_sl * H * W]
+            sig = _f32c(sigma_fn(pts).detach().reshape(-1))
+            cells = self.grid[i0:i0 + n_sl]
+            L.call("tn_occupancy_apply", dev, L.ptr(cells), L.ptr(sig), C.c_int64(n_sl * H * W),
+                   C.c_float(step), C.c_float(thr), C.c_float(self.decay))
+        self.mean = self._stats()[0] / self.grid.numel()
+
+    @torch.no_grad()
+    def forward(self, coords: torch.Tensor) -> torch.Tensor:
+        """coords [...,3] in [-1,1] -> bool, trilinear lookup > threshold (core.py:147-156)."""
+        x = _f32c(coords)
+        dev = L.require_cuda(x, self.grid)
+        D, H, W = self._dims
+        out = torch.empty(x.shape[:-1], dtype=torch.uint8, device=dev)
+        L.call("tn_occupancy_query", dev, L.ptr(self.grid), C.c_int(D), C.c_int(H), C.c_int(W), L.ptr(x),
+               C.c_int64(x.numel() // 3), C.c_float(self.threshold), L.ptr(out), C.c_void_p(None))
+        return out.bool()
+
+
+# --------------------------------------------------------------------------------------------
+# sample packing (reference core.py:158-188)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class RayProvider:
+    occupancy_grid: OccupancyGrid
+    contraction: Contraction
+    ray_marcher: RayMarcher
+
+    def _desc(self, device: torch.device, training: bool, jitter: Optional[torch.Tensor]) -> L.SamplerDesc:
+        desc = L.SamplerDesc()
+        self.ray_marcher._describe(desc, device)
+        self.contraction._describe(desc)
+        g = self.occupancy_grid
+        desc.grid_d, desc.grid_h, desc.grid_w = g._dims
+        desc.grid = g.grid.data_ptr()
+        desc.threshold = float(g.threshold)
+        if jitter is not None:
+            desc.jitter = jitter.data_ptr()
+        elif training:
+            desc.use_rng = 1
+            desc.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return desc
+
+    @torch.no_grad()
+    def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor, training: bool,
+                 jitter: Optional[torch.Tensor] = None, return_ray_ids: bool = False):
+        """packed_samples [N,7] = (contracted xyz, ray dir, step), packing_info [R,2] int32 =
+        (start,count) -- core.py:165-188.  ``jitter`` ([R,S] U[0,1)) replaces the device RNG that
+        stands in for ``torch.rand_like`` when ``training`` (parity runs)."""
+        o, d = _f32c(rays_o), _f32c(rays_d)
+        dev = L.require_cuda(o, d, self.occupancy_grid.grid)
+        R = o.size(0)
+        S = self.ray_marcher.n_samples
+        if jitter is not None:
+            jitter = _f32c(jitter)
+            L.require_cuda(jitter)
+        desc = self._desc(dev, training, jitter)
+        n_chunks = (S + 63) // 64
+        maskbits = torch.empty((R, n_chunks), dtype=torch.int64, device=dev)
+        counts = torch.empty(R, dtype=torch.int32, device=dev)
+        info = torch.empty((R, 2), dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(counts))
+        L.call("tn_sample_scan", dev, L.ptr(counts), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
+        n = int(total.item())                      # the one host sync: the output shape
+        packed = torch.empty((n, 7), device=dev)
+        ray_ids = torch.empty(n, dtype=torch.int32, device=dev) if return_ray_ids else None
+        L.call("tn_sample_pack", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(info),
+               C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), C.c_int64(n))
+        if return_ray_ids:
+            return packed, info, ray_ids
+        return packed, info
+
+
+# --------------------------------------------------------------------------------------------
+# rendering (reference core.py:192-267)
+# --------------------------------------------------------------------------------------------
+def _check_info(info: torch.Tensor) -> None:
+    if info.dtype != torch.int32 or info.dim() != 2 or info.size(1) != 2:
+        raise RuntimeError("packing_info must be an int32 tensor of shape [n_rays, 2]")
+
+
+class NerfWeights(torch.autograd.Function):
+    """w_k = T_k (1 - exp(-sigma_k delta_k)) with early termination (core.py:192-207, cuda.cu:3-58)."""
+
+    @staticmethod
+    def forward(ctx: Any, sigmas: torch.Tensor, steps: torch.Tensor, info: torch.Tensor, threshold: float) -> torch.Tensor:  # type: ignore
+        sigmas = sigmas.contiguous()
+        steps = steps.contiguous()
+        info = info.contiguous()
+        if sigmas.dim() != 1 or steps.dim() != 1:
+            raise RuntimeError("sigmas and steps must be 1-D")
+        _check_info(info)
+        dev = L.require_cuda(sigmas, steps, info)
+        weights = torch.empty_like(sigmas)
+        covered = int(info.size(0)) > 0
+        if not covered:
+            weights.zero_()
+        L.call("tn_weights_fwd", dev, L.ptr(sigmas), L.ptr(steps), L.ptr(info), C.c_float(threshold), L.ptr(weights),
+               C.c_int64(sigmas.numel()), C.c_int64(info.size(0)))
+        ctx.save_for_backward(sigmas, steps, info, weights)
+        return weights
+
+    @staticmethod
+    def backward(ctx: Any, grad_weights: torch.Tensor):  # type: ignore
+        grad_weights = grad_weights.contiguous()
+        sigmas, steps, info, weights = ctx.saved_tensors
+        dev = L.require_cuda(grad_weights)
+        grad_sigmas = torch.zeros_like(sigmas)
+        L.call("tn_weights_bwd", dev, L.ptr(sigmas), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(grad_weights),
+               L.ptr(grad_sigmas), C.c_int64(sigmas.numel()), C.c_int64(info.size(0)))
+        return grad_sigmas, None, None, None
+
+
+class _Composite(torch.autograd.Function):
+    """rendered[r] = sum_k w_k rgb_k (+ bg (1 - sum_k w_k)) -- core.py:256-265 as one kernel."""
+
+    @staticmethod
+    def forward(ctx: Any, rgbs: torch.Tensor, weights: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor]):  # type: ignore
+        rgbs, weights, info = rgbs.contiguous(), weights.contiguous(), info.contiguous()
+        dev = L.require_cuda(rgbs, weights, info)
+        R = info.size(0)
+        out = torch.empty((R, 3), device=dev)
+        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
+               C.c_int64(weights.numel()), C.c_int64(R))
+        ctx.save_for_backward(rgbs, weights, info, bg)
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
+        rgbs, weights, info, bg = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        dev = grad_out.device
+        g_rgb = torch.zeros_like(rgbs) if ctx.needs_input_grad[0] else None
+        g_w = torch.zeros_like(weights) if ctx.needs_input_grad[1] else None
+        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(grad_out),
+               L.ptr(g_rgb), L.ptr(g_w), C.c_int64(weights.numel()), C.c_int64(info.size(0)))
+        return g_rgb, g_w, None, None
+
+
+class NerfRenderer(torch.nn.Module):
+    def __init__(
+        self,
+        feature_module: torch.nn.Module,
+        sigma_decoder: torch.nn.Module,
+        rgb_decoder: torch.nn.Module,
+        bg_color: torch.Tensor | None = None,
+    ):
+        super().__init__()
+        self.feature_module = feature_module
+        self.sigma_decoder = sigma_decoder
+        self.rgb_decoder = rgb_decoder
+        self.bg_color = bg_color
+        assert hasattr(self.feature_module, "feature_dim"), "feature module requires a feature_dim attribute"
+
+    def _bg(self, device: torch.device) -> Optional[torch.Tensor]:
+        if self.bg_color is None:
+            return None
+        if self.bg_color.device != device or self.bg_color.dtype != torch.float32:
+            self.bg_color = self.bg_color.to(device, torch.float32)
+        return self.bg_color.contiguous()
+
+    def forward(
+        self,
+        packed_samples: torch.Tensor,  # [n_samples, 7]
+        packing_info: torch.Tensor,  # [n_rays, 2]
+        early_termination_threshold: float = 1e-4,
+    ) -> torch.Tensor:
+        """Module-by-module renderer of core.py:225-267: features -> sigma -> weights -> colour of
+        the samples with w > 0 -> per-ray composite.  Each stage is a HIP launch; the fully fused
+        K-Planes path lives in ``tinynerf_amd.fused``."""
+        device = packed_samples.device
+        n_samples = packed_samples.size(0)
+        n_rays = packing_info.size(0)
+        _check_info(packing_info)
+        bg = self._bg(device)
+        empty = n_samples == 0
+        if not empty:
+            feats = self.feature_module(packed_samples[:, :3])
+            sigmas = self.sigma_decoder(feats).ravel()
+            weights: torch.Tensor = NerfWeights.apply(sigmas, packed_samples[:, 6], packing_info, early_termination_threshold)  # type: ignore
+            active = torch.nonzero(weights > 0.).squeeze(1)       # host sync, like `mask.any()` in the reference
+            empty = active.numel() == 0
+        if empty:
+            # core.py:251-254: every sample masked -> background only, gradients are zero
+            print("Empty iteration, every sample is masked")
+            rgbs = torch.zeros((n_samples, 3), device=device, requires_grad=True)
+            weights = torch.zeros(n_samples, device=device, requires_grad=True)
+        else:
+            rgb_active = self.rgb_decoder(feats[active], packed_samples[:, 3:6][active])
+            rgbs = torch.zeros((n_samples, 3), device=device).index_copy(0, active, rgb_active)
+        if n_rays == 0:
+            return torch.zeros((0, 3), device=device)
+        return _Composite.apply(rgbs, weights, packing_info.contiguous(), bg)

@@ -1,0 +1,485 @@
+// Occupancy-grid ray sampling with variable-length sample packing.
+//
+// Replaces the ~25 ATen launches of reference src/core.py:165-188 (RayProvider) and the
+// marchers / contractions / occupancy lookup it calls (core.py:11-88,147-156) with three
+// launches that never materialise the [R,S,3] candidate tensors:
+//   1. sample_mask : one wavefront per ray walks the S candidates 64 at a time, evaluates
+//                    march -> jitter -> contraction -> trilinear occupancy test in registers and
+//                    stores one 64-bit ballot per chunk plus the per-ray popcount;
+//   2. sample_scan : int32 exclusive scan of the counts -> packing_info (start,count);
+//   3. sample_pack : the same wavefront-per-ray walk; lanes whose mask bit is set recompute
+//                    their sample (identical arithmetic -> identical bits) and write the 7-float
+//                    row at start + rank, rank = popcount of lower mask bits (v_mbcnt).
+//
+// BIT-EXACTNESS.  packing_info and the packed coordinates must equal the reference's (torch
+// ops, one IEEE rounding per op).  This translation unit is compiled with -ffp-contract=off and
+// correctly-rounded fp32 division; every expression below follows the operation order of the
+// cited reference line, and the trilinear lookup follows ATen's grid_sampler_3d (align_corners,
+// zeros padding): unnormalise ((x+1)/2)*(size-1), floor, corner weights as products of
+// differences, taps accumulated tnw,tne,tsw,tse,bnw,bne,bsw,bse with one rounded multiply and
+// one rounded add each.
+#include "tn_common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct SamplerArgs {
+    int marcher, contraction, n_samples;
+    int gd, gh, gw;
+    float lo[3], hi[3];
+    float near, far, step, threshold;
+    const float *t_table, *delta_table, *grid, *jitter;
+    uint64_t seed;
+    int use_rng;
+};
+
+// ATen grid_sampler_3d forward for one point (bilinear, zeros padding, align_corners=True)
+__device__ __forceinline__ float trilinear(const float *__restrict__ grid, int D, int H, int W,
+                                           float x, float y, float z)
+{
+    const float ix = ((x + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((y + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((z + 1.0f) / 2.0f) * (float)(D - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+    const float wx0 = x1 - ix, wx1 = ix - x0;
+    const float wy0 = y1 - iy, wy1 = iy - y0;
+    const float wz0 = z1 - iz, wz1 = iz - z0;
+    // within-bounds tests on the float corner coordinates (NaN compares false -> tap skipped)
+    const bool bx0 = x0 >= 0.0f && x0 < (float)W, bx1 = x1 >= 0.0f && x1 < (float)W;
+    const bool by0 = y0 >= 0.0f && y0 < (float)H, by1 = y1 >= 0.0f && y1 < (float)H;
+    const bool bz0 = z0 >= 0.0f && z0 < (float)D, bz1 = z1 >= 0.0f && z1 < (float)D;
+    const int xi0 = bx0 ? (int)x0 : 0, xi1 = bx1 ? (int)x1 : 0;
+    const int yi0 = by0 ? (int)y0 : 0, yi1 = by1 ? (int)y1 : 0;
+    const int zi0 = bz0 ? (int)z0 : 0, zi1 = bz1 ? (int)z1 : 0;
+    const int64_t r00 = ((int64_t)zi0 * H + yi0) * W, r01 = ((int64_t)zi0 * H + yi1) * W;
+    const int64_t r10 = ((int64_t)zi1 * H + yi0) * W, r11 = ((int64_t)zi1 * H + yi1) * W;
+    float acc = 0.0f;
+    if (bx0 && by0 && bz0) acc = acc + grid[r00 + xi0] * ((wx0 * wy0) * wz0);
+    if (bx1 && by0 && bz0) acc = acc + grid[r00 + xi1] * ((wx1 * wy0) * wz0);
+    if (bx0 && by1 && bz0) acc = acc + grid[r01 + xi0] * ((wx0 * wy1) * wz0);
+    if (bx1 && by1 && bz0) acc = acc + grid[r01 + xi1] * ((wx1 * wy1) * wz0);
+    if (bx0 && by0 && bz1) acc = acc + grid[r10 + xi0] * ((wx0 * wy0) * wz1);
+    if (bx1 && by0 && bz1) acc = acc + grid[r10 + xi1] * ((wx1 * wy0) * wz1);
+    if (bx0 && by1 && bz1) acc = acc + grid[r11 + xi0] * ((wx0 * wy1) * wz1);
+    if (bx1 && by1 && bz1) acc = acc + grid[r11 + xi1] * ((wx1 * wy1) * wz1);
+    return acc;
+}
+
+// per-ray constant of the AABB marcher: slab entry distance (reference core.py:78-81)
+__device__ __forceinline__ float aabb_t_min(const SamplerArgs &a, const float o[3], const float d[3])
+{
+    float m[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float den = (d[c] == 0.0f) ? (d[c] + 1e-9f) : d[c];
+        const float tl = (a.lo[c] - o[c]) / den;
+        const float th = (a.hi[c] - o[c]) / den;
+        m[c] = fminf(tl, th);
+    }
+    float t = fmaxf(fmaxf(m[0], m[1]), m[2]);
+    t = fminf(fmaxf(t, a.near), a.far);
+    return t;
+}
+
+template <int MARCH>
+__device__ __forceinline__ void march_t(const SamplerArgs &a, float t_min, int k, float &t, float &delta)
+{
+    if constexpr (MARCH == TN_MARCH_AABB) {
+        t = t_min + (float)k * a.step;                      // core.py:84-85
+        delta = a.step;                                     // core.py:86
+    } else {
+        t = a.t_table[k];                                   // core.py:52-58
+        delta = a.delta_table[k];
+    }
+}
+
+// contraction of one world-space point; returns the in-box flag (always true for Mip-360)
+template <int CONTRACT>
+__device__ __forceinline__ bool contract(const SamplerArgs &a, const float p[3], float c[3])
+{
+    bool inside = true;
+    if constexpr (CONTRACT == TN_CONTRACT_AABB) {           // core.py:29-30
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            inside = inside && (p[i] >= a.lo[i]) && (p[i] <= a.hi[i]);
+            c[i] = (p[i] - a.lo[i]) / (a.hi[i] - a.lo[i]) * 2.0f - 1.0f;
+        }
+    } else {                                                // core.py:18-19
+        float n;
+        if constexpr (CONTRACT == TN_CONTRACT_MIP360_INF) n = fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2]));
+        else n = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float far_branch = (2.0f - 1.0f / n) * p[i] / n;
+            c[i] = ((n <= 1.0f) ? p[i] : far_branch) / 2.0f;
+        }
+    }
+    return inside;
+}
+
+// One candidate: returns keep flag; fills contracted coords and the step size.
+template <int MARCH, int CONTRACT>
+__device__ __forceinline__ bool candidate(const SamplerArgs &a, const float o[3], const float d[3], float t_min,
+                                          int64_t ray, int k, float c[3], float &delta)
+{
+    float t;
+    march_t<MARCH>(a, t_min, k, t, delta);
+    if (a.jitter) {
+        t = t + a.jitter[ray * a.n_samples + k] * delta;    // core.py:173
+    } else if (a.use_rng) {
+        t = t + tn::uniform01(a.seed, (uint64_t)ray * (uint64_t)a.n_samples + (uint64_t)k) * delta;
+    }
+    float p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = o[i] + d[i] * t;     // core.py:174
+    if (!contract<CONTRACT>(a, p, c)) return false;
+    return trilinear(a.grid, a.gd, a.gh, a.gw, c[0], c[1], c[2]) > a.threshold;   // core.py:156
+}
+
+template <int MARCH>
+__global__ void march_rays_kernel(SamplerArgs a, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                  int64_t n_rays, float *__restrict__ t_values, float *__restrict__ step_sizes)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * a.n_samples) return;
+    const int64_t ray = i / a.n_samples;
+    const int k = (int)(i % a.n_samples);
+    float t_min = 0.0f;
+    if constexpr (MARCH == TN_MARCH_AABB) {
+        float o[3], d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = rays_o[3 * ray + c]; d[c] = rays_d[3 * ray + c]; }
+        t_min = aabb_t_min(a, o, d);
+    }
+    float t, delta;
+    march_t<MARCH>(a, t_min, k, t, delta);
+    t_values[i] = t;
+    step_sizes[i] = delta;
+}
+
+template <int CONTRACT>
+__global__ void contract_kernel(SamplerArgs a, const float *__restrict__ coords, int64_t n, float *__restrict__ out,
+                                uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+    float c[3];
+    const bool inside = contract<CONTRACT>(a, p, c);
+    out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+    if (mask) mask[i] = inside ? 1 : 0;
+}
+
+template <int MARCH, int CONTRACT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_mask_kernel(
+    SamplerArgs a, const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays,
+    uint64_t *__restrict__ maskbits, int32_t *__restrict__ counts)
+{
+    const int lane = tn::lane_id();
+    const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = rays_o[3 * ray + i]; d[i] = rays_d[3 * ray + i]; }
+    const float t_min = (MARCH == TN_MARCH_AABB) ? aabb_t_min(a, o, d) : 0.0f;
+    const int n_chunks = (a.n_samples + 63) >> 6;
+    int count = 0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int k = ch * 64 + lane;
+        float c[3], delta;
+        bool keep = false;
+        if (k < a.n_samples) keep = candidate<MARCH, CONTRACT>(a, o, d, t_min, ray, k, c, delta);
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) maskbits[ray * n_chunks + ch] = m;
+        count += __popcll(m);
+    }
+    if (lane == 0) counts[ray] = count;
+}
+
+// Exclusive int32 scan of the per-ray counts (reference core.py:179-181).  One workgroup of 1024
+// threads sweeps the rays in tiles of 1024 with a running carry: R is 10^3..10^6, the pass moves
+// 12 B/ray and is never the bottleneck.
+__global__ __launch_bounds__(1024) void sample_scan_kernel(
+    const int32_t *__restrict__ counts, int64_t n_rays, const int32_t *__restrict__ base_offset,
+    int32_t *__restrict__ info, int32_t *__restrict__ total)
+{
+    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t carry_s;
+    const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
+    const int32_t base = base_offset ? base_offset[0] : 0;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t tile = 0; tile < n_rays; tile += 1024) {
+        const int64_t r = tile + threadIdx.x;
+        const int32_t c = (r < n_rays) ? counts[r] : 0;
+        int32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) wave_tot[wave] = v;
+        __syncthreads();
+        int32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+        const int32_t carry = carry_s;
+        if (r < n_rays) {
+            info[2 * r] = base + carry + wave_off + v - c;
+            info[2 * r + 1] = c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) total[0] = carry_s;
+}
+
+template <int MARCH, int CONTRACT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_pack_kernel(
+    SamplerArgs a, const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays,
+    const uint64_t *__restrict__ maskbits, const int32_t *__restrict__ info, const int32_t *__restrict__ base_offset,
+    float *__restrict__ packed, int32_t *__restrict__ ray_ids, int64_t capacity)
+{
+    const int lane = tn::lane_id();
+    const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int count = info[2 * ray + 1];
+    if (count == 0) return;
+    int64_t out = (int64_t)info[2 * ray] - (base_offset ? base_offset[0] : 0);
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = rays_o[3 * ray + i]; d[i] = rays_d[3 * ray + i]; }
+    const float t_min = (MARCH == TN_MARCH_AABB) ? aabb_t_min(a, o, d) : 0.0f;
+    const int n_chunks = (a.n_samples + 63) >> 6;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const uint64_t m = maskbits[ray * n_chunks + ch];
+        if (m == 0) continue;
+        if ((m >> lane) & 1ull) {
+            const int k = ch * 64 + lane;
+            float c[3], delta;
+            (void)candidate<MARCH, CONTRACT>(a, o, d, t_min, ray, k, c, delta);
+            const int64_t row = out + tn::rank_below(m);
+            if (row < capacity) {
+                float *p = packed + 7 * row;
+                p[0] = c[0]; p[1] = c[1]; p[2] = c[2];
+                p[3] = d[0]; p[4] = d[1]; p[5] = d[2];
+                p[6] = delta;
+                if (ray_ids) ray_ids[row] = (int32_t)ray;
+            }
+        }
+        out += __popcll(m);
+    }
+}
+
+__global__ void occupancy_query_kernel(const float *__restrict__ grid, int D, int H, int W,
+                                       const float *__restrict__ coords, int64_t n, float threshold,
+                                       uint8_t *__restrict__ out, float *__restrict__ values)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = trilinear(grid, D, H, W, coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+    if (out) out[i] = v > threshold ? 1 : 0;
+    if (values) values[i] = v;
+}
+
+// reference core.py:109-119,136
+__global__ void occupancy_slice_coords_kernel(int D, int H, int W, int slice, const float *__restrict__ jitter,
+                                              uint64_t seed, float *__restrict__ coords)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int h = (int)(i / W), w = (int)(i % W);
+    const float idx[3] = {(float)w, (float)h, (float)slice};     // flipped to (x,y,z)
+    const float size[3] = {(float)D, (float)H, (float)W};        // NOT flipped in the reference
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float u = jitter ? jitter[3 * i + c]
+                               : tn::uniform01(seed, ((uint64_t)slice * (uint64_t)H * W + (uint64_t)i) * 3 + c);
+        coords[3 * i + c] = -1.0f + 2.0f * (idx[c] + u) / size[c];
+    }
+}
+
+// reference core.py:137-143
+__global__ void occupancy_apply_kernel(float *__restrict__ cells, const float *__restrict__ sigmas, int64_t n,
+                                       float step, float threshold, float decay)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float alpha = 1.0f - expf(-sigmas[i] * step);
+    cells[i] = alpha > threshold ? 1.0f : decay * cells[i];
+}
+
+__global__ __launch_bounds__(256) void occupancy_stats_kernel(const float *__restrict__ grid, int64_t n, float threshold,
+                                                              double *__restrict__ stats)
+{
+    double s = 0.0, c = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = grid[i];
+        s += (double)v;
+        c += v > threshold ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    __shared__ double ss[4], cc[4];
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; cc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], ss[0] + ss[1] + ss[2] + ss[3]);
+        atomicAdd(&stats[1], cc[0] + cc[1] + cc[2] + cc[3]);
+    }
+}
+
+int make_args(const tn_sampler_desc *d, SamplerArgs &a, bool need_grid = true)
+{
+    TN_REQUIRE(d, TN_E_NULL, "sampler: null descriptor");
+    TN_REQUIRE(d->n_samples > 0, TN_E_SIZE, "sampler: n_samples must be positive");
+    TN_REQUIRE(!need_grid || (d->grid && d->grid_d > 0 && d->grid_h > 0 && d->grid_w > 0), TN_E_NULL, "sampler: occupancy grid missing");
+    TN_REQUIRE(d->marcher == TN_MARCH_AABB || d->marcher == TN_MARCH_UNBOUNDED, TN_E_CONFIG, "sampler: unknown marcher");
+    TN_REQUIRE(d->contraction >= TN_CONTRACT_AABB && d->contraction <= TN_CONTRACT_MIP360_L2, TN_E_CONFIG, "sampler: unknown contraction");
+    TN_REQUIRE(d->marcher != TN_MARCH_UNBOUNDED || (d->t_table && d->delta_table), TN_E_NULL, "sampler: unbounded marcher needs t/delta tables");
+    a.marcher = d->marcher; a.contraction = d->contraction; a.n_samples = d->n_samples;
+    a.gd = d->grid_d; a.gh = d->grid_h; a.gw = d->grid_w;
+    for (int i = 0; i < 3; ++i) { a.lo[i] = d->aabb[i]; a.hi[i] = d->aabb[3 + i]; }
+    a.near = d->near; a.far = d->far; a.step = d->step_size; a.threshold = d->threshold;
+    a.t_table = d->t_table; a.delta_table = d->delta_table; a.grid = d->grid; a.jitter = d->jitter;
+    a.seed = d->seed; a.use_rng = d->use_rng;
+    return TN_OK;
+}
+
+inline unsigned ray_blocks(int64_t n_rays) { return (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+
+// compile-time specialisation of the (marcher, contraction) pair: no per-candidate branching
+#define TN_DISPATCH_MC(a, ...)                                                                        \
+    do {                                                                                              \
+        const int key_ = (a).marcher * 3 + (a).contraction;                                           \
+        switch (key_) {                                                                               \
+        case 0: { constexpr int M = 0, Cn = 0; __VA_ARGS__; } break;                                         \
+        case 1: { constexpr int M = 0, Cn = 1; __VA_ARGS__; } break;                                         \
+        case 2: { constexpr int M = 0, Cn = 2; __VA_ARGS__; } break;                                         \
+        case 3: { constexpr int M = 1, Cn = 0; __VA_ARGS__; } break;                                         \
+        case 4: { constexpr int M = 1, Cn = 1; __VA_ARGS__; } break;                                         \
+        default: { constexpr int M = 1, Cn = 2; __VA_ARGS__; } break;                                        \
+        }                                                                                             \
+    } while (0)
+
+}  // namespace
+
+extern "C" int tn_march_rays(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,
+                             float *t_values, float *step_sizes, void *stream)
+{
+    SamplerArgs a;
+    if (int rc = make_args(desc, a, false)) return rc;
+    TN_REQUIRE(n_rays >= 0, TN_E_SIZE, "tn_march_rays: negative n_rays");
+    if (n_rays == 0) return TN_OK;
+    TN_REQUIRE(rays_o && rays_d && t_values && step_sizes, TN_E_NULL, "tn_march_rays: null pointer");
+    const int64_t n = n_rays * a.n_samples;
+    if (a.marcher == TN_MARCH_AABB)
+        hipLaunchKernelGGL(march_rays_kernel<TN_MARCH_AABB>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           a, rays_o, rays_d, n_rays, t_values, step_sizes);
+    else
+        hipLaunchKernelGGL(march_rays_kernel<TN_MARCH_UNBOUNDED>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           a, rays_o, rays_d, n_rays, t_values, step_sizes);
+    return tn::check_launch("march_rays_kernel");
+}
+
+extern "C" int tn_contract(const tn_sampler_desc *desc, const float *coords, int64_t n, float *coords_out, uint8_t *mask,
+                           void *stream)
+{
+    SamplerArgs a;
+    if (int rc = make_args(desc, a, false)) return rc;
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_contract: negative n");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(coords && coords_out, TN_E_NULL, "tn_contract: null pointer");
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (a.contraction == TN_CONTRACT_AABB)
+        hipLaunchKernelGGL(contract_kernel<TN_CONTRACT_AABB>, grid, dim3(256), 0, (hipStream_t)stream, a, coords, n, coords_out, mask);
+    else if (a.contraction == TN_CONTRACT_MIP360_INF)
+        hipLaunchKernelGGL(contract_kernel<TN_CONTRACT_MIP360_INF>, grid, dim3(256), 0, (hipStream_t)stream, a, coords, n, coords_out, mask);
+    else
+        hipLaunchKernelGGL(contract_kernel<TN_CONTRACT_MIP360_L2>, grid, dim3(256), 0, (hipStream_t)stream, a, coords, n, coords_out, mask);
+    return tn::check_launch("contract_kernel");
+}
+
+extern "C" int tn_sample_mask(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,
+                              uint64_t *maskbits, int32_t *counts, void *stream)
+{
+    SamplerArgs a;
+    if (int rc = make_args(desc, a)) return rc;
+    TN_REQUIRE(n_rays >= 0, TN_E_SIZE, "tn_sample_mask: negative n_rays");
+    if (n_rays == 0) return TN_OK;
+    TN_REQUIRE(rays_o && rays_d && maskbits && counts, TN_E_NULL, "tn_sample_mask: null pointer");
+    TN_DISPATCH_MC(a, sample_mask_kernel<M, Cn><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(
+                          a, rays_o, rays_d, n_rays, maskbits, counts));
+    return tn::check_launch("sample_mask_kernel");
+}
+
+extern "C" int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32_t *base_offset, int32_t *info,
+                              int32_t *total, void *stream)
+{
+    TN_REQUIRE(n_rays >= 0, TN_E_SIZE, "tn_sample_scan: negative n_rays");
+    TN_REQUIRE(n_rays == 0 || (counts && info), TN_E_NULL, "tn_sample_scan: null pointer");
+    hipLaunchKernelGGL(sample_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, base_offset, info, total);
+    return tn::check_launch("sample_scan_kernel");
+}
+
+extern "C" int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,
+                              const uint64_t *maskbits, const int32_t *info, const int32_t *base_offset, float *packed,
+                              int32_t *ray_ids, int64_t capacity, void *stream)
+{
+    SamplerArgs a;
+    if (int rc = make_args(desc, a)) return rc;
+    TN_REQUIRE(n_rays >= 0 && capacity >= 0, TN_E_SIZE, "tn_sample_pack: negative size");
+    if (n_rays == 0 || capacity == 0) return TN_OK;
+    TN_REQUIRE(rays_o && rays_d && maskbits && info && packed, TN_E_NULL, "tn_sample_pack: null pointer");
+    TN_DISPATCH_MC(a, sample_pack_kernel<M, Cn><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(
+                          a, rays_o, rays_d, n_rays, maskbits, info, base_offset, packed, ray_ids, capacity));
+    return tn::check_launch("sample_pack_kernel");
+}
+
+extern "C" int tn_occupancy_query(const float *grid, int D, int H, int W, const float *coords, int64_t n, float threshold,
+                                  uint8_t *out, float *values, void *stream)
+{
+    TN_REQUIRE(n >= 0 && D > 0 && H > 0 && W > 0, TN_E_SIZE, "tn_occupancy_query: bad size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(grid && coords && (out || values), TN_E_NULL, "tn_occupancy_query: null pointer");
+    hipLaunchKernelGGL(occupancy_query_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grid, D, H, W, coords, n, threshold, out, values);
+    return tn::check_launch("occupancy_query_kernel");
+}
+
+extern "C" int tn_occupancy_slice_coords(int D, int H, int W, int slice, const float *jitter, uint64_t seed, float *coords,
+                                         void *stream)
+{
+    TN_REQUIRE(D > 0 && H > 0 && W > 0 && slice >= 0 && slice < D, TN_E_SIZE, "tn_occupancy_slice_coords: bad size");
+    TN_REQUIRE(coords, TN_E_NULL, "tn_occupancy_slice_coords: null pointer");
+    const int64_t n = (int64_t)H * W;
+    hipLaunchKernelGGL(occupancy_slice_coords_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       D, H, W, slice, jitter, seed, coords);
+    return tn::check_launch("occupancy_slice_coords_kernel");
+}
+
+extern "C" int tn_occupancy_apply(float *grid_cells, const float *sigmas, int64_t n, float step_size, float threshold,
+                                  float decay, void *stream)
+{
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_occupancy_apply: negative size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(grid_cells && sigmas, TN_E_NULL, "tn_occupancy_apply: null pointer");
+    hipLaunchKernelGGL(occupancy_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grid_cells, sigmas, n, step_size, threshold, decay);
+    return tn::check_launch("occupancy_apply_kernel");
+}
+
+extern "C" int tn_occupancy_stats(const float *grid, int64_t n, float threshold, double *stats, void *stream)
+{
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_occupancy_stats: negative size");
+    TN_REQUIRE(grid && stats, TN_E_NULL, "tn_occupancy_stats: null pointer");
+    hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) { tn::set_error("tn_occupancy_stats: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (n == 0) return TN_OK;
+    const unsigned blocks = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(occupancy_stats_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream,
+                       grid, n, threshold, stats);
+    return tn::check_launch("occupancy_stats_kernel");
+}

@@ -158,6 +158,7 @@ typedef struct tn_mlp_desc {
     int32_t n_freqs;                          /* F for the encodings                          */
     int32_t out_activation;                   /* TN_ACT_*                                     */
     int32_t reserved;
+    const float *freqs;                       /* [n_freqs] encoding frequencies (models.py:34); NULL = 2^j*pi */
     const float *weights[TN_MLP_MAX_LAYERS];  /* [dims[l+1], dims[l]]                         */
     const float *biases[TN_MLP_MAX_LAYERS];   /* [dims[l+1]]                                  */
 } tn_mlp_desc;
@@ -179,6 +180,7 @@ int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const 
  * Planes are stored channel-last: plane[s][p] is fp32 [H_s, W_s, C] (torch memory_format
  * channels_last of the reference's [1,C,H,W] parameter, so the state_dict shape is unchanged).
  * feat[n, s*C + c] = prod_p bilinear(plane[s][p], x[n, pair_p])[c], pairs (0,1),(0,2),(1,2).
+ * planes[s][1] / planes[s][2] may be NULL: that factor is 1 (KPlanesFeaturePlane.forward, models.py:105-113).
  * ------------------------------------------------------------------------------------------ */
 #define TN_KPLANES_MAX_SCALES 4
 typedef struct tn_kplanes_desc {

@@ -38,6 +38,7 @@ class MlpDesc(C.Structure):
     _fields_ = [
         ("n_layers", C.c_int32), ("in_dim", C.c_int32), ("dims", C.c_int32 * (TN_MLP_MAX_LAYERS + 1)),
         ("encoding", C.c_int32), ("n_freqs", C.c_int32), ("out_activation", C.c_int32), ("reserved", C.c_int32),
+        ("freqs", C.c_void_p),
         ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
     ]
 

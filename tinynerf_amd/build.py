@@ -31,9 +31,9 @@ SOURCES = {
     "weights.hip": FAST,
     "sampler.hip": STRICT,
     "encoding.hip": FAST,
-    "kplanes.hip": FAST,
+    "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp.hip": FAST,
-    "render.hip": FAST,
+    "render.hip": FAST + ["-munsafe-fp-atomics"],
 }
 
 

@@ -1,0 +1,167 @@
+// K-Planes feature field (reference src/models.py:93-163): 3 scales x 3 planes of bilinear
+// lookups, Hadamard product over the planes of a scale, scales concatenated.
+// Replaces 9 x (grid_sampler_2d + transpose + contiguous) + 6 muls + cat of the reference
+// (27+ launches) with one launch; backward scatters with hardware fp32 atomics.
+#include "kplanes_device.h"
+#include <algorithm>
+
+namespace {
+
+using tn::f32x4k;
+
+struct KpArgs {
+    int n_scales, C;
+    int H[TN_KPLANES_MAX_SCALES], W[TN_KPLANES_MAX_SCALES];
+    const float *planes[TN_KPLANES_MAX_SCALES][3];
+    float *grads[TN_KPLANES_MAX_SCALES][3];
+};
+
+// NV = C/8 float4 groups per lane (C = 32 -> 4)
+template <int NV>
+__global__ __launch_bounds__(256) void kplanes_fwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
+                                                          int64_t n, float *__restrict__ feat)
+{
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int C = a.C, FD = a.n_scales * C;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 32 + j;
+        if (row >= n) continue;
+        const float xs[3] = {x[row * x_stride], x[row * x_stride + 1], x[row * x_stride + 2]};
+        for (int s = 0; s < a.n_scales; ++s) {
+            f32x4k prod[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) prod[q] = f32x4k{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (a.planes[s][p] == nullptr) continue;        // absent plane == factor 1 (single-plane lookups)
+                float u, v;
+                tn::pair_uv(xs, p, u, v);
+                const tn::PlaneTaps t = tn::plane_taps(u, v, a.H[s], a.W[s], C);
+                f32x4k val[NV];
+                tn::plane_gather<NV>(a.planes[s][p], t, h * (C / 2), val);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) prod[q] = prod[q] * val[q];      // (1*p0)*p1*p2, models.py:157-160
+            }
+            f32x4k *o = reinterpret_cast<f32x4k *>(feat + row * FD + s * C + h * (C / 2));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) o[q] = prod[q];
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
+                                                          int64_t n, const float *__restrict__ grad_feat)
+{
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int C = a.C, FD = a.n_scales * C;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 32 + j;
+        if (row >= n) continue;
+        const float xs[3] = {x[row * x_stride], x[row * x_stride + 1], x[row * x_stride + 2]};
+        for (int s = 0; s < a.n_scales; ++s) {
+            tn::PlaneTaps t[3];
+            f32x4k val[3][NV];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float u, v;
+                tn::pair_uv(xs, p, u, v);
+                t[p] = tn::plane_taps(u, v, a.H[s], a.W[s], C);
+                if (a.planes[s][p]) tn::plane_gather<NV>(a.planes[s][p], t[p], h * (C / 2), val[p]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
+                }
+            }
+            const f32x4k *g = reinterpret_cast<const f32x4k *>(grad_feat + row * FD + s * C + h * (C / 2));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const f32x4k gq = g[q];
+                // d(p0 p1 p2)/dp_i
+                const f32x4k gp[3] = {gq * val[1][q] * val[2][q], gq * val[0][q] * val[2][q], gq * (val[0][q] * val[1][q])};
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (a.grads[s][p] == nullptr) continue;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (t[p].off[k] >= 0) {
+                            float *dst = a.grads[s][p] + t[p].off[k] + h * (C / 2) + 4 * q;
+                            const f32x4k c = gp[p] * t[p].w[k];
+                            atomicAdd(dst + 0, c[0]); atomicAdd(dst + 1, c[1]);
+                            atomicAdd(dst + 2, c[2]); atomicAdd(dst + 3, c[3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int make_args(const tn_kplanes_desc *d, KpArgs &a, float *const (*grads)[3])
+{
+    TN_REQUIRE(d, TN_E_NULL, "kplanes: null descriptor");
+    TN_REQUIRE(d->n_scales >= 1 && d->n_scales <= TN_KPLANES_MAX_SCALES, TN_E_CONFIG, "kplanes: n_scales out of range");
+    TN_REQUIRE(d->channels == 8 || d->channels == 16 || d->channels == 32, TN_E_CONFIG, "kplanes: channels must be 8, 16 or 32");
+    a.n_scales = d->n_scales; a.C = d->channels;
+    for (int s = 0; s < d->n_scales; ++s) {
+        TN_REQUIRE(d->height[s] > 0 && d->width[s] > 0, TN_E_SIZE, "kplanes: bad plane resolution");
+        TN_REQUIRE((int64_t)d->height[s] * d->width[s] * d->channels < (1ll << 31), TN_E_SIZE, "kplanes: plane too large");
+        a.H[s] = d->height[s]; a.W[s] = d->width[s];
+        TN_REQUIRE(d->planes[s][0], TN_E_NULL, "kplanes: null plane pointer");
+        for (int p = 0; p < 3; ++p) {     // planes 1 and 2 may be NULL: the factor is then 1 (single-plane lookup)
+            TN_REQUIRE(((uintptr_t)d->planes[s][p] & 15) == 0, TN_E_ALIGN, "kplanes: planes must be 16-byte aligned");
+            a.planes[s][p] = d->planes[s][p];
+            a.grads[s][p] = nullptr;
+            if (grads && d->planes[s][p]) {
+                TN_REQUIRE(grads[s][p], TN_E_NULL, "kplanes: null grad plane pointer");
+                a.grads[s][p] = grads[s][p];
+            }
+        }
+    }
+    return TN_OK;
+}
+
+inline unsigned tile_blocks(int64_t n) { return (unsigned)std::min<int64_t>(((n + 31) / 32 + 3) / 4, 256 * 8); }
+
+}  // namespace
+
+extern "C" int tn_kplanes_fwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n, float *feat,
+                              void *stream)
+{
+    KpArgs a;
+    if (int rc = make_args(desc, a, nullptr)) return rc;
+    TN_REQUIRE(n >= 0 && x_stride >= 3, TN_E_SIZE, "tn_kplanes_fwd: bad size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(x && feat, TN_E_NULL, "tn_kplanes_fwd: null pointer");
+    TN_REQUIRE(((uintptr_t)feat & 15) == 0, TN_E_ALIGN, "tn_kplanes_fwd: feat must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(tile_blocks(n)), block(256);
+    switch (a.C) {
+    case 8: kplanes_fwd_kernel<1><<<grid, block, 0, s>>>(a, x, x_stride, n, feat); break;
+    case 16: kplanes_fwd_kernel<2><<<grid, block, 0, s>>>(a, x, x_stride, n, feat); break;
+    default: kplanes_fwd_kernel<4><<<grid, block, 0, s>>>(a, x, x_stride, n, feat); break;
+    }
+    return tn::check_launch("kplanes_fwd_kernel");
+}
+
+extern "C" int tn_kplanes_bwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
+                              const float *grad_feat, float *const (*grad_planes)[3], void *stream)
+{
+    KpArgs a;
+    TN_REQUIRE(grad_planes, TN_E_NULL, "tn_kplanes_bwd: null grad_planes");
+    if (int rc = make_args(desc, a, grad_planes)) return rc;
+    TN_REQUIRE(n >= 0 && x_stride >= 3, TN_E_SIZE, "tn_kplanes_bwd: bad size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(x && grad_feat, TN_E_NULL, "tn_kplanes_bwd: null pointer");
+    TN_REQUIRE(((uintptr_t)grad_feat & 15) == 0, TN_E_ALIGN, "tn_kplanes_bwd: grad_feat must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(tile_blocks(n)), block(256);
+    switch (a.C) {
+    case 8: kplanes_bwd_kernel<1><<<grid, block, 0, s>>>(a, x, x_stride, n, grad_feat); break;
+    case 16: kplanes_bwd_kernel<2><<<grid, block, 0, s>>>(a, x, x_stride, n, grad_feat); break;
+    default: kplanes_bwd_kernel<4><<<grid, block, 0, s>>>(a, x, x_stride, n, grad_feat); break;
+    }
+    return tn::check_launch("kplanes_bwd_kernel");
+}

@@ -1,0 +1,67 @@
+// K-Planes bilinear plane lookups (reference src/models.py:93-163) for channel-last planes.
+//
+// Layout: plane[s][p] is fp32 [H][W][C] -- one texel's C channels are one contiguous 4*C-byte
+// run (128 B = one cache line for C = 32), where the reference's [1,C,H,W] layout spreads a texel
+// over C cache lines (SURVEY 7 "K-Planes gather locality").  torch sees the same memory as a
+// channels_last [1,C,H,W] parameter, so state_dict shapes do not change.
+//
+// Lane mapping (shared with the fused MLP, mlp_device.h): lane l = (h = l>>5, j = l&31) owns
+// sample j of the wave's 32-sample tile and the channel half [h*C/2, (h+1)*C/2) of every plane, read
+// as float4: lanes j and j+32 together consume one full texel line.
+#pragma once
+#include "tn_common.h"
+
+namespace tn {
+
+typedef float f32x4k __attribute__((ext_vector_type(4)));
+
+struct PlaneTaps {
+    int off[4];      // element offset of texel (y,x) * C for nw, ne, sw, se; -1 when out of bounds
+    float w[4];      // bilinear weights
+};
+
+// ATen grid_sampler_2d conventions: align_corners=True, zeros padding; u indexes W, v indexes H.
+__device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, int C) {
+    PlaneTaps t;
+    const float ix = ((u + 1.0f) * 0.5f) * (float)(W - 1);
+    const float iy = ((v + 1.0f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const float gx = (x0f + 1.0f) - ix, gy = (y0f + 1.0f) - iy;
+    t.w[0] = gx * gy; t.w[1] = fx * gy; t.w[2] = gx * fy; t.w[3] = fx * fy;
+    const bool bx0 = x0f >= 0.0f && x0f < (float)W, bx1 = x0f + 1.0f >= 0.0f && x0f + 1.0f < (float)W;
+    const bool by0 = y0f >= 0.0f && y0f < (float)H, by1 = y0f + 1.0f >= 0.0f && y0f + 1.0f < (float)H;
+    const int x0 = bx0 ? (int)x0f : 0, x1 = bx1 ? (int)x0f + 1 : 0;
+    const int y0 = by0 ? (int)y0f : 0, y1 = by1 ? (int)y0f + 1 : 0;
+    t.off[0] = (bx0 && by0) ? (y0 * W + x0) * C : -1;
+    t.off[1] = (bx1 && by0) ? (y0 * W + x1) * C : -1;
+    t.off[2] = (bx0 && by1) ? (y1 * W + x0) * C : -1;
+    t.off[3] = (bx1 && by1) ? (y1 * W + x1) * C : -1;
+    return t;
+}
+
+// interpolate NV float4 groups (channels c0 .. c0+4*NV) of one plane
+template <int NV>
+__device__ __forceinline__ void plane_gather(const float *__restrict__ plane, const PlaneTaps &t, int c0, f32x4k (&out)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = f32x4k{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (t.off[k] >= 0) {
+            const f32x4k *p = reinterpret_cast<const f32x4k *>(plane + t.off[k] + c0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const f32x4k tex = p[v];
+                out[v] += tex * t.w[k];
+            }
+        }
+    }
+}
+
+// coordinate pairs of the three planes of a scale: itertools.combinations(range(3), 2) (models.py:146)
+__device__ __forceinline__ void pair_uv(const float x[3], int p, float &u, float &v) {
+    u = (p == 2) ? x[1] : x[0];
+    v = (p == 0) ? x[1] : x[2];
+}
+
+}  // namespace tn

@@ -1,0 +1,346 @@
+// Fused MLP heads (reference src/models.py:7-89) as ONE persistent launch on fp32 MFMA.
+//
+//   y = act_out( W_L relu( ... relu(W_0 enc(x) + b_0) ... ) + b_L )
+//
+// Replaces the reference's per-layer sgemm + bias + ReLU launches, whose activations round-trip
+// HBM between layers.  Here a wavefront owns 32 samples; layer inputs/outputs
+// stay in the register file (see mlp_device.h for the transposed MFMA formulation), all layer
+// weights are staged once per workgroup into LDS (rows padded, first-layer columns permuted for
+// the fused encodings) and re-used by every tile the persistent workgroup processes.  When the
+// weights do not fit the 160 KiB LDS (width-256 stacks) the A operands are fetched from L2.
+//
+// Fused encodings (computed in registers, never materialised):
+//   TN_ENC_POSENC  : enc(x) = PE_F(x)                       (models.py:59-68, VanillaFeatureMLP)
+//   TN_ENC_DIR_CAT : enc(x, d) = cat[PE_F(d), d, x]          (models.py:79-89, VanillaColorDecoder)
+// Output activations: exp(y-1) (models.py:74) and sigmoid (models.py:85).
+#include "mlp_device.h"
+#include <algorithm>
+
+namespace {
+
+using tn::f32x16;
+using tn::f32x4;
+
+struct MlpArgs {
+    int n_layers, in_dim, K0, K0_pad, enc, n_freqs, out_act, out_dim;
+    const float *freqs;
+    const float *W[TN_MLP_MAX_LAYERS];
+    const float *B[TN_MLP_MAX_LAYERS];
+    int w_off[TN_MLP_MAX_LAYERS], b_off[TN_MLP_MAX_LAYERS], stride[TN_MLP_MAX_LAYERS];
+    int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];     // true in / out width of each layer
+    int lds_floats;
+};
+
+// column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
+__device__ __forceinline__ int layer0_col(const MlpArgs &a, int q) {
+    if (a.enc == TN_ENC_DIR_CAT) {
+        const int pe = 6 * a.n_freqs + 3;
+        return q < a.in_dim ? pe + q : q - a.in_dim;       // torch order: [PE(d), d, feat]
+    }
+    return q;
+}
+
+// copy every layer into LDS: [rows][K_pad + 4] + bias, zero padded
+__device__ void stage_weights(const MlpArgs &a, float *lds) {
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int stride = a.stride[l];
+        const int rows = (a.b_off[l] - a.w_off[l]) / stride;
+        const int K = a.K[l], N = a.N[l];
+        float *w = lds + a.w_off[l];
+        for (int e = threadIdx.x; e < rows * stride; e += blockDim.x) {
+            const int r = e / stride, q = e - r * stride;
+            float v = 0.0f;
+            if (r < N && q < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, q) : q)];
+            w[e] = v;
+        }
+        float *b = lds + a.b_off[l];
+        const int brow = (rows + 3) & ~3;
+        for (int e = threadIdx.x; e < brow; e += blockDim.x) b[e] = e < N ? a.B[l][e] : 0.0f;
+    }
+}
+
+// The four first-layer inputs of slots 8g+4h .. +3 for this lane's sample.
+//   TN_ENC_NONE    slot q = x[q]
+//   TN_ENC_POSENC  slot q = PE(x)[q]
+//   TN_ENC_DIR_CAT slot q = x[q] (q < in_dim), PE(d)[q-in_dim], d[..], 0 padding
+__device__ __forceinline__ f32x4 fetch_input(const MlpArgs &a, const float *__restrict__ xrow, const float *aux3,
+                                             bool valid, int g, int h)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!valid) return v;
+    const int q0 = 8 * g + 4 * h;
+    if (a.enc == TN_ENC_POSENC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q0 + u < a.K0) v[u] = tn::posenc_value(aux3, q0 + u, a.n_freqs, a.freqs);
+        return v;
+    }
+    if (q0 + 3 < a.in_dim && (a.in_dim & 3) == 0) return *reinterpret_cast<const f32x4 *>(xrow + q0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        if (q < a.in_dim) v[u] = xrow[q];
+        else if (a.enc == TN_ENC_DIR_CAT) {
+            const int p = q - a.in_dim;
+            if (p < 6 * a.n_freqs) v[u] = tn::posenc_value(aux3, p, a.n_freqs, a.freqs);
+            else if (p < 6 * a.n_freqs + 3) v[u] = aux3[p - 6 * a.n_freqs];
+        }
+    }
+    return v;
+}
+
+// A operand of 4 consecutive steps: LDS copy (padded, always in range) or guarded global read
+template <bool WLDS>
+__device__ __forceinline__ f32x4 load_a4(const float *__restrict__ W, int row, int col, int K, int stride) {
+    if constexpr (WLDS) {
+        return *reinterpret_cast<const f32x4 *>(W + row * stride + col);
+    } else {
+        if (col + 3 < K && (K & 3) == 0) return *reinterpret_cast<const f32x4 *>(W + (int64_t)row * K + col);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (col + u < K) v[u] = W[(int64_t)row * K + col + u];
+        return v;
+    }
+}
+
+template <int H, bool WLDS, int WPB>
+__global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const float *__restrict__ x,
+                                                           const float *__restrict__ aux, int64_t n,
+                                                           float *__restrict__ y, float *__restrict__ pre_act)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = H / 32;
+    if constexpr (WLDS) {
+        stage_weights(a, lds);
+        __syncthreads();
+    }
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int L = a.n_layers;
+    const int G0 = a.K0_pad >> 3;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        float aux3[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
+            else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
+        }
+        // ---- layer 0: inputs streamed 4 slots at a time, prefetched one group ahead ----
+        const float *W0 = WLDS ? lds + a.w_off[0] : a.W[0];
+        const float *B0 = WLDS ? lds + a.b_off[0] : a.B[0];
+        f32x16 act[T];
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(B0, ob, h);
+        f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h);
+        for (int g = 0; g < G0; ++g) {
+            f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+            if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h);
+            f32x4 w[T];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) {
+                if constexpr (WLDS) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
+                else {   // global first layer: columns are in torch order, no permutation possible
+                    w[ob] = load_a4<false>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.K0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
+            b = bn;
+        }
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) act[ob] = tn::relu16(act[ob]);
+        // ---- hidden layers H -> H ----
+        for (int l = 1; l + 1 < L; ++l) {
+            const float *Wl = WLDS ? lds + a.w_off[l] : a.W[l];
+            const float *Bl = WLDS ? lds + a.b_off[l] : a.B[l];
+            tn::hidden_layer<H>(Wl, Bl, WLDS ? a.stride[l] : H, act, j, h);
+        }
+        // ---- output layer ----
+        const float *Wf = WLDS ? lds + a.w_off[L - 1] : a.W[L - 1];
+        const float *Bf = WLDS ? lds + a.b_off[L - 1] : a.B[L - 1];
+        const int sf = WLDS ? a.stride[L - 1] : H;
+        const int out = a.out_dim;
+        if (out <= 4) {
+            float o4[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                o4[o] = 0.f;
+                if (o < out) o4[o] = tn::small_out<H>(Wf + o * sf, Bf[o], act, h);
+            }
+            if (valid && h == 0) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < out) {
+                        if (pre_act) pre_act[row * out + o] = o4[o];
+                        y[row * out + o] = tn::apply_act(o4[o], a.out_act);
+                    }
+            }
+        } else {
+            const int n_ob = (out + 31) >> 5;
+            for (int ob = 0; ob < n_ob; ++ob) {
+                f32x16 acc;
+                if constexpr (WLDS) acc = tn::bias_tile(Bf, ob, h);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        acc[r] = f < out ? Bf[f] : 0.f;
+                    }
+                }
+                const int arow = 32 * ob + j;
+#pragma unroll
+                for (int kb = 0; kb < T; ++kb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                        if (WLDS || arow < out) w = load_a4<WLDS>(Wf, arow, 32 * kb + 8 * q + 4 * h, H, sf);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], act[kb][4 * q + u], acc);
+                    }
+                }
+                if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 32 * ob + 8 * q + 4 * h;
+                        if (f0 + 3 < out && (out & 3) == 0) {
+                            f32x4 v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = acc[4 * q + u];
+                            if (pre_act) *reinterpret_cast<f32x4 *>(pre_act + row * out + f0) = v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = tn::apply_act(v[u], a.out_act);
+                            *reinterpret_cast<f32x4 *>(y + row * out + f0) = v;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (f0 + u < out) {
+                                    if (pre_act) pre_act[row * out + f0 + u] = acc[4 * q + u];
+                                    y[row * out + f0 + u] = tn::apply_act(acc[4 * q + u], a.out_act);
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// reference models.py:30-39 as a stand-alone kernel (PositionalEncoding.forward)
+__global__ void posenc_kernel(const float *__restrict__ x, int64_t n, int C, const float *__restrict__ freqs, int F,
+                              float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = 2 * F * C;
+    if (e >= n * width) return;
+    const int64_t row = e / width;
+    const int p = (int)(e - row * width);
+    const int c = p / (2 * F);
+    const int rem = p - c * 2 * F;
+    const bool is_cos = rem >= F;
+    const int f = is_cos ? rem - F : rem;
+    const float ang = x[row * C + c] * (freqs ? freqs[f] : ldexpf(3.14159274101257324f, f));
+    out[e] = is_cos ? cosf(ang) : sinf(ang);
+}
+
+constexpr int LDS_LIMIT_BYTES = 160 * 1024;
+
+int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
+{
+    TN_REQUIRE(d, TN_E_NULL, "mlp: null descriptor");
+    const int L = d->n_layers;
+    TN_REQUIRE(L >= 2 && L <= TN_MLP_MAX_LAYERS, TN_E_CONFIG, "mlp: n_layers must be in [2, 12]");
+    H = d->dims[1];
+    TN_REQUIRE(H == 32 || H == 64 || H == 128 || H == 256, TN_E_CONFIG, "mlp: hidden width must be 32, 64, 128 or 256");
+    for (int l = 1; l < L; ++l) TN_REQUIRE(d->dims[l] == H, TN_E_CONFIG, "mlp: all hidden layers must share one width");
+    for (int l = 0; l < L; ++l) TN_REQUIRE(d->weights[l] && d->biases[l], TN_E_NULL, "mlp: null weight / bias pointer");
+    a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
+    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L];
+    a.freqs = d->freqs;
+    TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
+    switch (a.enc) {
+    case TN_ENC_NONE: TN_REQUIRE(a.K0 == a.in_dim, TN_E_CONFIG, "mlp: dims[0] must equal in_dim"); break;
+    case TN_ENC_POSENC:
+        TN_REQUIRE(a.in_dim == 3 && a.K0 == 6 * a.n_freqs, TN_E_CONFIG, "mlp: posenc expects in_dim 3 and dims[0] = 6F");
+        break;
+    case TN_ENC_DIR_CAT:
+        TN_REQUIRE(a.K0 == a.in_dim + 6 * a.n_freqs + 3, TN_E_CONFIG, "mlp: dir_cat expects dims[0] = in_dim + 6F + 3");
+        break;
+    default: return tn::fail(TN_E_CONFIG, "mlp: unknown encoding");
+    }
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+        a.W[l] = d->weights[l]; a.B[l] = d->biases[l];
+        a.K[l] = d->dims[l]; a.N[l] = d->dims[l + 1];
+        const int Kp = l == 0 ? a.K0_pad : H;
+        const int rows = (l == L - 1) ? (a.out_dim <= 4 ? a.out_dim : ((a.out_dim + 31) & ~31)) : H;
+        a.stride[l] = Kp + 4;
+        a.w_off[l] = off; off += rows * a.stride[l];
+        a.b_off[l] = off; off += (rows + 3) & ~3;
+    }
+    a.lds_floats = off;
+    return TN_OK;
+}
+
+template <int H>
+int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, hipStream_t s)
+{
+    const int64_t n_tiles = (n + 31) / 32;
+    const size_t lds_bytes = (size_t)a.lds_floats * 4;
+    const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
+    constexpr int WPB = H <= 64 ? 8 : 4;
+    if (wlds) {
+        auto kern = mlp_fwd_kernel<H, true, WPB>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
+        const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act);
+    } else {
+        // weights streamed from L2; the DIR_CAT column permutation needs the LDS copy
+        if (a.enc == TN_ENC_DIR_CAT) return tn::fail(TN_E_CONFIG, "mlp: dir_cat head too large for LDS staging");
+        auto kern = mlp_fwd_kernel<H, false, WPB>;
+        const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act);
+    }
+    return tn::check_launch("mlp_fwd_kernel");
+}
+
+}  // namespace
+
+extern "C" int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act,
+                          void *stream)
+{
+    MlpArgs a;
+    int H = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mlp_fwd: negative n");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(x && y, TN_E_NULL, "tn_mlp_fwd: null pointer");
+    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_fwd: dir_cat needs aux (ray directions)");
+    TN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: x / y must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (H) {
+    case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, s);
+    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, s);
+    case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, s);
+    default: return launch_fwd<256>(a, x, aux, n, y, pre_act, s);
+    }
+}
+
+extern "C" int tn_posenc_fwd(const float *x, int64_t n, int n_channels, const float *freqs, int n_freqs, float *out,
+                             void *stream)
+{
+    TN_REQUIRE(n >= 0 && n_channels > 0 && n_freqs > 0, TN_E_SIZE, "tn_posenc_fwd: bad size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(x && out, TN_E_NULL, "tn_posenc_fwd: null pointer");
+    const int64_t total = n * 2 * n_freqs * n_channels;
+    posenc_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, n, n_channels, freqs, n_freqs, out);
+    return tn::check_launch("posenc_kernel");
+}

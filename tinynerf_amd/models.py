@@ -1,0 +1,409 @@
+"""Field models with the API of the reference's ``src/models.py``, evaluated by HIP kernels.
+
+Class names, constructor signatures, sub-module names and ``state_dict`` keys/shapes are the
+reference's (a reference ``model.pt`` loads unchanged); ``forward`` of every head is
+ONE launch of the fused fp32-MFMA MLP kernel (``csrc/mlp.hip``) with its encoding and output
+activation fused, and the K-Planes field is one gather kernel (``csrc/kplanes.hip``).
+
+Reference map: MLP models.py:7-28, PositionalEncoding :30-39, TruncatedExponential :42-55,
+Vanilla* :59-89, KPlanes* :93-205, Cobafa* :209-266.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Any, Callable, List, Optional, Sequence, Tuple, cast
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+
+# --------------------------------------------------------------------------------------------
+# fused MLP plumbing
+# --------------------------------------------------------------------------------------------
+def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,
+              freqs: Optional[torch.Tensor]) -> L.MlpDesc:
+    n_layers = len(params) // 2
+    if n_layers > L.TN_MLP_MAX_LAYERS:
+        raise RuntimeError(f"MLP with {n_layers} layers exceeds the kernel limit {L.TN_MLP_MAX_LAYERS}")
+    d = L.MlpDesc()
+    d.n_layers = n_layers
+    d.in_dim = in_dim
+    d.encoding = encoding
+    d.n_freqs = n_freqs
+    d.out_activation = out_act
+    d.freqs = freqs.data_ptr() if freqs is not None else None
+    d.dims[0] = params[0].size(1)
+    for l in range(n_layers):
+        w, b = params[2 * l], params[2 * l + 1]
+        d.dims[l + 1] = w.size(0)
+        d.weights[l] = w.data_ptr()
+        d.biases[l] = b.data_ptr()
+    return d
+
+
+class _FusedMLP(Function):
+    """y = act(MLP(enc(x, aux))) in one launch; backward recomputes the hidden activations."""
+
+    @staticmethod
+    def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
+                n_freqs: int, out_act: int, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.size(-1)).to(torch.float32).contiguous()
+        aux2 = None if aux is None else aux.reshape(-1, aux.size(-1)).to(torch.float32).contiguous()
+        ps = [p.contiguous() for p in params]
+        dev = L.require_cuda(x2, aux2, *ps)
+        n = x2.size(0)
+        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
+        y = torch.empty((n, ps[-1].numel()), device=dev)
+        L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
+        ctx.save_for_backward(x2, aux2, freqs, *ps)
+        ctx.cfg = (encoding, n_freqs, out_act)
+        ctx.x_shape = x.shape
+        return y.reshape(*lead, y.size(-1))
+
+    @staticmethod
+    def backward(ctx: Any, grad_y: torch.Tensor):  # type: ignore
+        x2, aux2, freqs, *ps = ctx.saved_tensors
+        encoding, n_freqs, out_act = ctx.cfg
+        dev = x2.device
+        n = x2.size(0)
+        gy = grad_y.reshape(n, -1).to(torch.float32).contiguous()
+        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
+        grads = [torch.zeros_like(p) for p in ps]
+        n_layers = len(ps) // 2
+        gw = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[0::2]])
+        gb = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[1::2]])
+        want_gx = ctx.needs_input_grad[0] and encoding != L.ENC_POSENC
+        gx = torch.empty_like(x2) if want_gx else None
+        L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx))
+        gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
+        return (gx_out, None, None, None, None, None, *grads)
+
+
+def _linear_params(net: torch.nn.Sequential) -> List[torch.Tensor]:
+    out: List[torch.Tensor] = []
+    for m in net.modules():
+        if isinstance(m, torch.nn.Linear):
+            out += [m.weight, m.bias]
+    return out
+
+
+class MLP(torch.nn.Module):
+    """Linear(in,h) ReLU [Linear(h,h) ReLU]*L Linear(h,out) -- models.py:7-28."""
+
+    def __init__(
+        self,
+        in_features: int,
+        hidden_features: int,
+        hidden_layers: int,
+        out_features: int | None = None,
+        activation: Callable = torch.nn.ReLU,
+    ):
+        super().__init__()
+        if activation is not torch.nn.ReLU:
+            raise NotImplementedError("the fused MLP kernel implements ReLU hidden activations (the only one the reference uses)")
+        out_features = out_features if out_features is not None else hidden_features
+        self.net = torch.nn.Sequential(
+            torch.nn.Linear(in_features, hidden_features),
+            activation(),
+            *[torch.nn.Sequential(
+                torch.nn.Linear(hidden_features, hidden_features),
+                activation()
+            ) for _ in range(hidden_layers)],
+            torch.nn.Linear(hidden_features, out_features)
+        )
+
+    def params(self) -> List[torch.Tensor]:
+        return _linear_params(self.net)
+
+    def fused(self, x: torch.Tensor, aux: Optional[torch.Tensor] = None, encoding: int = L.ENC_NONE, n_freqs: int = 0,
+              out_act: int = L.ACT_NONE, freqs: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, *self.params())
+
+    def forward(self, x: torch.Tensor):
+        return self.fused(x)
+
+
+class PositionalEncoding(torch.nn.Module):
+    """[sin(x f_j), cos(x f_j)] per coordinate, f_j = 2^j pi -- models.py:30-39."""
+
+    def __init__(self, n_freqs: int):
+        super().__init__()
+        self.freqs: torch.Tensor
+        self.register_buffer("freqs", 2 ** torch.arange(0, n_freqs) * torch.pi)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x2 = x.reshape(-1, x.size(-1)).to(torch.float32).contiguous()
+        fr = self.freqs.to(torch.float32).contiguous()
+        dev = L.require_cuda(x2, fr)
+        F = fr.numel()
+        out = torch.empty((x2.size(0), x2.size(1) * 2 * F), device=dev)
+        L.call("tn_posenc_fwd", dev, L.ptr(x2), C.c_int64(x2.size(0)), C.c_int(x2.size(1)), L.ptr(fr), C.c_int(F), L.ptr(out))
+        return out.reshape(*x.shape[:-1], out.size(-1))
+
+
+class TruncatedExponential(Function):  # pylint: disable=abstract-method
+    """exp with a clamped backward (models.py:42-53); inside the heads it is fused into the MLP kernel."""
+
+    @staticmethod
+    def forward(ctx, x):  # pylint: disable=arguments-differ
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):  # pylint: disable=arguments-differ
+        x = ctx.saved_tensors[0]
+        return g * torch.exp(torch.clamp(x, min=-15, max=15))
+
+
+truncated_exp: Callable = TruncatedExponential.apply
+
+
+# --------------------------------------------------------------------------------------------
+# Vanilla NeRF (models.py:59-89)
+# --------------------------------------------------------------------------------------------
+class VanillaFeatureMLP(torch.nn.Module):
+    def __init__(self, n_freqs: int, hidden_features: int, hidden_layers: int):
+        super().__init__()
+        in_features = n_freqs * 2 * 3
+        self.encoding = PositionalEncoding(n_freqs=n_freqs)
+        self.net = MLP(in_features, hidden_features, hidden_layers)
+        self.feature_dim = hidden_features
+        self.n_freqs = n_freqs
+
+    def forward(self, x):
+        # PE fused into the first layer of the MLP launch
+        return self.net.fused(x, None, L.ENC_POSENC, self.n_freqs, L.ACT_NONE, self.encoding.freqs)
+
+
+class VanillaOpacityDecoder(torch.nn.Module):
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.net = MLP(feature_dim, 64, 0, 1)
+        self.activation = lambda x: truncated_exp(x - 1.)
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        # exp(y - 1) fused as the output activation (gradient clamp of truncated_exp kept in the backward kernel)
+        return self.net.fused(features, None, L.ENC_NONE, 0, L.ACT_EXP_M1)
+
+
+class VanillaColorDecoder(torch.nn.Module):
+    def __init__(self, n_freqs: int, in_features: int, hidden_features: int, hidden_layers: int):
+        super().__init__()
+        self.pe = PositionalEncoding(n_freqs)
+        total_features = in_features + n_freqs * 2 * 3 + 3
+        self.net = MLP(total_features, hidden_features, hidden_layers, 3)
+        self.activation = torch.nn.Sigmoid()
+        self.n_freqs = n_freqs
+
+    def forward(self, features: torch.Tensor, rays_d: torch.Tensor) -> torch.Tensor:
+        # cat[PE(d), d, features] is formed in registers; sigmoid fused
+        return self.net.fused(features, rays_d, L.ENC_DIR_CAT, self.n_freqs, L.ACT_SIGMOID, self.pe.freqs)
+
+
+# --------------------------------------------------------------------------------------------
+# K-Planes (models.py:93-205)
+# --------------------------------------------------------------------------------------------
+def _hwc(plane: torch.Tensor) -> torch.Tensor:
+    """[1,C,H,W] channels_last parameter -> the [H,W,C] memory the kernels index (no copy)."""
+    p = plane if plane.is_contiguous(memory_format=torch.channels_last) else plane.contiguous(memory_format=torch.channels_last)
+    return p.permute(0, 2, 3, 1)[0]
+
+
+def _kplanes_desc(planes: Sequence[Optional[torch.Tensor]]) -> Tuple[L.KPlanesDesc, List[torch.Tensor]]:
+    n_scales = len(planes) // 3
+    if n_scales > L.TN_KPLANES_MAX_SCALES:
+        raise RuntimeError("too many K-Planes scales for the kernel")
+    d = L.KPlanesDesc()
+    d.n_scales = n_scales
+    d.channels = planes[0].size(1)
+    keep = []
+    for s in range(n_scales):
+        d.height[s] = planes[3 * s].size(2)
+        d.width[s] = planes[3 * s].size(3)
+        for p in range(3):
+            if planes[3 * s + p] is None:           # absent plane = factor 1
+                d.planes[s][p] = None
+                continue
+            hwc = _hwc(planes[3 * s + p])
+            assert hwc.is_contiguous()
+            keep.append(hwc)
+            d.planes[s][p] = hwc.data_ptr()
+    return d, keep
+
+
+class _KPlanesFeatures(Function):
+    @staticmethod
+    def forward(ctx: Any, x: torch.Tensor, *planes: torch.Tensor) -> torch.Tensor:  # type: ignore
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, 3).to(torch.float32)
+        if x2.stride(1) != 1 or (x2.size(0) > 1 and x2.stride(0) < 3):
+            x2 = x2.contiguous()
+        if not x2.is_cuda:
+            raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
+        dev = x2.device
+        desc, keep = _kplanes_desc(planes)
+        n = x2.size(0)
+        stride = x2.stride(0) if n > 1 else 3
+        feat = torch.empty((n, desc.n_scales * desc.channels), device=dev)
+        L.call("tn_kplanes_fwd", dev, C.byref(desc), L.ptr(x2), C.c_int64(stride), C.c_int64(n), L.ptr(feat))
+        ctx.present = [p is not None for p in planes]
+        ctx.save_for_backward(x2, *[p if p is not None else x2.new_empty(0) for p in planes])
+        return feat.reshape(*lead, feat.size(-1))
+
+    @staticmethod
+    def backward(ctx: Any, grad_feat: torch.Tensor):  # type: ignore
+        x2, *planes = ctx.saved_tensors
+        dev = x2.device
+        desc, keep = _kplanes_desc([p if ctx.present[i] else None for i, p in enumerate(planes)])
+        n = x2.size(0)
+        stride = x2.stride(0) if n > 1 else 3
+        g = grad_feat.reshape(n, -1).to(torch.float32).contiguous()
+        planes = [p if ctx.present[i] else None for i, p in enumerate(planes)]
+        grads = [None if p is None else torch.zeros_like(p, memory_format=torch.channels_last) for p in planes]
+        gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
+        for s in range(desc.n_scales):
+            for p in range(3):
+                gp[s][p] = None if grads[3 * s + p] is None else _hwc(grads[3 * s + p]).data_ptr()
+        L.call("tn_kplanes_bwd", dev, C.byref(desc), L.ptr(x2), C.c_int64(stride), C.c_int64(n), L.ptr(g), gp)
+        return (None, *grads)
+
+
+class KPlanesFeaturePlane(torch.nn.Module):
+    def __init__(
+        self,
+        feature_dim: int = 8,
+        resolution: Tuple[int, int] = (128, 128),
+        init: Callable = torch.nn.init.uniform_,
+    ):
+        super().__init__()
+        self.feature_dim = feature_dim
+        # logical [1,C,H,W] like the reference; physically channel-last so a texel is one cache line
+        self.plane = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution).contiguous(memory_format=torch.channels_last))
+        init(self.plane)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (..., 2) -> (..., C).  A single plane is the field kernel with one scale whose other two
+        planes are absent (factor 1)."""
+        x3 = torch.cat([x.reshape(-1, 2).float(), torch.zeros((x.numel() // 2, 1), device=x.device)], -1)
+        out = _KPlanesFeatures.apply(x3, self.plane, None, None)
+        return out.view([*x.size()[:-1], self.feature_dim])
+
+    def loss_tv(self) -> torch.Tensor:
+        tv_x = torch.nn.functional.mse_loss(self.plane[:, :, 1:, :], self.plane[:, :, :-1, :])
+        tv_y = torch.nn.functional.mse_loss(self.plane[:, :, :, 1:], self.plane[:, :, :, :-1])
+        return tv_x + tv_y
+
+    def loss_l1(self) -> torch.Tensor:
+        return torch.mean(torch.abs(self.plane))
+
+
+class KPlanesFeatureField(torch.nn.Module):
+    def __init__(self, feature_dim: int = 32):
+        super().__init__()
+        self.planes = torch.nn.ModuleList([
+            torch.nn.ModuleList([KPlanesFeaturePlane(feature_dim, resolution=(r, r)) for _ in range(3)])
+            for r in (128, 256, 512)
+        ])
+        self.dropout = torch.nn.Dropout(0.)
+        # coordinate pairs, in this order (models.py:144-146); the kernel hard-codes the same order
+        self.dimension_pairs = list(itertools.combinations(range(3), 2))
+        self.feature_dim = 32 * len(self.planes)   # the reference hard-codes 32 here too (models.py:147)
+        for plane_scale in self.planes:
+            assert isinstance(plane_scale, torch.nn.ModuleList)
+            assert len(plane_scale) == len(self.dimension_pairs)
+
+    def plane_tensors(self) -> List[torch.Tensor]:
+        return [cast(KPlanesFeaturePlane, p).plane for scale in self.planes for p in cast(torch.nn.ModuleList, scale)]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (..., 3) -> (..., C * n_scales): Hadamard product of the 3 planes per scale, scales concatenated."""
+        return self.dropout(_KPlanesFeatures.apply(x, *self.plane_tensors()))
+
+    def loss_tv(self) -> torch.Tensor:
+        vals = [cast(KPlanesFeaturePlane, p).loss_tv() for scale in self.planes for p in cast(torch.nn.ModuleList, scale)]
+        return cast(torch.Tensor, sum(vals)) / len(vals)
+
+    def loss_l1(self) -> torch.Tensor:
+        vals = [cast(KPlanesFeaturePlane, p).loss_l1() for scale in self.planes for p in cast(torch.nn.ModuleList, scale)]
+        return cast(torch.Tensor, sum(vals)) / len(vals)
+
+
+class KPlanesExplicitOpacityDecoder(torch.nn.Module):
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.net = torch.nn.Linear(feature_dim, feature_dim)
+        self.activation = lambda x: truncated_exp(x - 1.)
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        x = torch.sum(features * self.net(features), -1, keepdim=True)
+        return self.activation(x)
+
+
+class KPlanesExplicitColorDecoder(torch.nn.Module):
+    def __init__(self, feature_dim, n_freqs=8, hidden_dim=128):
+        super().__init__()
+        self.pe = PositionalEncoding(n_freqs)
+        self.feature_dim = feature_dim
+        self.n_freqs = n_freqs
+        in_dim = feature_dim + n_freqs * 2 * 3 + 3
+        self.net = MLP(in_dim, hidden_dim, 3, 3 * feature_dim)
+
+    def forward(self, features: torch.Tensor, rays_d: torch.Tensor) -> torch.Tensor:
+        x = self.net.fused(features, rays_d, L.ENC_DIR_CAT, self.n_freqs, L.ACT_NONE, self.pe.freqs)
+        x = x.view(-1, 3, self.feature_dim)
+        output = torch.sum(features.unsqueeze(-2) * x, -1)
+        return torch.sigmoid(output)
+
+
+# --------------------------------------------------------------------------------------------
+# CoBaFa (models.py:209-266) -- API-compatible; grids sampled by torch on the device, the
+# 128-wide MLP by the fused kernel.  Fused Cobafa gathers are SURVEY 8(f)-3 (next).
+# --------------------------------------------------------------------------------------------
+class SawtoothEncoding(torch.nn.Module):
+    def __init__(self, f):
+        super().__init__()
+        self.f = f
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return 2. * ((self.f * x) % 1.) - 1.
+
+
+class CobafaGrid(torch.nn.Module):
+    def __init__(self, res: int | Tuple[int, int, int], feature_dim: int, init: Callable = torch.nn.init.uniform_):
+        super().__init__()
+        resolution = (res, res, res) if isinstance(res, int) else res
+        self.grid = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution))
+        self.feature_dim = feature_dim
+        init(self.grid)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        new_shape = [*x.size()[:-1], self.feature_dim]
+        output = torch.nn.functional.grid_sample(self.grid, x.view(1, -1, 1, 1, 3), align_corners=True)
+        return output.view(self.feature_dim, -1).transpose(0, 1).contiguous().view(new_shape)
+
+
+class CobafaFeatureField(torch.nn.Module):
+    def __init__(self, basis_res: List[int | Tuple[int, int, int]], coef_res: int | Tuple[int, int, int],
+                 freqs: List[float], channels: List[int], mlp_hidden_dim: int):
+        super().__init__()
+        assert len(basis_res) == len(freqs) == len(channels)
+        n = len(basis_res)
+        self.basis_grids = torch.nn.ModuleList([CobafaGrid(res, c) for res, c in zip(basis_res, channels)])
+        self.encoders = torch.nn.ModuleList([SawtoothEncoding(f) for f in freqs])
+        self.coef_grid = CobafaGrid(coef_res, n)
+        self.dropout = torch.nn.Dropout(0.01)
+        self.mlp = MLP(sum(channels), mlp_hidden_dim, 5)
+        self.feature_dim = mlp_hidden_dim
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        coefs = self.coef_grid(x)
+        features = []
+        for i, (encoder, basis) in enumerate(zip(self.encoders, self.basis_grids)):
+            features.append(basis(encoder(x)) * coefs[:, [i]])
+        return self.mlp(self.dropout(torch.cat(features, -1)))

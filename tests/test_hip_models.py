@@ -172,3 +172,68 @@ def test_cobafa_forward():
     cf.to(DEV).eval()
     out = cf(cu(g["x"]))
     assert out.shape == (128, 32)
+
+
+def _grads(module):
+    return {n: p.grad.detach().cpu().numpy() for n, p in module.named_parameters()}
+
+
+def test_vanilla_heads_backward():
+    """gradients of sigma / rgb w.r.t. every parameter of the feature MLP and the decoders (G8)."""
+    m = models()
+    g = load_golden("G8_vanilla_heads")
+    fm = m.VanillaFeatureMLP(6, 64, 3); od = m.VanillaOpacityDecoder(64); cd = m.VanillaColorDecoder(8, 64, 64, 3)
+    fm.load_state_dict(sub(g, "fm.")); od.load_state_dict(sub(g, "od.")); cd.load_state_dict(sub(g, "cd."))
+    fm.to(DEV); od.to(DEV); cd.to(DEV)
+    x, dirs = cu(g["x"]), cu(g["dirs"])
+    sig = od(fm(x))
+    (sig * cu(g["grad_sigma"])).sum().backward()
+    for name, got in {**{"fm." + k: v for k, v in _grads(fm).items()}, **{"od." + k: v for k, v in _grads(od).items()}}.items():
+        ref = g["gsig." + name]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+    fm.zero_grad(); od.zero_grad()
+    rgb = cd(fm(x), dirs)
+    (rgb * cu(g["grad_rgb"])).sum().backward()
+    for name, got in {**{"fm." + k: v for k, v in _grads(fm).items()}, **{"cd." + k: v for k, v in _grads(cd).items()}}.items():
+        ref = g["grgb." + name]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+
+
+def test_decoders_96_backward():
+    """K-Planes-shaped heads: grads w.r.t. parameters AND the incoming features (G8b)."""
+    m = models()
+    g = load_golden("G8b_decoders_96")
+    od = m.VanillaOpacityDecoder(96); cd = m.VanillaColorDecoder(8, 96, 64, 3)
+    od.load_state_dict(sub(g, "od.")); cd.load_state_dict(sub(g, "cd.")); od.to(DEV); cd.to(DEV)
+    feat = cu(g["feat"]).requires_grad_(True)
+    s = od(feat); c = cd(feat, cu(g["dirs"]))
+    ((s * cu(g["grad_sigma"])).sum() + (c * cu(g["grad_rgb"])).sum()).backward()
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), g["grad_feat"], rtol=1e-4, atol=TOL)
+    for name, got in _grads(od).items():
+        ref = g["god." + name]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+    for name, got in _grads(cd).items():
+        ref = g["gcd." + name]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+
+
+def test_mlp_backward_ragged_sizes_vs_torch():
+    """n not a multiple of 32, several tiles per wave: the fused backward against torch autograd of the
+    same fp32 network evaluated with torch ops on the device."""
+    m = models()
+    torch.manual_seed(3)
+    net = m.MLP(40, 64, 2, 3).to(DEV)
+    x = torch.randn(1000 + 17, 40, device=DEV, requires_grad=True)
+    gy = torch.randn(1017, 3, device=DEV)
+    y = net(x)
+    y.backward(gy)
+    got = {n: p.grad.clone() for n, p in net.named_parameters()}
+    gx = x.grad.clone()
+    net.zero_grad(); x.grad = None
+    y2 = net.net(x)                      # torch.nn.Sequential of the same Linear layers (rocBLAS fp32)
+    y2.backward(gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), atol=TOL)
+    np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-4, atol=TOL)
+    for n_, p in net.named_parameters():
+        ref = p.grad.cpu().numpy()
+        np.testing.assert_allclose(got[n_].cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=n_)

@@ -33,6 +33,7 @@ SOURCES = {
     "encoding.hip": FAST,
     "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp.hip": FAST,
+    "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
     "render.hip": FAST + ["-munsafe-fp-atomics"],
 }
 

@@ -115,13 +115,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
         stage_weights(a, lds);
         __syncthreads();
     }
-    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int64_t n_tiles = (n + 31) >> 5;
     const int L = a.n_layers;
     const int G0 = a.K0_pad >> 3;
 
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        // keep per-lane weight addresses out of LICM's reach (hoisted, they cost dozens of VGPRs)
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
             b = bn;
         }
 #pragma unroll
-        for (int ob = 0; ob < T; ++ob) act[ob] = tn::relu16(act[ob]);
+        for (int ob = 0; ob < T; ++ob) { tn::pin16(act[ob]); act[ob] = tn::relu16(act[ob]); }
         // ---- hidden layers H -> H ----
         for (int l = 1; l + 1 < L; ++l) {
             const float *Wl = WLDS ? lds + a.w_off[l] : a.W[l];
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
                         for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], act[kb][4 * q + u], acc);
                     }
                 }
+                tn::pin16(acc);
                 if (valid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

@@ -37,6 +37,16 @@ __device__ __forceinline__ f32x16 bias_tile(const float *bias, int ob, int h) {
     return y;
 }
 
+// Materialise an MFMA result in VGPRs HERE, in straight-line code.  hipcc (ROCm 7.2) counts the MFMA ->
+// v_accvgpr_read wait states along the longest predecessor path only: when a branch sits between the last
+// MFMA and the first read of its accumulator, the short path reads a[15] (written in the final pass) too
+// early and gets a stale value -- observed as rare wrong values in output register 15 only.  Every chain
+// whose result is consumed under a branch is therefore pinned first.
+__device__ __forceinline__ void pin16(f32x16 &v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
+}
+
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
@@ -68,7 +78,7 @@ __device__ __forceinline__ void hidden_layer(const float *__restrict__ W, const 
         }
     }
 #pragma unroll
-    for (int ob = 0; ob < T; ++ob) x[ob] = relu16(y[ob]);
+    for (int ob = 0; ob < T; ++ob) { pin16(y[ob]); x[ob] = relu16(y[ob]); }
 }
 
 // out[o] = <W[o][:], x> + b[o] for a few outputs (o < NOUT <= 4) on the VALU: each lane reduces the

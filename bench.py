@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ray-samples/sec of the K-Planes training step on synthetic Lego-shaped input.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+K-Planes field (3 scales x 3 planes of 32 channels, 128^2/256^2/512^2) + Vanilla sigma / colour
+decoders, aabb +-1.5, S = 1024 candidates per ray, B = 1024 rays per loader batch, dynamic batches of
+~B*S = 2^20 packed samples per step, 128^3 occupancy grid occupied inside a centred ball of radius 0.5
+(normalised), 800x800 pinhole cameras on the radius-4.0311 sphere, synthetic colours.  All inputs are
+resident in HBM before the timed region.
+
+A "step" is one full pass of the hot path as train() drives it (reference run.py:215-261): dynamic
+batch assembly by the sampler, render forward, MSE (+TV) loss, backward through every kernel, Adam
+step, LR scheduler step (+ gradient all-reduce when N > 1, + the occupancy refresh whenever the
+reference's schedule puts one inside the window).  value = packed samples processed by all ranks /
+wall time of exactly K steps (barrier + synchronize on both sides, max over ranks).
+
+The line also carries `roofline` for the dominant kernel (HIP-event timed on its own stream) and
+`cpu_baseline` (the CPU port of the same step, oracle/torch_port.py, on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+# algorithmic work per unit of the kernels that can dominate
+FLOP_SIGMA_FWD = 2 * (96 * 64 + 64)                                   # 12 416   
+FLOP_RGB_FWD = 2 * (147 * 64 + 3 * 64 * 64 + 64 * 3)                  # 43 776   
+KERNEL_MODEL = {
+    # entry point            (bound, unit work per row, what a row is)
+    "tn_mlp_bwd:rgb": ("mfma", 2 * FLOP_RGB_FWD, "active sample"),
+    "tn_mlp_bwd:sigma": ("mfma", 2 * FLOP_SIGMA_FWD, "sample"),
+    "tn_mlp_fwd:rgb": ("mfma", FLOP_RGB_FWD, "active sample"),
+    "tn_mlp_fwd:sigma": ("mfma", FLOP_SIGMA_FWD, "sample"),
+    "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample"),            # coords + 36 texel-halves*... + feat row
+    "tn_kplanes_bwd": ("hbm", 12 + 384 + 4608 + 2 * 4608, "sample"),  # + gather again + atomic RMW
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=20, help="synthetic 800x800 cameras (640k rays each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1 << 16)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI entry points on the stream they are launched on."""
+
+    def __init__(self):
+        self.records = {}
+
+    def install(self):
+        from tinynerf_amd import _lib as L
+        orig = L.call
+        timer = self
+
+        def timed_call(name, device, *args):
+            tag = name
+            if name in ("tn_mlp_fwd", "tn_mlp_bwd"):
+                desc = args[0]._obj
+                tag = name + (":rgb" if desc.encoding == L.ENC_DIR_CAT else ":sigma")
+            if tag not in KERNEL_MODEL or not timer.enabled:
+                return orig(name, device, *args)
+            rows = int(args[3].value) if name.startswith("tn_kplanes") else int(args[3].value if name == "tn_mlp_fwd" else args[4].value)
+            s = torch.cuda.current_stream(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            orig(name, device, *args)
+            e1.record(s)
+            timer.records.setdefault(tag, []).append((e0, e1, rows))
+
+        self.enabled = False
+        L.call = timed_call
+
+    def summary(self):
+        out = {}
+        for tag, recs in self.records.items():
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in recs]
+            rows = [r for _, _, r in recs]
+            out[tag] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), avg_rows=sum(rows) / len(rows))
+        return out
+
+
+def cpu_baseline(trainer, n_target: int):
+    """The CPU port of the same training step (render fwd + loss + bwd) on a bounded sample of the same
+    workload: the first rays of a real batch totalling ~n_target packed samples."""
+    import numpy as np
+    from oracle import torch_port as tp
+    packed, info, target, _ = trainer.build_batch()
+    cnt = info[:, 1].long().cumsum(0)
+    R = int((cnt <= n_target).sum().item())
+    n = int(cnt[R - 1].item())
+    packed, info, target = packed[:n].cpu(), info[:R].cpu(), target[:R].cpu()
+    sd = {k: v.detach().cpu().contiguous() for k, v in trainer.renderer.state_dict().items()}
+    bg = trainer.renderer.bg_color.cpu() if trainer.renderer.bg_color is not None else None
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        tp.grads_of(sd, lambda p: tp.training_loss(p, packed, info, target, bg))
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"render fwd+loss+bwd of {n} packed samples / {R} rays of the same batch (no Adam step), "
+                      f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, best of 2 after warm-up"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: tinynerf_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    from tinynerf_amd import rays
+    from tinynerf_amd.run import TrainConfig, Trainer
+
+    timer = KernelTimer()
+    timer.install()
+
+    o, d, rgbs, K, _ = rays.synthetic_scene(n_views=args.views, res=800, seed=rank, device=str(dev))
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
+    tr = Trainer(cfg, o, d, rgbs, torch.ones(3, device=dev), dev, rank=rank, world_size=world)
+    # occupancy: 1 inside the centred ball of radius 0.5 (normalised coords), decay^20 elsewhere
+    lin = torch.linspace(-1, 1, 128, device=dev)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    tr.occupancy_grid.grid.copy_(torch.where(xx * xx + yy * yy + zz * zz < 0.25, 1.0, tr.occupancy_grid.decay ** 20))
+    tr.occupancy_grid.mean = float(tr.occupancy_grid.grid.mean().item())
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step()
+    sync()
+    timer.enabled = True
+    samples = 0.0
+    rays_n = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = tr.step()
+        samples += st["n_samples"]
+        rays_n += st["n_rays"]
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    stats = torch.tensor([dt, samples, rays_n], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(stats[1:])
+        stats[0] = tmax[0]
+    dt, samples, rays_n = stats.tolist()
+    loss = tr.loss_value()
+
+    if rank == 0:
+        ks = timer.summary()
+        dom = max(ks, key=lambda t: ks[t]["total_ms"]) if ks else None
+        roof = None
+        if dom:
+            bound, unit_work, unit = KERNEL_MODEL[dom]
+            k = ks[dom]
+            per_launch = unit_work * k["avg_rows"]
+            if bound == "mfma":
+                achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+            else:
+                achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+            roof.update(kernel=dom, avg_launch_ms=k["avg_ms"], rows_per_launch=k["avg_rows"], row=unit,
+                        algorithmic_per_row=unit_work)
+        line = {
+            "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
+                       "parallelism": f"rays sharded over {world} rank(s), RCCL gradient all-reduce" if world > 1 else "single GPU",
+                       "samples_per_step_per_gpu": samples / args.steps / world, "rays_per_step_per_gpu": rays_n / args.steps / world},
+            "loss": loss,
+            "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tr, args.cpu_samples)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

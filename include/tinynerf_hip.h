@@ -125,6 +125,12 @@ int tn_sample_mask(const tn_sampler_desc *desc, const float *rays_o, const float
  * base_offset (device int32, may be NULL = 0) implements run.py:231 `info[:,0] += current_size`. */
 int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32_t *base_offset,
                    int32_t *info, int32_t *total, void *stream);
+/* a8 (reference run.py:215-244), device side: the harness draws loader batches of `batch_size` rays until
+ * int(cur*(1+1/k)) >= target.  Given the kept-sample counts of n_rays = n_batches*batch_size candidate rays,
+ * plan[0] = k (loader batches consumed), plan[1] = N (packed samples), plan[2] = R = k*batch_size rays,
+ * plan[3] = 1 if the rule tripped within the supplied rays (else every supplied batch is used). */
+int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
+                  void *stream);
 /* pass 3: packed[start_r - base + j] = (contracted xyz, ray dir, step) for the j-th set bit
  * (core.py:182-186).  ray_ids (optional) receives the ray index of every packed sample. */
 int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d,

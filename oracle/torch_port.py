@@ -1,0 +1,144 @@
+"""Differentiable CPU port of the render path, op for op what the reference executes.
+
+TEST INFRASTRUCTURE ONLY (see oracle/tinynerf_oracle.py): used by tests/ as the gradient oracle at
+sizes where golden vectors would be too large, and by ``bench.py``'s ``cpu_baseline`` leg, where it
+stands for "the reference's CPU path" (the reference itself has no CPU weights kernel).
+
+Functional restatement with torch CPU ops -- the same ATen primitives the reference calls
+(grid_sample / linear / index_add_; reference src/models.py:93-163,7-89 and src/core.py:225-267) --
+plus the C restatement of the weights kernels (oracle/weights_ref.c) wrapped in an autograd Function.
+Parameters are passed as a flat dict with the reference's state_dict keys.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import tinynerf_oracle as orc
+
+PAIRS = list(itertools.combinations(range(3), 2))        # models.py:146
+
+
+def plane_lookup(plane: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
+    """models.py:105-113: bilinear, zeros padding, align_corners=True -> [N,C]."""
+    out = torch.nn.functional.grid_sample(plane, xy.view(1, -1, 1, 2), align_corners=True)
+    return out.view(plane.size(1), -1).t()
+
+
+def kplanes_features(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix: str = "feature_module.") -> torch.Tensor:
+    """models.py:153-163."""
+    feats = []
+    s = 0
+    while f"{prefix}planes.{s}.0.plane" in sd:
+        prod = None
+        for p, (i, j) in enumerate(PAIRS):
+            v = plane_lookup(sd[f"{prefix}planes.{s}.{p}.plane"], x[:, (i, j)])
+            prod = v if prod is None else prod * v
+        feats.append(prod)
+        s += 1
+    return torch.cat(feats, -1)
+
+
+def _layers(sd: Dict[str, torch.Tensor], prefix: str):
+    keys = sorted({k[len(prefix):].rsplit(".", 1)[0] for k in sd if k.startswith(prefix) and k.endswith(".weight")},
+                  key=lambda s: int(s.split(".")[0]))
+    return [(sd[prefix + k + ".weight"], sd[prefix + k + ".bias"]) for k in keys]
+
+
+def mlp(sd, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """models.py:7-28."""
+    layers = _layers(sd, prefix)
+    for li, (w, b) in enumerate(layers):
+        x = torch.nn.functional.linear(x, w, b)
+        if li + 1 < len(layers):
+            x = torch.relu(x)
+    return x
+
+
+def posenc(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """models.py:36-39."""
+    a = x[..., None] * freqs
+    return torch.cat([torch.sin(a), torch.cos(a)], -1).flatten(-2)
+
+
+class _TruncExp(torch.autograd.Function):
+    """models.py:42-53."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(torch.clamp(ctx.saved_tensors[0], min=-15, max=15))
+
+
+class _Weights(torch.autograd.Function):
+    """core.py:192-207 over the C restatement of cuda.cu."""
+
+    @staticmethod
+    def forward(ctx, sigmas, steps, info, thr):
+        w = torch.from_numpy(orc.weights_fwd(sigmas.detach().numpy(), steps.detach().numpy(), info.numpy(), float(thr)))
+        ctx.save_for_backward(sigmas, steps, info, w)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        s, d, info, w = ctx.saved_tensors
+        gs = orc.weights_bwd(s.detach().numpy(), d.detach().numpy(), info.numpy(), w.numpy(), g.contiguous().numpy())
+        return torch.from_numpy(gs), None, None, None
+
+
+def render(sd: Dict[str, torch.Tensor], packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor],
+           thr: float = 1e-4, vanilla_freqs: int = 0) -> torch.Tensor:
+    """core.py:225-267 for a K-Planes (or Vanilla, vanilla_freqs > 0) field with the Vanilla decoders."""
+    n, R = packed.size(0), info.size(0)
+    x = packed[:, :3]
+    if vanilla_freqs:
+        feat = mlp(sd, "feature_module.net.net.", posenc(x, sd["feature_module.encoding.freqs"]))
+    else:
+        feat = kplanes_features(sd, x)
+    sig = _TruncExp.apply(mlp(sd, "sigma_decoder.net.net.", feat) - 1.).ravel()
+    w = _Weights.apply(sig, packed[:, 6].contiguous(), info, thr)
+    mask = w > 0
+    rgbs = torch.zeros((n, 3))
+    if mask.any():
+        d = packed[:, 3:6][mask]
+        inp = torch.cat([posenc(d, sd["rgb_decoder.pe.freqs"]), d, feat[mask]], -1)
+        rgbs = rgbs.index_put((torch.nonzero(mask).squeeze(1),), torch.sigmoid(mlp(sd, "rgb_decoder.net.net.", inp)))
+    rgbs = rgbs * w[:, None]
+    idx = torch.repeat_interleave(torch.arange(R), info[:, 1].long())
+    out = torch.zeros((R, 3)).index_add(0, idx, rgbs)
+    if bg is not None:
+        op = torch.zeros(R).index_add(0, idx, w)
+        out = out + bg * (1 - op[:, None])
+    return out
+
+
+def loss_tv(sd, prefix: str = "feature_module.") -> torch.Tensor:
+    """models.py:115-118,165-172."""
+    vals = []
+    for k, p in sd.items():
+        if k.startswith(prefix) and k.endswith(".plane"):
+            vals.append(torch.nn.functional.mse_loss(p[:, :, 1:, :], p[:, :, :-1, :]) +
+                        torch.nn.functional.mse_loss(p[:, :, :, 1:], p[:, :, :, :-1]))
+    return sum(vals) / len(vals)
+
+
+def training_loss(sd, packed, info, target, bg, tv_alpha: float = 1e-4) -> torch.Tensor:
+    """run.py:251-256 for method == kplanes."""
+    out = render(sd, packed, info, bg)
+    return torch.nn.functional.mse_loss(out, target) + tv_alpha * loss_tv(sd)
+
+
+def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
+    """Run loss_fn on a leaf copy of every floating parameter and return d loss / d param."""
+    leaves = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v)
+              for k, v in sd.items()}
+    loss = loss_fn(leaves)
+    loss.backward()
+    return {k: v.grad.numpy() for k, v in leaves.items() if isinstance(v, torch.Tensor) and v.grad is not None}, float(loss)

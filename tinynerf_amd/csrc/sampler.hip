@@ -236,6 +236,38 @@ __global__ __launch_bounds__(1024) void sample_scan_kernel(
     if (threadIdx.x == 0 && total) total[0] = carry_s;
 }
 
+// reference run.py:215-244 -- the dynamic-batch projection rule evaluated on the device: per-loader-batch sums
+// by wave reductions, then the (inherently sequential, <= 4096 steps) rule on one lane.
+__global__ __launch_bounds__(1024) void batch_plan_kernel(const int32_t *__restrict__ counts, int64_t n_rays,
+                                                          int32_t batch_size, int64_t target, int32_t *__restrict__ plan)
+{
+    __shared__ int32_t sums[4096];
+    const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
+    const int n_batches = (int)((n_rays + batch_size - 1) / batch_size);
+    for (int b = wave; b < n_batches; b += 16) {
+        int32_t s = 0;
+        const int64_t lo = (int64_t)b * batch_size;
+        const int64_t hi = lo + batch_size < n_rays ? lo + batch_size : n_rays;
+        for (int64_t r = lo + lane; r < hi; r += 64) s += counts[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) sums[b] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t cur = 0;
+        int k = 0, tripped = 0;
+        while (k < n_batches) {
+            cur += sums[k];
+            ++k;
+            const int64_t projected = (int64_t)((double)cur * (1.0 + 1.0 / (double)k));     // run.py:240
+            if (projected >= target) { tripped = 1; break; }
+        }
+        const int64_t R = (int64_t)k * batch_size < n_rays ? (int64_t)k * batch_size : n_rays;
+        plan[0] = k; plan[1] = (int32_t)cur; plan[2] = (int32_t)R; plan[3] = tripped;
+    }
+}
+
 template <int MARCH, int CONTRACT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_pack_kernel(
     SamplerArgs a, const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays,
@@ -422,6 +454,16 @@ extern "C" int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32
     TN_REQUIRE(n_rays == 0 || (counts && info), TN_E_NULL, "tn_sample_scan: null pointer");
     hipLaunchKernelGGL(sample_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, base_offset, info, total);
     return tn::check_launch("sample_scan_kernel");
+}
+
+extern "C" int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
+                             void *stream)
+{
+    TN_REQUIRE(n_rays >= 0 && batch_size > 0 && target >= 0, TN_E_SIZE, "tn_batch_plan: bad size");
+    TN_REQUIRE((n_rays + batch_size - 1) / batch_size <= 4096, TN_E_SIZE, "tn_batch_plan: more than 4096 loader batches");
+    TN_REQUIRE(plan && (n_rays == 0 || counts), TN_E_NULL, "tn_batch_plan: null pointer");
+    batch_plan_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(counts, n_rays, batch_size, target, plan);
+    return tn::check_launch("batch_plan_kernel");
 }
 
 extern "C" int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,

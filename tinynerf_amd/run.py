@@ -1,0 +1,218 @@
+"""Training / evaluation harness -- the caller side of the hot path (reference ``src/run.py``).
+
+Keeps the reference's recipe literal for literal (run.py:100-114,186-202: 2048*4096/B steps, occupancy
+refresh every 16*4096/B steps, threshold .01, 128^3 grid, decay .01^(1/16), Adam(lr 1e-2, eps 1e-15,
+wd 1e-5), MultiStepLR(1/2, 3/4, 5/6, 9/10; gamma .33), MSE + 1e-4 TV for K-Planes, and the GradScaler
+quirk: the loss is scaled by 2^10 and never unscaled before ``optimizer.step()``, run.py:259-260) but
+re-plumbs the loop MI355X-first:
+
+* rays live in HBM as flat tables; loader batches are device-side index draws (no DataLoader workers);
+* the dynamic batch (run.py:215-244) is built by ONE pass of the sampler over a block of loader batches,
+  the projection rule ``int(cur*(1+1/k)) >= B*S`` is evaluated on the device (``tn_batch_plan``) and a
+  single 16-byte read-back per step replaces the reference's >= 3 host syncs per loader batch;
+* rays shard across ranks (one process per GPU); gradients are summed with RCCL all-reduce, the MSE is
+  normalised by the GLOBAL ray count so the result equals the single-GPU loss.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .core import (ContractionAABB, ContractionMip360, NerfRenderer, OccupancyGrid, RayMarcherAABB,
+                   RayMarcherUnbounded, RayProvider)
+from .models import (CobafaFeatureField, KPlanesFeatureField, VanillaColorDecoder, VanillaFeatureMLP,
+                     VanillaOpacityDecoder)
+
+
+def psnr(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """-10 log10(mse) -- run.py:53-54."""
+    return -10. * torch.log10(torch.mean((x - y) ** 2))
+
+
+@dataclass
+class TrainConfig:
+    method: str = "kplanes"            # vanilla | kplanes | cobafa   (run.py:130-152)
+    scene_type: str = "aabb"           # aabb | unbounded             (run.py:154-162)
+    batch_size: int = 1024             # rays per loader batch
+    n_samples: int = 1024              # candidates per ray
+    scene_scale: float = 1.0           # uniform_range of the unbounded marcher
+    grad_scale: float = 2.0 ** 10      # GradScaler(2**10) without unscale (run.py:201,259-260)
+    seed: int = 0
+
+
+def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: torch.device):
+    """Model / scene construction of run.py:124-182 with the reference's literals."""
+    if cfg.method == "vanilla":
+        feature_module: torch.nn.Module = VanillaFeatureMLP(10, 256, 8)
+    elif cfg.method == "kplanes":
+        feature_module = KPlanesFeatureField(32)
+    elif cfg.method == "cobafa":
+        feature_module = CobafaFeatureField(
+            basis_res=torch.linspace(32., 128, 6).int().tolist(), coef_res=64,
+            freqs=torch.linspace(2., 8., 6).tolist(), channels=[8, 8, 8, 4, 4, 4], mlp_hidden_dim=128)
+    else:
+        raise NotImplementedError(f"Unknown method {cfg.method}.")
+    dim = feature_module.feature_dim
+    sigma_decoder = VanillaOpacityDecoder(dim)
+    rgb_decoder = VanillaColorDecoder(8, dim, 64, 3)
+    if cfg.scene_type == "unbounded":
+        ray_marcher = RayMarcherUnbounded(cfg.n_samples, 0.1, 1e5, uniform_range=cfg.scene_scale)
+        contraction = ContractionMip360(order=float("inf"))
+    elif cfg.scene_type == "aabb":
+        aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]]).to(device)
+        ray_marcher = RayMarcherAABB(aabb, cfg.n_samples, 0.1)
+        contraction = ContractionAABB(aabb)
+    else:
+        raise NotImplementedError(f"Unknown scene type {cfg.scene_type}.")
+    occupancy_grid = OccupancyGrid(size=128, step_size=ray_marcher.step_size, threshold=0.01,
+                                   decay=0.01 ** (1 / 16)).to(device)
+    ray_provider = RayProvider(occupancy_grid=occupancy_grid, contraction=contraction, ray_marcher=ray_marcher)
+    renderer = NerfRenderer(feature_module, sigma_decoder, rgb_decoder, bg_color=bg_color).to(device)
+    return renderer, occupancy_grid, ray_provider
+
+
+class Trainer:
+    """One object = the body of ``train()`` (run.py:97-319) with ``step()`` as the loop iteration."""
+
+    def __init__(self, cfg: TrainConfig, rays_o: torch.Tensor, rays_d: torch.Tensor, rgbs: torch.Tensor,
+                 bg_color: Optional[torch.Tensor], device: torch.device, rank: int = 0, world_size: int = 1):
+        self.cfg, self.device, self.rank, self.world = cfg, device, rank, world_size
+        self.rays_o, self.rays_d, self.rgbs = rays_o, rays_d, rgbs
+        torch.manual_seed(cfg.seed)                    # identical parameters on every rank
+        self.renderer, self.occupancy_grid, self.ray_provider = build_renderer(cfg, bg_color, device)
+        bs_ratio = 4096 / cfg.batch_size
+        self.steps = int(2048 * bs_ratio)
+        self.occupancy_grid_updates = int(16 * bs_ratio)
+        self.tv_reg_alpha, self.l1_reg_alpha = 0.0001, 0.
+        self.target_sample_size = cfg.batch_size * cfg.n_samples
+        params = list(self.renderer.parameters())
+        for p in params:                                # grads keep the parameter's (channels_last) layout
+            p.grad = torch.zeros_like(p)
+        self.optimizer = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
+            self.optimizer, milestones=[self.steps // 2, self.steps * 3 // 4, self.steps * 5 // 6, self.steps * 9 // 10],
+            gamma=0.33)
+        self.train_step = 0
+        self._k_guess = 8
+        # per-rank ray stream: same generator family, different seed -> disjoint draws
+        self._gen = torch.Generator(device=device)
+        self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
+        self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
+        self.last: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------ a8: dynamic batch
+    @torch.no_grad()
+    def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
+        """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass."""
+        cfg, dev = self.cfg, self.device
+        B, S = cfg.batch_size, cfg.n_samples
+        rp = self.ray_provider
+        n_chunks = (S + 63) // 64
+        while True:
+            n_b = min(4096, max(2, int(self._k_guess * 1.5) + 2))
+            idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
+            o, d = self.rays_o[idx], self.rays_d[idx]
+            desc = rp._desc(dev, True, None)
+            desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
+            R_all = n_b * B
+            maskbits = torch.empty((R_all, n_chunks), dtype=torch.int64, device=dev)
+            counts = torch.empty(R_all, dtype=torch.int32, device=dev)
+            plan = torch.empty(4, dtype=torch.int32, device=dev)
+            L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
+            L.call("tn_batch_plan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan))
+            k, n, R, tripped = plan.tolist()           # the step's single host read-back
+            if tripped or n_b >= 4096:
+                break
+            self._k_guess = n_b * 2                      # not enough rays drawn: redraw a larger block
+        self._k_guess = k
+        info = torch.empty((R, 2), dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        L.call("tn_sample_scan", dev, L.ptr(counts), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
+        packed = torch.empty((n, 7), device=dev)
+        L.call("tn_sample_pack", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(info),
+               C.c_void_p(None), L.ptr(packed), C.c_void_p(None), C.c_int64(n))
+        return packed, info, self.rgbs[idx[:R]], k
+
+    # ------------------------------------------------------------------ one optimizer step
+    def sigma_fn(self, t: torch.Tensor) -> torch.Tensor:
+        return self.renderer.sigma_decoder(self.renderer.feature_module(t))
+
+    def step(self) -> Dict[str, float]:
+        cfg = self.cfg
+        packed, info, target, k = self.build_batch()
+        self.renderer.train()
+        if self.train_step % self.occupancy_grid_updates == 0:                    # run.py:248-249
+            torch.manual_seed(cfg.seed + 7919 * (self.train_step + 1))            # same jitter on every rank
+            self.occupancy_grid.update(self.sigma_fn)
+        rendered = self.renderer(packed, info)                                    # run.py:251
+        loss = self.global_mse(rendered, target)
+        if cfg.method == "kplanes":                                               # run.py:254-256
+            reg = self.renderer.feature_module.loss_tv() * self.tv_reg_alpha      # type: ignore
+            reg = reg + self.renderer.feature_module.loss_l1() * self.l1_reg_alpha  # type: ignore
+            loss = loss + reg / self.world
+        self.optimizer.zero_grad(set_to_none=False)
+        (loss * cfg.grad_scale).backward()                                        # scaled, never unscaled (quirk)
+        if self.world > 1:
+            self.all_reduce_grads()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.train_step += 1
+        self.last = {"n_samples": float(packed.size(0)), "n_rays": float(info.size(0)), "k": float(k)}
+        self._loss = loss.detach()
+        return self.last
+
+    def global_mse(self, rendered: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """MSE over ALL ranks' rays: sum of local squared errors / (3 * global ray count).  Dynamic batches
+        give every rank a different ray count, so a per-rank mean followed by gradient averaging would not
+        equal the single-GPU loss; with this normalisation the SUM of rank gradients does."""
+        n_rays = torch.tensor([float(rendered.size(0))], device=rendered.device)
+        if self.world > 1:
+            torch.distributed.all_reduce(n_rays)
+        return ((rendered - target) ** 2).sum() / (3.0 * n_rays[0])
+
+    def loss_value(self) -> float:
+        v = self._loss.clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(v)
+        return float(v.item())
+
+    # ------------------------------------------------------------------ e: gradient exchange
+    def all_reduce_grads(self) -> None:
+        """Sum gradients over ranks with RCCL.  Large plane gradients go as individual in-place all-reduces
+        (each drives all xGMI peers); everything small is packed into one bucket."""
+        small, handles = [], []
+        for p in self.renderer.parameters():
+            if p.grad is None:
+                continue
+            if p.grad.numel() >= (1 << 18):
+                g = p.grad
+                flat = g.permute(0, 2, 3, 1) if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last) else g
+                assert flat.is_contiguous()
+                handles.append(torch.distributed.all_reduce(flat, async_op=True))
+            else:
+                small.append(p.grad)
+        if small:
+            bucket = torch.cat([g.reshape(-1) for g in small])
+            torch.distributed.all_reduce(bucket)
+            off = 0
+            for g in small:
+                g.copy_(bucket[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        for h in handles:
+            h.wait()
+
+    # ------------------------------------------------------------------ inference (run.py:15-50)
+    @torch.no_grad()
+    def render_rays(self, rays_o: torch.Tensor, rays_d: torch.Tensor, batch_size: Optional[int] = None) -> torch.Tensor:
+        self.renderer.eval()
+        bs = batch_size or self.cfg.batch_size
+        out = []
+        for k in range(0, rays_o.size(0), bs):
+            samples, info = self.ray_provider(rays_o[k:k + bs], rays_d[k:k + bs], training=False)
+            out.append(self.renderer(samples, info))
+        return torch.cat(out, 0)

@@ -200,7 +200,7 @@ typedef struct tn_kplanes_desc {
 /* x has row stride x_stride floats (7 when reading packed_samples directly, 3 for [n,3]). */
 int tn_kplanes_fwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
                    float *feat, void *stream);
-/* grad_planes[s][p] ([H,W,C], += via atomics; caller initialises) from grad_feat [n, S*C]. */
+/* grad_planes[s][p] ([H,W,C], += with fp32 atomics; caller initialises) from grad_feat [n, S*C]. */
 int tn_kplanes_bwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
                    const float *grad_feat, float *const (*grad_planes)[3], void *stream);
 

@@ -50,17 +50,35 @@ __global__ __launch_bounds__(256) void kplanes_fwd_kernel(KpArgs a, const float 
     }
 }
 
+// ---- backward: transposed, run-merged scatter ------------------------------------------------------
+// Measured on MI355X (scratch/atomic_bench.hip): a wave64 global_atomic_add_f32 whose lanes hit 64 different
+// cache lines retires ~20 G lane-atomics/s, one whose half-waves each cover the 32 consecutive dwords of ONE
+// line ~270 G/s.  The forward mapping (lane = sample) is the slow pattern, so the scatter is transposed
+// through a 5 KiB per-wave LDS tile: phase A (lane = sample, channel half) writes the 32x32 tile of
+// d(feat)/d(plane value) plus the 4 tap offsets / weights of every sample; phase B (lane = channel) walks the
+// samples in order -- consecutive samples of a ray fall into the same texel for several steps (a straight
+// line visits the cells of a plane monotonically), so the contribution is accumulated in a register while
+// the texel offset stays the same and ONE full-line atomic is issued when it changes.  Half-wave 0 handles
+// the taps (nw, ne), half-wave 1 (sw, se).
+constexpr int GS = 36;                                   // floats per tile row: conflict-free b128 writes
+constexpr int KP_WAVE_LDS = 32 * GS + 2 * 4 * 32;        // tile + offsets + weights (floats)
+
 template <int NV>
 __global__ __launch_bounds__(256) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
                                                           int64_t n, const float *__restrict__ grad_feat)
 {
+    __shared__ __attribute__((aligned(16))) float lds[4 * KP_WAVE_LDS];
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    float *tileG = lds + (threadIdx.x >> 6) * KP_WAVE_LDS;
+    int *tileO = reinterpret_cast<int *>(tileG + 32 * GS);
+    float *tileW = tileG + 32 * GS + 4 * 32;
     const int64_t n_tiles = (n + 31) >> 5;
     const int C = a.C, FD = a.n_scales * C;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t row = tile * 32 + j;
-        if (row >= n) continue;
-        const float xs[3] = {x[row * x_stride], x[row * x_stride + 1], x[row * x_stride + 2]};
+        const bool valid = row < n;
+        const int64_t rr = valid ? row : 0;
+        const float xs[3] = {x[rr * x_stride], x[rr * x_stride + 1], x[rr * x_stride + 2]};
         for (int s = 0; s < a.n_scales; ++s) {
             tn::PlaneTaps t[3];
             f32x4k val[3][NV];
@@ -75,25 +93,54 @@ __global__ __launch_bounds__(256) void kplanes_bwd_kernel(KpArgs a, const float 
                     for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
                 }
             }
-            const f32x4k *g = reinterpret_cast<const f32x4k *>(grad_feat + row * FD + s * C + h * (C / 2));
+            f32x4k g[NV];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const f32x4k gq = g[q];
-                // d(p0 p1 p2)/dp_i
-                const f32x4k gp[3] = {gq * val[1][q] * val[2][q], gq * val[0][q] * val[2][q], gq * (val[0][q] * val[1][q])};
+            for (int q = 0; q < NV; ++q)
+                g[q] = valid ? reinterpret_cast<const f32x4k *>(grad_feat + row * FD + s * C + h * (C / 2))[q]
+                             : f32x4k{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    if (a.grads[s][p] == nullptr) continue;
+            for (int p = 0; p < 3; ++p) {
+                if (a.grads[s][p] == nullptr) continue;
+                // ---- phase A: lane = (sample j, channel half h) ----
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (t[p].off[k] >= 0) {
-                            float *dst = a.grads[s][p] + t[p].off[k] + h * (C / 2) + 4 * q;
-                            const f32x4k c = gp[p] * t[p].w[k];
-                            atomicAdd(dst + 0, c[0]); atomicAdd(dst + 1, c[1]);
-                            atomicAdd(dst + 2, c[2]); atomicAdd(dst + 3, c[3]);
+                for (int q = 0; q < NV; ++q) {
+                    const f32x4k gp = p == 0 ? g[q] * val[1][q] * val[2][q]
+                                             : (p == 1 ? g[q] * val[0][q] * val[2][q] : g[q] * (val[0][q] * val[1][q]));
+                    *reinterpret_cast<f32x4k *>(tileG + j * GS + h * (C / 2) + 4 * q) = gp;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {          // this lane publishes taps 2h, 2h+1 of its sample
+                    const int o0 = t[p].off[0 + k], o1 = t[p].off[2 + k];
+                    const float w0 = t[p].w[0 + k], w1 = t[p].w[2 + k];
+                    tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
+                    tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
+                }
+                asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
+                // ---- phase B: lane = (tap pair hw, channel c) ----
+                const int c = j;                       // channel
+                float *gbase = a.grads[s][p] + c;
+                if (c < C) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int *O = tileO + (2 * h + k) * 32;
+                        const float *Wt = tileW + (2 * h + k) * 32;
+                        float acc = 0.0f;
+                        int cur = -1;
+#pragma unroll 4
+                        for (int sI = 0; sI < 32; ++sI) {
+                            const int o = O[sI];
+                            const float contrib = tileG[sI * GS + c] * Wt[sI];
+                            if (o != cur) {
+                                if (cur >= 0) atomicAdd(gbase + cur, acc);
+                                acc = 0.0f;
+                                cur = o;
+                            }
+                            acc += contrib;
                         }
+                        if (cur >= 0) atomicAdd(gbase + cur, acc);
                     }
                 }
+                asm volatile("" ::: "memory");
             }
         }
     }

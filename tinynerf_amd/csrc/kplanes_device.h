@@ -18,6 +18,7 @@ typedef float f32x4k __attribute__((ext_vector_type(4)));
 struct PlaneTaps {
     int off[4];      // element offset of texel (y,x) * C for nw, ne, sw, se; -1 when out of bounds
     float w[4];      // bilinear weights
+    int cell;        // id of the (x0,y0) cell the point falls in (also defined out of bounds)
 };
 
 // ATen grid_sampler_2d conventions: align_corners=True, zeros padding; u indexes W, v indexes H.
@@ -37,6 +38,8 @@ __device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, 
     t.off[1] = (bx1 && by0) ? (y0 * W + x1) * C : -1;
     t.off[2] = (bx0 && by1) ? (y1 * W + x0) * C : -1;
     t.off[3] = (bx1 && by1) ? (y1 * W + x1) * C : -1;
+    const float cx = fminf(fmaxf(x0f, -2.0f), (float)W + 1.0f), cy = fminf(fmaxf(y0f, -2.0f), (float)H + 1.0f);
+    t.cell = ((int)cy + 2) * (W + 4) + (int)cx + 2;
     return t;
 }
 

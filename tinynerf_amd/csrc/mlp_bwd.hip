@@ -103,7 +103,7 @@ __device__ __forceinline__ void hidden_fwd(const float *__restrict__ W, const fl
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int ob = 0; ob < T; ++ob) y[ob] = tn::mfma32(w[ob][u], x[kb][4 * q + u], y[ob]);
-            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // bound how far weight loads are hoisted
+
         }
     }
 #pragma unroll
@@ -156,7 +156,7 @@ __device__ __forceinline__ void wgrad_tile(const BwdArgs &a, const float *scrA, 
         const bool ok = kok && nn < Nl;
         atomicAdd(&dW[ok ? nn * Kl + kc : 0], ok ? acc[r] : 0.0f);
     }
-    __builtin_amdgcn_sched_barrier(0);
+
 }
 
 // NH = number of hidden activations kept (= n_layers - 1)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(BwdArgs a, const floa
             hidden_fwd<H>(a.W[l], a.B[l], act[l - 1], act[l], j, h);
         });
 
-        __builtin_amdgcn_sched_barrier(0);
+
         // ================= output gradient  G = gy * act'(pre) in D layout =================
         f32x16 G[T];
 #pragma unroll
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(BwdArgs a, const floa
             }
         }
 
-        __builtin_amdgcn_sched_barrier(0);
+
         // ================= layers, last to first =================
         static_for<L>([&](auto lc) {
             constexpr int l = L - 1 - decltype(lc)::value;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(BwdArgs a, const floa
                     }
                 }
             });
-            __builtin_amdgcn_sched_barrier(0);
+
             // ---- data gradient: G <- relu'(a_l) * (W_l^T G), or grad_x for l == 0 ----
             const int ng = (Nl + 7) >> 3;                     // groups of 8 out-features actually present
             if constexpr (l > 0) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(BwdArgs a, const floa
                             for (int u = 0; u < 4; ++u)
 #pragma unroll
                                 for (int kt = 0; kt < T; ++kt) Gn[kt] = tn::mfma32(w[kt][u], G[tn][4 * q + u], Gn[kt]);
-                            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+
                         }
                     }
                 }

@@ -204,6 +204,17 @@ int tn_kplanes_fwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride
 int tn_kplanes_bwd(const tn_kplanes_desc *desc, const float *x, int64_t x_stride, int64_t n,
                    const float *grad_feat, float *const (*grad_planes)[3], void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a19  K-Planes regularisers                         (reference models.py:115-121,165-181)
+ * One pass per plane ([H,W,C] channel-last) instead of the 4 strided torch passes per plane of
+ * the reference.  fwd: sums[0] += sum (p[y+1]-p[y])^2, sums[1] += sum (p[x+1]-p[x])^2,
+ * sums[2] += sum |p|  (fp64 device accumulators, caller zeroes them).
+ * bwd: grad += upstream[0] * ( cy * d/dp sum_dy + cx * d/dp sum_dx + cl1 * sign(p) ), where
+ * upstream is a device scalar (dLoss/dRegulariser) and cy, cx, cl1 fold the means and weights. */
+int tn_plane_reg_fwd(const float *plane, int H, int W, int C, double *sums, void *stream);
+int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float cy, float cx, float cl1,
+                     const float *upstream, float *grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

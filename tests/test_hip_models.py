@@ -237,3 +237,25 @@ def test_mlp_backward_ragged_sizes_vs_torch():
     for n_, p in net.named_parameters():
         ref = p.grad.cpu().numpy()
         np.testing.assert_allclose(got[n_].cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=n_)
+
+
+def test_plane_regularisers_fwd_bwd_vs_torch():
+    """a19: fused TV / L1 passes against torch autograd of the reference formulas (models.py:115-121)."""
+    m = models()
+    torch.manual_seed(5)
+    field = m.KPlanesFeatureField(32)
+    field.planes = torch.nn.ModuleList([torch.nn.ModuleList([m.KPlanesFeaturePlane(32, r) for _ in range(3)])
+                                        for r in ((8, 8), (12, 10), (33, 17))]).to(DEV)
+    field.to(DEV)
+    loss = field.loss_tv() * 0.7 + field.loss_l1() * 0.3
+    loss.backward()
+    got = [p.plane.grad.clone() for s in field.planes for p in s]
+    ref_params = [p.plane.detach().clone().requires_grad_(True) for s in field.planes for p in s]
+    tv = sum(torch.nn.functional.mse_loss(p[:, :, 1:, :], p[:, :, :-1, :]) + torch.nn.functional.mse_loss(p[:, :, :, 1:], p[:, :, :, :-1]) for p in ref_params) / 9
+    l1 = sum(p.abs().mean() for p in ref_params) / 9
+    ref = tv * 0.7 + l1 * 0.3
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-6)
+    for g, p in zip(got, ref_params):
+        np.testing.assert_allclose(g.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(field.regulariser(1e-4, 0.0).item(), 1e-4 * tv.item(), rtol=1e-6)

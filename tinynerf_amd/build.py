@@ -30,7 +30,7 @@ SOURCES = {
     "common.hip": FAST,
     "weights.hip": FAST,
     "sampler.hip": STRICT,
-    "encoding.hip": FAST,
+    "planes_reg.hip": FAST,
     "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp.hip": FAST,
     "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],

@@ -1,0 +1,84 @@
+// K-Planes total-variation / L1 regularisers (reference src/models.py:115-121,165-181) for
+// channel-last planes [H][W][C].  The reference evaluates, per plane, two mse_loss calls on shifted
+// strided views (plus their autograd backward): ~0.5 GB of traffic per step over the 126 MiB of
+// planes.  Here the forward is one streaming read per plane with an fp64 block
+// reduction, and the backward one pass that adds the 5-point stencil of the gradient straight into
+// the plane's gradient buffer.  HBM-bound: fwd 4 B/element, bwd 12 B/element.
+#include "tn_common.h"
+#include <algorithm>
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void plane_reg_fwd_kernel(const float *__restrict__ p, int H, int W, int C4,
+                                                            double *__restrict__ sums)
+{
+    const int64_t total = (int64_t)H * W * C4;
+    double sy = 0.0, sx = 0.0, sl = 0.0;
+    const f4 *q = reinterpret_cast<const f4 *>(p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t texel = i / C4;
+        const int x = (int)(texel % W), y = (int)(texel / W);
+        const f4 v = q[i];
+        sl += (double)(fabsf(v[0]) + fabsf(v[1]) + fabsf(v[2]) + fabsf(v[3]));
+        if (y + 1 < H) { const f4 d = q[i + (int64_t)W * C4] - v; sy += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]); }
+        if (x + 1 < W) { const f4 d = q[i + C4] - v; sx += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sy += __shfl_xor(sy, o, 64); sx += __shfl_xor(sx, o, 64); sl += __shfl_xor(sl, o, 64); }
+    __shared__ double red[3][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sy; red[1][threadIdx.x >> 6] = sx; red[2][threadIdx.x >> 6] = sl; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void plane_reg_bwd_kernel(const float *__restrict__ p, int H, int W, int C4, float cy, float cx,
+                                                            float cl1, const float *__restrict__ upstream, float *__restrict__ grad)
+{
+    const int64_t total = (int64_t)H * W * C4;
+    const float up = upstream[0];
+    const f4 *q = reinterpret_cast<const f4 *>(p);
+    f4 *g = reinterpret_cast<f4 *>(grad);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t texel = i / C4;
+        const int x = (int)(texel % W), y = (int)(texel / W);
+        const f4 v = q[i];
+        f4 dy = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+        if (y > 0) dy += v - q[i - (int64_t)W * C4];
+        if (y + 1 < H) dy -= q[i + (int64_t)W * C4] - v;
+        if (x > 0) dx += v - q[i - C4];
+        if (x + 1 < W) dx -= q[i + C4] - v;
+        f4 r = (dy * (2.0f * cy) + dx * (2.0f * cx));
+        if (cl1 != 0.0f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] += cl1 * (v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f));
+        }
+        g[i] += r * up;
+    }
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+extern "C" int tn_plane_reg_fwd(const float *plane, int H, int W, int C, double *sums, void *stream)
+{
+    TN_REQUIRE(H > 0 && W > 0 && C > 0 && (C & 3) == 0, TN_E_SIZE, "tn_plane_reg_fwd: bad shape (C must be a multiple of 4)");
+    TN_REQUIRE(plane && sums, TN_E_NULL, "tn_plane_reg_fwd: null pointer");
+    TN_REQUIRE(((uintptr_t)plane & 15) == 0, TN_E_ALIGN, "tn_plane_reg_fwd: plane must be 16-byte aligned");
+    const int64_t n = (int64_t)H * W * (C / 4);
+    plane_reg_fwd_kernel<<<dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream>>>(plane, H, W, C / 4, sums);
+    return tn::check_launch("plane_reg_fwd_kernel");
+}
+
+extern "C" int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float cy, float cx, float cl1, const float *upstream,
+                                float *grad, void *stream)
+{
+    TN_REQUIRE(H > 0 && W > 0 && C > 0 && (C & 3) == 0, TN_E_SIZE, "tn_plane_reg_bwd: bad shape (C must be a multiple of 4)");
+    TN_REQUIRE(plane && upstream && grad, TN_E_NULL, "tn_plane_reg_bwd: null pointer");
+    TN_REQUIRE((((uintptr_t)plane | (uintptr_t)grad) & 15) == 0, TN_E_ALIGN, "tn_plane_reg_bwd: buffers must be 16-byte aligned");
+    const int64_t n = (int64_t)H * W * (C / 4);
+    plane_reg_bwd_kernel<<<dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream>>>(plane, H, W, C / 4, cy, cx, cl1, upstream, grad);
+    return tn::check_launch("plane_reg_bwd_kernel");
+}

@@ -274,6 +274,45 @@ class _KPlanesFeatures(Function):
         return (None, *grads)
 
 
+class _PlaneRegulariser(Function):
+    """w_tv * mean_planes(loss_tv) + w_l1 * mean_planes(loss_l1) over channel-last planes in two streaming
+    kernels per plane (models.py:115-121,165-181); the gradient is added by a 5-point-stencil pass."""
+
+    @staticmethod
+    def forward(ctx: Any, w_tv: float, w_l1: float, *planes: torch.Tensor) -> torch.Tensor:  # type: ignore
+        dev = planes[0].device
+        if not planes[0].is_cuda:
+            raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
+        n = len(planes)
+        sums = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        coef = torch.empty((n, 3), dtype=torch.float64)
+        for i, p in enumerate(planes):
+            _, Cc, H, W = p.shape
+            L.call("tn_plane_reg_fwd", dev, L.ptr(_hwc(p)), C.c_int(H), C.c_int(W), C.c_int(Cc),
+                   C.c_void_p(sums.data_ptr() + i * 24))
+            coef[i, 0] = w_tv / (n * Cc * max(H - 1, 1) * W)       # mse over [C,H-1,W]
+            coef[i, 1] = w_tv / (n * Cc * H * max(W - 1, 1))       # mse over [C,H,W-1]
+            coef[i, 2] = w_l1 / (n * Cc * H * W)
+        ctx.coef = coef
+        ctx.save_for_backward(*planes)
+        return (sums * coef.to(dev)).sum().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
+        planes = ctx.saved_tensors
+        dev = planes[0].device
+        up = grad_out.reshape(1).to(torch.float32).contiguous()
+        grads = []
+        for i, p in enumerate(planes):
+            _, Cc, H, W = p.shape
+            g = torch.zeros_like(p, memory_format=torch.channels_last)
+            cy, cx, cl1 = (float(v) for v in ctx.coef[i])
+            L.call("tn_plane_reg_bwd", dev, L.ptr(_hwc(p)), C.c_int(H), C.c_int(W), C.c_int(Cc), C.c_float(cy), C.c_float(cx),
+                   C.c_float(cl1), L.ptr(up), L.ptr(_hwc(g)))
+            grads.append(g)
+        return (None, None, *grads)
+
+
 class KPlanesFeaturePlane(torch.nn.Module):
     def __init__(
         self,
@@ -295,12 +334,10 @@ class KPlanesFeaturePlane(torch.nn.Module):
         return out.view([*x.size()[:-1], self.feature_dim])
 
     def loss_tv(self) -> torch.Tensor:
-        tv_x = torch.nn.functional.mse_loss(self.plane[:, :, 1:, :], self.plane[:, :, :-1, :])
-        tv_y = torch.nn.functional.mse_loss(self.plane[:, :, :, 1:], self.plane[:, :, :, :-1])
-        return tv_x + tv_y
+        return _PlaneRegulariser.apply(1.0, 0.0, self.plane)
 
     def loss_l1(self) -> torch.Tensor:
-        return torch.mean(torch.abs(self.plane))
+        return _PlaneRegulariser.apply(0.0, 1.0, self.plane)
 
 
 class KPlanesFeatureField(torch.nn.Module):
@@ -326,12 +363,14 @@ class KPlanesFeatureField(torch.nn.Module):
         return self.dropout(_KPlanesFeatures.apply(x, *self.plane_tensors()))
 
     def loss_tv(self) -> torch.Tensor:
-        vals = [cast(KPlanesFeaturePlane, p).loss_tv() for scale in self.planes for p in cast(torch.nn.ModuleList, scale)]
-        return cast(torch.Tensor, sum(vals)) / len(vals)
+        return _PlaneRegulariser.apply(1.0, 0.0, *self.plane_tensors())
 
     def loss_l1(self) -> torch.Tensor:
-        vals = [cast(KPlanesFeaturePlane, p).loss_l1() for scale in self.planes for p in cast(torch.nn.ModuleList, scale)]
-        return cast(torch.Tensor, sum(vals)) / len(vals)
+        return _PlaneRegulariser.apply(0.0, 1.0, *self.plane_tensors())
+
+    def regulariser(self, w_tv: float, w_l1: float) -> torch.Tensor:
+        """w_tv * loss_tv() + w_l1 * loss_l1() in one pass over the planes (run.py:254-256)."""
+        return _PlaneRegulariser.apply(float(w_tv), float(w_l1), *self.plane_tensors())
 
 
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):

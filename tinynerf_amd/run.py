@@ -152,8 +152,7 @@ class Trainer:
         rendered = self.renderer(packed, info)                                    # run.py:251
         loss = self.global_mse(rendered, target)
         if cfg.method == "kplanes":                                               # run.py:254-256
-            reg = self.renderer.feature_module.loss_tv() * self.tv_reg_alpha      # type: ignore
-            reg = reg + self.renderer.feature_module.loss_l1() * self.l1_reg_alpha  # type: ignore
+            reg = self.renderer.feature_module.regulariser(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
             loss = loss + reg / self.world
         self.optimizer.zero_grad(set_to_none=False)
         (loss * cfg.grad_scale).backward()                                        # scaled, never unscaled (quirk)

@@ -176,10 +176,15 @@ int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_
 /* Backward of tn_mlp_fwd: recomputes the hidden activations, accumulates (+=) weight/bias
  * gradients into grad_weights[l]/grad_biases[l] (same shapes; must be initialised by the caller)
  * and writes grad_x [n,in_dim] when non-NULL (TN_ENC_POSENC: no grad_x, coords carry no grad;
- * TN_ENC_DIR_CAT: gradient w.r.t. the feature part x only). */
+ * TN_ENC_DIR_CAT: gradient w.r.t. the feature part x only).
+ * workspace (optional, tn_mlp_bwd_workspace_bytes(desc, n) bytes, uninitialised) selects the two-pass
+ * form (data-gradient chain with LDS-resident weights, then a sample-reducing weight-gradient kernel);
+ * without it, or for configurations the two-pass form does not cover (it returns 0 bytes), the
+ * single-kernel form runs. */
+int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y,
                int64_t n, float *const *grad_weights, float *const *grad_biases, float *grad_x,
-               void *stream);
+               void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a15/a16  K-Planes feature field                              (reference models.py:93-163)

@@ -34,6 +34,7 @@ SOURCES = {
     "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp.hip": FAST,
     "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
     "render.hip": FAST + ["-munsafe-fp-atomics"],
 }
 

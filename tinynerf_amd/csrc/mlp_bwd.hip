@@ -483,8 +483,10 @@ int launch_h(const BwdArgs &a, const float *x, const float *aux, const float *gy
 
 }  // namespace
 
-extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
-                          float *const *grad_weights, float *const *grad_biases, float *grad_x, void *stream)
+// single-kernel form; the public entry point tn_mlp_bwd (mlp_bwd2.hip) dispatches here when no workspace is given
+extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_fused1(const tn_mlp_desc *desc, const float *x, const float *aux,
+                                                                      const float *grad_y, int64_t n, float *const *grad_weights,
+                                                                      float *const *grad_biases, float *grad_x, void *stream)
 {
     BwdArgs a;
     int H = 0;

@@ -1,0 +1,467 @@
+// Backward of the fused MLP heads, two-pass form (the fast path of tn_mlp_bwd).
+//
+// The single-kernel backward (mlp_bwd.hip) keeps every hidden activation AND the gradient image on chip,
+// which leaves one wave per SIMD and weights in L2: ~8 % of the fp32 MFMA peak.  Splitting along the
+// one place where the data layout has to change anyway -- the weight gradient reduces over SAMPLES,
+// everything else over FEATURES -- gives two clean kernels:
+//
+//   chain kernel  (samples on lanes, weights resident in LDS, 2+ waves per SIMD)
+//       recompute forward -> output gradient -> data-gradient chain -> grad_x.  Hidden activations are
+//       streamed to a workspace as they are produced (only their ReLU bit masks stay in registers), and so
+//       is every layer's pre-activation gradient.  Workspace rows are [feature][32 samples] (128 B): the
+//       transposition the weight gradient needs is done by the store / load address pattern, for free.
+//   wgrad kernel  (features on lanes)
+//       dW_l += G_l * H_l^T as 32x32 MFMA tiles whose reduction index is the sample; each wave owns a few
+//       (layer, row-tile, column-tile) accumulators for its workgroup's share of the samples and flushes
+//       them once with full-line atomics.  The first layer's input operand is rebuilt from x / aux (PE
+//       recomputed), so the encoded input is never stored.
+//
+// Workspace: (2*NH*H + 4) rows of 128 B per 32 samples (2.06 KB/sample for the K-Planes colour head).
+#include "mlp_stage.h"
+#include <algorithm>
+#include <type_traits>
+
+extern "C" int tn_mlp_bwd_fused1(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
+                                 float *const *grad_weights, float *const *grad_biases, float *grad_x, void *stream);
+
+namespace {
+
+using tn::f32x16;
+using tn::f32x4;
+using namespace tn::mlp;
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ float act_grad(float pre, int act) {
+    if (act == TN_ACT_EXP_M1) return expf(fminf(fmaxf(pre - 1.0f, -15.0f), 15.0f));     // models.py:50-53
+    if (act == TN_ACT_SIGMOID) { const float s = 1.0f / (1.0f + expf(-pre)); return s * (1.0f - s); }
+    return 1.0f;
+}
+
+// D-layout tile -> workspace rows [feature][32 samples]; two fully used 128-B lines per store instruction
+__device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[(32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = t[r];
+}
+
+__device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (t[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+
+template <int H> constexpr int stash_rows(int nh) { return 2 * nh * H + 4; }
+
+// ------------------------------------------------------------------------------------------------
+// chain kernel
+// ------------------------------------------------------------------------------------------------
+template <int H, int NH, int WPB>
+__global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+                                                             const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
+                                                             float *__restrict__ stash)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = H / 32;
+    constexpr int L = NH + 1;
+    stage_weights(a, lds);
+    __syncthreads();
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int G0 = a.K0_pad >> 3;
+    const int out = a.out_dim;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));           // keep per-lane LDS addresses out of LICM's reach
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        float aux3[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
+            else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
+        }
+        float *st = stash + tile * (int64_t)(stash_rows<H>(NH) * 32);
+        float *stH = st;                                // H_1 .. H_NH
+        float *stG = st + NH * H * 32;                  // G_0 .. G_{NH-1}
+        float *stP = st + 2 * NH * H * 32;              // g_pre (4 rows)
+
+        // ---------------- forward ----------------
+        f32x16 act[T];
+        unsigned mask[NH][T];
+        {
+            const float *W0 = lds + a.w_off[0];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(lds + a.b_off[0], ob, h);
+            f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h);
+            for (int g = 0; g < G0; ++g) {
+                f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+                if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h);
+                f32x4 w[T];
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
+                b = bn;
+            }
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) {
+                tn::pin16(act[ob]);
+                act[ob] = tn::relu16(act[ob]);
+                mask[0][ob] = relu_bits(act[ob]);
+                store_rows(stH, act[ob], ob, j, h);
+            }
+        }
+        static_for<NH - 1>([&](auto lc) {
+            constexpr int l = decltype(lc)::value + 1;          // layer l: H_l -> H_{l+1}
+            tn::hidden_layer<H>(lds + a.w_off[l], lds + a.b_off[l], a.stride[l], act, j, h);
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) {
+                mask[l][ob] = relu_bits(act[ob]);
+                store_rows(stH + l * H * 32, act[ob], ob, j, h);
+            }
+        });
+
+        // ---------------- output gradient (out <= 4) and first data-gradient step on the VALU ----------------
+        const float *Wf = lds + a.w_off[L - 1];
+        const float *Bf = lds + a.b_off[L - 1];
+        const int sf = a.stride[L - 1];
+        float gp[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            gp[o] = 0.0f;
+            if (o < out) {
+                const float pre = tn::small_out<H>(Wf + o * sf, Bf[o], act, h);
+                gp[o] = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
+            }
+            if (h == 0) stP[o * 32 + j] = gp[o];
+        }
+        f32x16 G[T];
+#pragma unroll
+        for (int kb = 0; kb < T; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (o < out) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(Wf + o * sf + 32 * kb + 8 * q + 4 * h);
+                        acc4 += w * gp[o];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = (mask[NH - 1][kb] >> (4 * q + u)) & 1u ? acc4[u] : 0.0f;
+            }
+        }
+
+        // ---------------- hidden layers, last to first ----------------
+        static_for<NH - 1>([&](auto lc) {
+            constexpr int l = NH - 1 - decltype(lc)::value;     // l = NH-1 .. 1 : G holds G_l
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
+            const float *Wl = lds + a.w_off[l];
+            const int sl = a.stride[l];
+            f32x16 Gn[T];
+#pragma unroll
+            for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Gn[kt][r] = 0.0f;
+#pragma unroll
+            for (int tn_ = 0; tn_ < T; ++tn_) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w[T][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int kt = 0; kt < T; ++kt) w[kt][u] = Wl[(32 * tn_ + 8 * q + 4 * h + u) * sl + 32 * kt + j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int kt = 0; kt < T; ++kt) Gn[kt] = tn::mfma32(w[kt][u], G[tn_][4 * q + u], Gn[kt]);
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < T; ++kt) {
+                tn::pin16(Gn[kt]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[kt][r] = (mask[l - 1][kt] >> r) & 1u ? Gn[kt][r] : 0.0f;
+            }
+        });
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
+
+        // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
+        if (gx != nullptr && a.enc != TN_ENC_POSENC) {
+            const float *W0 = lds + a.w_off[0];
+            const int s0 = a.stride[0];
+            const int n_kt = (a.in_dim + 31) >> 5;
+#pragma clang loop unroll(disable)
+            for (int kt = 0; kt < n_kt; ++kt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int tn_ = 0; tn_ < T; ++tn_)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = tn::mfma32(W0[(32 * tn_ + 8 * q + 4 * h + u) * s0 + 32 * kt + j], G[tn_][4 * q + u], acc);
+                tn::pin16(acc);
+                if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 32 * kt + 8 * q + 4 * h;
+                        if (f0 + 3 < a.in_dim && (a.in_dim & 3) == 0) {
+                            f32x4 v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = acc[4 * q + u];
+                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + f0) = v;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (f0 + u < a.in_dim) gx[row * a.in_dim + f0 + u] = acc[4 * q + u];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad kernel
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    int n_layers, in_dim, K0, enc, n_freqs, out_dim, Tk0, total_tiles;
+    const float *freqs;
+    float *gW[TN_MLP_MAX_LAYERS];
+    float *gB[TN_MLP_MAX_LAYERS];
+    int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];
+};
+
+__device__ __forceinline__ int wg_col0(const WgradArgs &a, int q) {
+    if (a.enc == TN_ENC_DIR_CAT) {
+        const int pe = 6 * a.n_freqs + 3;
+        return q < a.in_dim ? pe + q : q - a.in_dim;
+    }
+    return q;
+}
+
+// value of first-layer input slot q for sample `row` (slot order of fetch_input)
+__device__ __forceinline__ float input_slot(const WgradArgs &a, const float *__restrict__ x, const float *__restrict__ aux,
+                                            int64_t row, int q)
+{
+    if (a.enc == TN_ENC_POSENC) {
+        if (q >= a.K0) return 0.0f;
+        const float xc[3] = {x[row * 3], x[row * 3 + 1], x[row * 3 + 2]};
+        return tn::posenc_value(xc, q, a.n_freqs, a.freqs);
+    }
+    if (q < a.in_dim) return x[row * a.in_dim + q];
+    if (a.enc == TN_ENC_DIR_CAT) {
+        const int p = q - a.in_dim;
+        if (p < 6 * a.n_freqs + 3) {
+            const float d[3] = {aux[3 * row], aux[3 * row + 1], aux[3 * row + 2]};
+            return p < 6 * a.n_freqs ? tn::posenc_value(d, p, a.n_freqs, a.freqs) : d[p - 6 * a.n_freqs];
+        }
+    }
+    return 0.0f;
+}
+
+// Tile id -> (layer, tn, tk).  Order: layer 0 tiles (tn-major), hidden layers, last layer.
+template <int H, int NH>
+__device__ __forceinline__ void decode_tile(const WgradArgs &a, int id, int &l, int &tn_, int &tk) {
+    constexpr int T = H / 32;
+    const int n0 = T * a.Tk0;
+    if (id < n0) { l = 0; tn_ = id / a.Tk0; tk = id - tn_ * a.Tk0; return; }
+    id -= n0;
+    if (id < (NH - 1) * T * T) { l = 1 + id / (T * T); id -= (l - 1) * T * T; tn_ = id / T; tk = id - tn_ * T; return; }
+    id -= (NH - 1) * T * T;
+    l = NH; tn_ = 0; tk = id;
+}
+
+template <int H, int NH, int MAXS>
+__global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+                                                        int64_t n, const float *__restrict__ stash)
+{
+    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    f32x16 acc[MAXS];
+    float dbacc[MAXS];
+    int tl[MAXS], ttn[MAXS], ttk[MAXS];
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+        dbacc[m] = 0.0f;
+        tl[m] = -1; ttn[m] = 0; ttk[m] = 0;
+        const int id = wave + 8 * m;
+        if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *st = stash + tile * (int64_t)(stash_rows<H>(NH) * 32);
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) {
+            const int l = tl[m];
+            if (l < 0) continue;
+            // ---- G operand: 16 samples of row (32 tn + i) ----
+            f32x4 gv[4];
+            if (l < NH) {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + ((NH + l) * H + 32 * ttn[m] + i) * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[e] = p[e];
+            } else {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + (2 * NH * H + (i < 4 ? i : 0)) * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[e] = i < 4 ? p[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // ---- A operand ----
+            f32x4 av[4];
+            if (l == 0) {
+                const int q = 32 * ttk[m] + i;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t row = tile * 32 + 16 * h + 4 * e + u;
+                        av[e][u] = row < n ? input_slot(a, x, aux, row, q) : 0.0f;
+                    }
+            } else {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + ((l - 1) * H + 32 * ttk[m] + i) * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = p[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[e][u], av[e][u], acc[m]);
+            if (ttk[m] == 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += (gv[e][0] + gv[e][1]) + (gv[e][2] + gv[e][3]);
+                dbacc[m] += s;
+            }
+        }
+    }
+    // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+        const int l = tl[m];
+        if (l < 0) continue;
+        tn::pin16(acc[m]);
+        const int Nl = a.N[l], Kl = a.K[l];
+        const int k = 32 * ttk[m] + i;
+        const bool kok = k < Kl;
+        const int kc = kok ? (l == 0 ? wg_col0(a, k) : k) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = 32 * ttn[m] + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (kok && nn < Nl) atomicAdd(&a.gW[l][(int64_t)nn * Kl + kc], acc[m][r]);
+        }
+        if (ttk[m] == 0) {
+            float s = dbacc[m];
+            s += __shfl_xor(s, 32, 64);
+            const int nn = 32 * ttn[m] + i;
+            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool v2_supported(const tn_mlp_desc *d) {
+    if (!d) return false;
+    const int L = d->n_layers, H = d->dims[1];
+    if (L < 2 || L > 5) return false;
+    if (H != 32 && H != 64) return false;
+    for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
+    if (d->dims[L] > 4) return false;
+    const int T = H / 32, Tk0 = (((d->dims[0] + 7) & ~7) + 31) / 32;
+    if (T * Tk0 + (L - 2) * T * T + T > 40) return false;        // MAXS <= 5
+    return true;
+}
+
+template <int H, int NH>
+int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
+              float *const *gw, float *const *gb, float *gx, float *stash, hipStream_t s)
+{
+    const int64_t n_tiles = (n + 31) / 32;
+    const size_t lds_bytes = (size_t)a.lds_floats * 4;
+    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
+    constexpr int WPB = 8;
+    auto kern = mlp_chain_kernel<H, NH, WPB>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
+    const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
+    kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash);
+    if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
+
+    WgradArgs w;
+    constexpr int T = H / 32;
+    w.n_layers = a.n_layers; w.in_dim = a.in_dim; w.K0 = a.K0; w.enc = a.enc; w.n_freqs = a.n_freqs; w.out_dim = a.out_dim;
+    w.freqs = a.freqs;
+    w.Tk0 = (a.K0_pad + 31) / 32;
+    w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
+    for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
+    const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
+    const int slots = (w.total_tiles + 7) / 8;
+    if (slots <= 1) mlp_wgrad_kernel<H, NH, 1><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
+    else if (slots <= 3) mlp_wgrad_kernel<H, NH, 3><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
+    else mlp_wgrad_kernel<H, NH, 5><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
+    return tn::check_launch("mlp_wgrad_kernel");
+}
+
+template <int H>
+int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
+                float *const *gw, float *const *gb, float *gx, float *stash, hipStream_t s)
+{
+    switch (a.n_layers - 1) {
+    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
+    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
+    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
+    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n)
+{
+    if (!v2_supported(desc) || n <= 0) return 0;
+    const int H = desc->dims[1], NH = desc->n_layers - 1;
+    return ((n + 31) / 32) * (int64_t)(2 * NH * H + 4) * 32 * (int64_t)sizeof(float);
+}
+
+extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
+                          float *const *grad_weights, float *const *grad_biases, float *grad_x, void *workspace,
+                          int64_t workspace_bytes, void *stream)
+{
+    const int64_t need = tn_mlp_bwd_workspace_bytes(desc, n);
+    if (need == 0 || workspace == nullptr || workspace_bytes < need)
+        return tn_mlp_bwd_fused1(desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, stream);
+    MlpArgs a;
+    int H = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    TN_REQUIRE(x && grad_y && grad_weights && grad_biases, TN_E_NULL, "tn_mlp_bwd: null pointer");
+    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_bwd: dir_cat needs aux (ray directions)");
+    TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_bwd: workspace must be 16-byte aligned");
+    for (int l = 0; l < a.n_layers; ++l)
+        TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd: null gradient pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 32) return launch_v2_h<32>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, s);
+    return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, s);
+}

@@ -1,0 +1,136 @@
+// Kernel arguments, LDS weight staging and first-layer input fetch shared by the fused MLP forward
+// (mlp.hip) and backward (mlp_bwd.hip) kernels.
+#pragma once
+#include "mlp_device.h"
+
+namespace tn {
+namespace mlp {
+
+using tn::f32x16;
+using tn::f32x4;
+
+struct MlpArgs {
+    int n_layers, in_dim, K0, K0_pad, enc, n_freqs, out_act, out_dim;
+    const float *freqs;
+    const float *W[TN_MLP_MAX_LAYERS];
+    const float *B[TN_MLP_MAX_LAYERS];
+    int w_off[TN_MLP_MAX_LAYERS], b_off[TN_MLP_MAX_LAYERS], stride[TN_MLP_MAX_LAYERS];
+    int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];     // true in / out width of each layer
+    int lds_floats;
+};
+
+// column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
+__device__ __forceinline__ int layer0_col(const MlpArgs &a, int q) {
+    if (a.enc == TN_ENC_DIR_CAT) {
+        const int pe = 6 * a.n_freqs + 3;
+        return q < a.in_dim ? pe + q : q - a.in_dim;       // torch order: [PE(d), d, feat]
+    }
+    return q;
+}
+
+// copy every layer into LDS: [rows][K_pad + 4] + bias, zero padded
+__device__ inline void stage_weights(const MlpArgs &a, float *lds) {
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int stride = a.stride[l];
+        const int rows = (a.b_off[l] - a.w_off[l]) / stride;
+        const int K = a.K[l], N = a.N[l];
+        float *w = lds + a.w_off[l];
+        for (int e = threadIdx.x; e < rows * stride; e += blockDim.x) {
+            const int r = e / stride, q = e - r * stride;
+            float v = 0.0f;
+            if (r < N && q < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, q) : q)];
+            w[e] = v;
+        }
+        float *b = lds + a.b_off[l];
+        const int brow = (rows + 3) & ~3;
+        for (int e = threadIdx.x; e < brow; e += blockDim.x) b[e] = e < N ? a.B[l][e] : 0.0f;
+    }
+}
+
+// The four first-layer inputs of slots 8g+4h .. +3 for this lane's sample.
+//   TN_ENC_NONE    slot q = x[q]
+//   TN_ENC_POSENC  slot q = PE(x)[q]
+//   TN_ENC_DIR_CAT slot q = x[q] (q < in_dim), PE(d)[q-in_dim], d[..], 0 padding
+__device__ __forceinline__ f32x4 fetch_input(const MlpArgs &a, const float *__restrict__ xrow, const float *aux3,
+                                             bool valid, int g, int h)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!valid) return v;
+    const int q0 = 8 * g + 4 * h;
+    if (a.enc == TN_ENC_POSENC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q0 + u < a.K0) v[u] = tn::posenc_value(aux3, q0 + u, a.n_freqs, a.freqs);
+        return v;
+    }
+    if (q0 + 3 < a.in_dim && (a.in_dim & 3) == 0) return *reinterpret_cast<const f32x4 *>(xrow + q0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        if (q < a.in_dim) v[u] = xrow[q];
+        else if (a.enc == TN_ENC_DIR_CAT) {
+            const int p = q - a.in_dim;
+            if (p < 6 * a.n_freqs) v[u] = tn::posenc_value(aux3, p, a.n_freqs, a.freqs);
+            else if (p < 6 * a.n_freqs + 3) v[u] = aux3[p - 6 * a.n_freqs];
+        }
+    }
+    return v;
+}
+
+// A operand of 4 consecutive steps: LDS copy (padded, always in range) or guarded global read
+template <bool WLDS>
+__device__ __forceinline__ f32x4 load_a4(const float *__restrict__ W, int row, int col, int K, int stride) {
+    if constexpr (WLDS) {
+        return *reinterpret_cast<const f32x4 *>(W + row * stride + col);
+    } else {
+        if (col + 3 < K && (K & 3) == 0) return *reinterpret_cast<const f32x4 *>(W + (int64_t)row * K + col);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (col + u < K) v[u] = W[(int64_t)row * K + col + u];
+        return v;
+    }
+}
+
+constexpr int LDS_LIMIT_BYTES = 160 * 1024;
+
+inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
+{
+    TN_REQUIRE(d, TN_E_NULL, "mlp: null descriptor");
+    const int L = d->n_layers;
+    TN_REQUIRE(L >= 2 && L <= TN_MLP_MAX_LAYERS, TN_E_CONFIG, "mlp: n_layers must be in [2, 12]");
+    H = d->dims[1];
+    TN_REQUIRE(H == 32 || H == 64 || H == 128 || H == 256, TN_E_CONFIG, "mlp: hidden width must be 32, 64, 128 or 256");
+    for (int l = 1; l < L; ++l) TN_REQUIRE(d->dims[l] == H, TN_E_CONFIG, "mlp: all hidden layers must share one width");
+    for (int l = 0; l < L; ++l) TN_REQUIRE(d->weights[l] && d->biases[l], TN_E_NULL, "mlp: null weight / bias pointer");
+    a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
+    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L];
+    a.freqs = d->freqs;
+    TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
+    switch (a.enc) {
+    case TN_ENC_NONE: TN_REQUIRE(a.K0 == a.in_dim, TN_E_CONFIG, "mlp: dims[0] must equal in_dim"); break;
+    case TN_ENC_POSENC:
+        TN_REQUIRE(a.in_dim == 3 && a.K0 == 6 * a.n_freqs, TN_E_CONFIG, "mlp: posenc expects in_dim 3 and dims[0] = 6F");
+        break;
+    case TN_ENC_DIR_CAT:
+        TN_REQUIRE(a.K0 == a.in_dim + 6 * a.n_freqs + 3, TN_E_CONFIG, "mlp: dir_cat expects dims[0] = in_dim + 6F + 3");
+        break;
+    default: return tn::fail(TN_E_CONFIG, "mlp: unknown encoding");
+    }
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+        a.W[l] = d->weights[l]; a.B[l] = d->biases[l];
+        a.K[l] = d->dims[l]; a.N[l] = d->dims[l + 1];
+        const int Kp = l == 0 ? a.K0_pad : H;
+        const int rows = (l == L - 1) ? (a.out_dim <= 4 ? a.out_dim : ((a.out_dim + 31) & ~31)) : H;
+        a.stride[l] = Kp + 4;
+        a.w_off[l] = off; off += rows * a.stride[l];
+        a.b_off[l] = off; off += (rows + 3) & ~3;
+    }
+    a.lds_floats = off;
+    return TN_OK;
+}
+
+
+}  // namespace mlp
+}  // namespace tn

@@ -47,6 +47,8 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
 class _FusedMLP(Function):
     """y = act(MLP(enc(x, aux))) in one launch; backward recomputes the hidden activations."""
 
+    two_pass = True     # give tn_mlp_bwd its workspace (two-pass form); False forces the single-kernel form
+
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
                 n_freqs: int, out_act: int, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
@@ -78,7 +80,12 @@ class _FusedMLP(Function):
         gb = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[1::2]])
         want_gx = ctx.needs_input_grad[0] and encoding != L.ENC_POSENC
         gx = torch.empty_like(x2) if want_gx else None
-        L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx))
+        wsfn = L.lib().tn_mlp_bwd_workspace_bytes
+        wsfn.restype = C.c_int64
+        ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n))) if _FusedMLP.two_pass else 0
+        ws = torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None     # caching allocator: no hipMalloc per step
+        L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
+               L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
         return (gx_out, None, None, None, None, None, *grads)
 

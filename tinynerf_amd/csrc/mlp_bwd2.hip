@@ -57,7 +57,12 @@ __device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
     return m;
 }
 
-template <int H> constexpr int stash_rows(int nh) { return 2 * nh * H + 4; }
+// workspace rows per 32-sample tile: H_1..H_NH, G_0..G_{NH-1}, g_pre (4), E = encoded first-layer slots that
+// are not plain x columns (PE(d), d, padding), which the chain kernel has in hand and the wgrad kernel would
+// otherwise have to recompute (16 sincos per lane and tile)
+__host__ __device__ inline int x_slots(int enc, int in_dim) { return enc == TN_ENC_POSENC ? 0 : in_dim; }
+__host__ __device__ inline int extra_rows(int enc, int in_dim, int K0_pad) { return enc == TN_ENC_NONE ? 0 : K0_pad - x_slots(enc, in_dim); }
+template <int H> __host__ __device__ inline int stash_rows(int nh, int extra) { return 2 * nh * H + 4 + extra; }
 
 // ------------------------------------------------------------------------------------------------
 // chain kernel
@@ -89,10 +94,12 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
             else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
         }
-        float *st = stash + tile * (int64_t)(stash_rows<H>(NH) * 32);
+        const int xs = x_slots(a.enc, a.in_dim);
+        float *st = stash + tile * (int64_t)(stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad)) * 32);
         float *stH = st;                                // H_1 .. H_NH
         float *stG = st + NH * H * 32;                  // G_0 .. G_{NH-1}
         float *stP = st + 2 * NH * H * 32;              // g_pre (4 rows)
+        float *stE = stP + 4 * 32;                      // encoded extras
 
         // ---------------- forward ----------------
         f32x16 act[T];
@@ -112,6 +119,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
+                if (a.enc != TN_ENC_NONE && 8 * g + 4 * h + 3 >= xs) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = 8 * g + 4 * h + u;
+                        if (q >= xs) stE[(q - xs) * 32 + j] = b[u];
+                    }
+                }
                 b = bn;
             }
 #pragma unroll
@@ -244,8 +258,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 // wgrad kernel
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
-    int n_layers, in_dim, K0, enc, n_freqs, out_dim, Tk0, total_tiles;
-    const float *freqs;
+    int n_layers, in_dim, K0, K0_pad, enc, n_freqs, out_dim, Tk0, total_tiles;
     float *gW[TN_MLP_MAX_LAYERS];
     float *gB[TN_MLP_MAX_LAYERS];
     int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];
@@ -257,26 +270,6 @@ __device__ __forceinline__ int wg_col0(const WgradArgs &a, int q) {
         return q < a.in_dim ? pe + q : q - a.in_dim;
     }
     return q;
-}
-
-// value of first-layer input slot q for sample `row` (slot order of fetch_input)
-__device__ __forceinline__ float input_slot(const WgradArgs &a, const float *__restrict__ x, const float *__restrict__ aux,
-                                            int64_t row, int q)
-{
-    if (a.enc == TN_ENC_POSENC) {
-        if (q >= a.K0) return 0.0f;
-        const float xc[3] = {x[row * 3], x[row * 3 + 1], x[row * 3 + 2]};
-        return tn::posenc_value(xc, q, a.n_freqs, a.freqs);
-    }
-    if (q < a.in_dim) return x[row * a.in_dim + q];
-    if (a.enc == TN_ENC_DIR_CAT) {
-        const int p = q - a.in_dim;
-        if (p < 6 * a.n_freqs + 3) {
-            const float d[3] = {aux[3 * row], aux[3 * row + 1], aux[3 * row + 2]};
-            return p < 6 * a.n_freqs ? tn::posenc_value(d, p, a.n_freqs, a.freqs) : d[p - 6 * a.n_freqs];
-        }
-    }
-    return 0.0f;
 }
 
 // Tile id -> (layer, tn, tk).  Order: layer 0 tiles (tn-major), hidden layers, last layer.
@@ -311,7 +304,9 @@ __global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgradArgs a, const float
         if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
     }
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const float *st = stash + tile * (int64_t)(stash_rows<H>(NH) * 32);
+        const int xs = x_slots(a.enc, a.in_dim);
+        const float *st = stash + tile * (int64_t)(stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad)) * 32);
+        const float *stE = st + (2 * NH * H + 4) * 32;
 #pragma unroll
         for (int m = 0; m < MAXS; ++m) {
             const int l = tl[m];
@@ -330,14 +325,32 @@ __global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgradArgs a, const float
             // ---- A operand ----
             f32x4 av[4];
             if (l == 0) {
-                const int q = 32 * ttk[m] + i;
+                // first-layer input, slot q = 32 tk + i: plain x columns are read straight from x (all 16 loads
+                // unconditional on clamped rows so they are issued back to back), encoded slots from the E rows
+                const int q0 = 32 * ttk[m], q = q0 + i;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) av[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q0 < xs) {                                     // wave-uniform: this tile holds x columns
+                    const int qx = q < xs ? q : 0;
+                    const int64_t r0 = tile * 32 + 16 * h;
+                    float xv[16];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int64_t row = tile * 32 + 16 * h + 4 * e + u;
-                        av[e][u] = row < n ? input_slot(a, x, aux, row, q) : 0.0f;
+                    for (int t = 0; t < 16; ++t) {
+                        const int64_t rc = r0 + t < n ? r0 + t : n - 1;
+                        xv[t] = x[rc * a.in_dim + qx];
                     }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = (q < xs && r0 + t < n) ? xv[t] : 0.0f;
+                }
+                if (a.enc != TN_ENC_NONE && q0 + 31 >= xs) {       // wave-uniform: this tile holds encoded slots
+                    const int qe = (q >= xs && q < a.K0_pad) ? q - xs : 0;
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(stE + qe * 32 + 16 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 v = p[e];
+                        if (q >= xs && q < a.K0_pad) av[e] = v;
+                    }
+                }
             } else {
                 const f32x4 *p = reinterpret_cast<const f32x4 *>(st + ((l - 1) * H + 32 * ttk[m] + i) * 32 + 16 * h);
 #pragma unroll
@@ -412,8 +425,8 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
 
     WgradArgs w;
     constexpr int T = H / 32;
-    w.n_layers = a.n_layers; w.in_dim = a.in_dim; w.K0 = a.K0; w.enc = a.enc; w.n_freqs = a.n_freqs; w.out_dim = a.out_dim;
-    w.freqs = a.freqs;
+    w.n_layers = a.n_layers; w.in_dim = a.in_dim; w.K0 = a.K0; w.K0_pad = a.K0_pad; w.enc = a.enc; w.n_freqs = a.n_freqs;
+    w.out_dim = a.out_dim;
     w.Tk0 = (a.K0_pad + 31) / 32;
     w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
     for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
@@ -443,7 +456,8 @@ extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n
 {
     if (!v2_supported(desc) || n <= 0) return 0;
     const int H = desc->dims[1], NH = desc->n_layers - 1;
-    return ((n + 31) / 32) * (int64_t)(2 * NH * H + 4) * 32 * (int64_t)sizeof(float);
+    const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
+    return ((n + 31) / 32) * (int64_t)(2 * NH * H + 4 + extra) * 32 * (int64_t)sizeof(float);
 }
 
 extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,

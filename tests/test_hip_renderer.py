@@ -27,9 +27,12 @@ def build_renderer(g, bg=True):
     return r.to(DEV)
 
 
-def test_renderer_forward_backward_vs_reference():
+@pytest.mark.parametrize("fused", [True, False])
+def test_renderer_forward_backward_vs_reference(fused):
+    """fused = one autograd node over the C-ABI kernels; not fused = module-by-module like the reference."""
     g = load_golden("G9_renderer_kplanes")
     r = build_renderer(g)
+    r.fused = fused
     packed, info = cu(g["packed"]), cu(g["info"], torch.int32)
     out = r(packed, info)
     assert out.shape == (info.shape[0], 3)
@@ -72,3 +75,18 @@ def test_renderer_empty_iteration(capsys):
     # all-masked: threshold above 1 terminates every ray before its first sample
     out = r(cu(g["packed"]), cu(g["info"], torch.int32), early_termination_threshold=2.0)
     np.testing.assert_allclose(out.detach().cpu().numpy(), e["rendered_empty"], atol=0)
+
+
+def test_fused_accumulates_into_existing_grads():
+    """harness option: parameter gradients are added in place into param.grad (two steps == twice one step)."""
+    g = load_golden("G9_renderer_kplanes")
+    r = build_renderer(g)
+    packed, info, target = cu(g["packed"]), cu(g["info"], torch.int32), cu(g["target"])
+    for p in r.parameters():
+        p.grad = torch.zeros_like(p)
+    r.accumulate_into_grad = True
+    for _ in range(2):
+        torch.nn.functional.mse_loss(r(packed, info), target).backward()
+    for name, p in r.named_parameters():
+        ref = 2 * g["grad." + name]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * max(1.0, np.abs(ref).max() / 1e-2), err_msg=name)

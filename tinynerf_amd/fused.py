@@ -1,0 +1,139 @@
+"""Fused K-Planes render path: the whole of ``NerfRenderer.forward`` (reference core.py:225-267) as one
+autograd node that drives the C-ABI kernels back to back on the current stream.
+
+The module-by-module path in ``core.NerfRenderer`` mirrors the reference's data flow, including its
+boolean gather of the samples with w > 0 (a host sync, a [M,96] gather, an index_copy and their autograd
+counterparts).  Here every sample goes through the colour head in place -- samples with w == 0 contribute
+exactly 0 to the composite in both directions, as in the reference -- so there is no sync, no gather and
+no intermediate autograd graph: forward = gather+sigma -> weights scan -> colour -> composite,
+backward = composite -> colour head -> weights -> sigma head -> plane scatter, 9 launches in total.
+Parameter gradients are accumulated straight into ``param.grad`` when it exists (the harness keeps the
+gradient buffers allocated), which saves two passes over the 126 MiB of plane gradients per step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from .models import _hwc, _kplanes_desc, _mlp_desc
+
+
+def _workspace(desc: L.MlpDesc, n: int, dev: torch.device):
+    fn = L.lib().tn_mlp_bwd_workspace_bytes
+    fn.restype = C.c_int64
+    nbytes = int(fn(C.byref(desc), C.c_int64(n)))
+    return (torch.empty(nbytes // 4, device=dev) if nbytes else None), nbytes
+
+
+class _RenderKPlanes(Function):
+    @staticmethod
+    def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
+                freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool,
+                *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+        planes = list(params[:n_planes])
+        sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
+        rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
+        dev = L.require_cuda(packed, info, *sig_p, *rgb_p)
+        n, R = packed.size(0), info.size(0)
+        kdesc, keep = _kplanes_desc(planes)
+        F = kdesc.n_scales * kdesc.channels
+        feat = torch.empty((n, F), device=dev)
+        L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+        sigma = torch.empty(n, device=dev)
+        L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
+        steps = packed[:, 6].contiguous()
+        dirs = packed[:, 3:6].contiguous()
+        weights = torch.empty(n, device=dev)
+        L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
+               C.c_int64(n), C.c_int64(R))
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
+        rgbs = torch.empty((n, 3), device=dev)
+        L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
+        out = torch.empty((R, 3), device=dev)
+        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
+               C.c_int64(n), C.c_int64(R))
+        ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, dirs, weights, rgbs, *params)
+        ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate)
+        ctx.param_refs = params if accumulate else None
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
+        packed, info, bg, freqs, feat, sigma, steps, dirs, weights, rgbs, *params = ctx.saved_tensors
+        n_freqs, n_planes, n_sigma, accumulate = ctx.cfg
+        planes = list(params[:n_planes])
+        sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
+        rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
+        dev = packed.device
+        n, R = packed.size(0), info.size(0)
+        F = feat.size(1)
+        g_out = grad_out.contiguous()
+
+        def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
+            if accumulate and ref is not None and ref.grad is not None and ref.grad.stride() == p.stride():
+                return ref.grad, True
+            return torch.zeros_like(p), False
+
+        refs: Sequence[Optional[torch.Tensor]] = ctx.param_refs if ctx.param_refs is not None else [None] * len(params)
+        bufs = [grad_buffer(p, r) for p, r in zip(params, refs)]
+        g_planes = [b[0] for b in bufs[:n_planes]]
+        g_sig = [b[0] for b in bufs[n_planes:n_planes + n_sigma]]
+        g_rgb = [b[0] for b in bufs[n_planes + n_sigma:]]
+
+        g_rgbs = torch.empty_like(rgbs)
+        g_w = torch.empty_like(weights)
+        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
+               L.ptr(g_w), C.c_int64(n), C.c_int64(R))
+        # colour head: grads of its parameters + d/d feat
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
+        nl = len(rgb_p) // 2
+        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[0::2]])
+        gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[1::2]])
+        g_feat = torch.empty_like(feat)
+        ws, ws_bytes = _workspace(rdesc, n, dev)
+        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), L.ptr(g_rgbs), C.c_int64(n), gw, gb, L.ptr(g_feat),
+               L.ptr(ws), C.c_int64(ws_bytes))
+        # weights -> sigma
+        g_sigma = torch.zeros_like(sigma)
+        L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
+               C.c_int64(n), C.c_int64(R))
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+        nl = len(sig_p) // 2
+        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[0::2]])
+        gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[1::2]])
+        g_feat2 = torch.empty_like(feat)
+        ws, ws_bytes = _workspace(sdesc, n, dev)
+        L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw, gb,
+               L.ptr(g_feat2), L.ptr(ws), C.c_int64(ws_bytes))
+        g_feat.add_(g_feat2)
+        # plane scatter
+        kdesc, keep = _kplanes_desc(planes)
+        gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
+        for s in range(kdesc.n_scales):
+            for p in range(3):
+                gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
+        L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
+        grads = [None if in_place else g for (g, in_place) in bufs]
+        return (None, None, None, None, None, None, None, None, None, *grads)
+
+
+def supports(renderer) -> bool:
+    from .models import KPlanesFeatureField, VanillaColorDecoder, VanillaOpacityDecoder
+    fm, sd, cd = renderer.feature_module, renderer.sigma_decoder, renderer.rgb_decoder
+    return (isinstance(fm, KPlanesFeatureField) and isinstance(sd, VanillaOpacityDecoder) and isinstance(cd, VanillaColorDecoder)
+            and fm.dropout.p == 0.0 and type(sd) is VanillaOpacityDecoder and type(cd) is VanillaColorDecoder)
+
+
+def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accumulate_into_grad: bool = False) -> torch.Tensor:
+    """Fused forward of ``renderer`` (a NerfRenderer with K-Planes field + Vanilla decoders) on packed samples."""
+    fm, sd, cd = renderer.feature_module, renderer.sigma_decoder, renderer.rgb_decoder
+    planes = fm.plane_tensors()
+    sig_p, rgb_p = sd.net.params(), cd.net.params()
+    bg = renderer._bg(packed.device)
+    return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
+                                len(sig_p), accumulate_into_grad, *planes, *sig_p, *rgb_p)

@@ -93,6 +93,7 @@ class Trainer:
         params = list(self.renderer.parameters())
         for p in params:                                # grads keep the parameter's (channels_last) layout
             p.grad = torch.zeros_like(p)
+        self.renderer.accumulate_into_grad = True       # fused path adds into these buffers directly
         self.optimizer = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=[self.steps // 2, self.steps * 3 // 4, self.steps * 5 // 6, self.steps * 9 // 10],

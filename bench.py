@@ -178,6 +178,28 @@ def main():
     dt, samples, rays_n = stats.tolist()
     loss = tr.loss_value()
 
+    # stage rates on one batch of the same workload (sampler / render fwd / render fwd+bwd)
+    stages = None
+    if rank == 0:
+        def timed(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps
+        packed, info, target, _ = tr.build_batch()
+        nb = packed.size(0)
+        t_samp = timed(lambda: tr.build_batch())
+        with torch.no_grad():
+            t_fwd = timed(lambda: tr.renderer(packed, info))
+        def fwd_bwd():
+            tr.optimizer.zero_grad(set_to_none=False)
+            torch.nn.functional.mse_loss(tr.renderer(packed, info), target).backward()
+        t_fb = timed(fwd_bwd)
+        stages = {"sampler_samples_per_s": nb / t_samp, "render_fwd_samples_per_s": nb / t_fwd,
+                  "render_fwd_bwd_samples_per_s": nb / t_fb, "batch_samples": nb}
+
     if rank == 0:
         ks = timer.summary()
         dom = max(ks, key=lambda t: ks[t]["total_ms"]) if ks else None
@@ -205,6 +227,7 @@ def main():
                        "parallelism": f"rays sharded over {world} rank(s), RCCL gradient all-reduce" if world > 1 else "single GPU",
                        "samples_per_step_per_gpu": samples / args.steps / world, "rays_per_step_per_gpu": rays_n / args.steps / world},
             "loss": loss,
+            "stages": stages,
             "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
             "roofline": roof,
         }

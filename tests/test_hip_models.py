@@ -259,3 +259,53 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     for g, p in zip(got, ref_params):
         np.testing.assert_allclose(g.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(field.regulariser(1e-4, 0.0).item(), 1e-4 * tv.item(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(kind="vanilla", F=10, H=256, layers=8, n=700),        # reference config (run.py:131): 60->256 x9 ->256
+    dict(kind="vanilla", F=6, H=128, layers=5, n=333),
+    dict(kind="mlp", K=36, H=128, layers=5, out=128, n=500),   # Cobafa MLP (run.py:141-147)
+    dict(kind="mlp", K=40, H=64, layers=6, out=3, n=257),      # deeper than the register-resident forms cover
+    dict(kind="color", F=4, dim=256, H=128, layers=1, n=300),  # reference tests/test_core.py:58 decoder shape
+])
+def test_wide_deep_mlp_backward_vs_torch(cfg):
+    """layer-by-layer backward (mlp_bwd_layers.hip) against torch autograd of the same fp32 network on the device."""
+    m = models()
+    torch.manual_seed(11)
+    n = cfg["n"]
+    if cfg["kind"] == "vanilla":
+        net = m.VanillaFeatureMLP(cfg["F"], cfg["H"], cfg["layers"]).to(DEV)
+        x = torch.rand(n, 3, device=DEV) * 2 - 1
+        y = net(x)
+        ref_in = net.encoding(x)
+        seq = net.net.net
+    elif cfg["kind"] == "mlp":
+        net = m.MLP(cfg["K"], cfg["H"], cfg["layers"], cfg["out"]).to(DEV)
+        x = torch.randn(n, cfg["K"], device=DEV, requires_grad=True)
+        y = net(x)
+        ref_in = x
+        seq = net.net
+    else:
+        net = m.VanillaColorDecoder(cfg["F"], cfg["dim"], cfg["H"], cfg["layers"]).to(DEV)
+        x = torch.rand(n, cfg["dim"], device=DEV, requires_grad=True)
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
+        y = net(x, d)
+        ref_in = torch.cat([net.pe(d), d, x], -1)
+        seq = net.net.net
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    gx = x.grad.clone() if x.requires_grad else None
+    net.zero_grad()
+    if x.requires_grad:
+        x.grad = None
+    y2 = seq(ref_in)
+    if cfg["kind"] == "color":
+        y2 = torch.sigmoid(y2)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), atol=2e-5)
+    y2.backward(gy)
+    for k, p in net.named_parameters():
+        ref = p.grad.cpu().numpy()
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    if gx is not None:
+        np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=3e-4, atol=2e-5)

@@ -35,6 +35,7 @@ SOURCES = {
     "mlp.hip": FAST,
     "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "render.hip": FAST + ["-munsafe-fp-atomics"],
 }
 

@@ -65,8 +65,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
 #pragma unroll
             for (int ob = 0; ob < T; ++ob) {
                 if constexpr (WLDS) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
-                else {   // global first layer: columns are in torch order, no permutation possible
-                    w[ob] = load_a4<false>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.K0);
+                else if (a.enc != TN_ENC_DIR_CAT) w[ob] = load_a4<false>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.K0);
+                else {   // global first layer of a dir_cat head: slot -> torch column, one dword at a time
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = 8 * g + 4 * h + u;
+                        w[ob][u] = q < a.K0 ? W0[(int64_t)(32 * ob + j) * a.K0 + layer0_col(a, q)] : 0.0f;
+                    }
                 }
             }
 #pragma unroll
@@ -186,8 +191,7 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
         kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act);
     } else {
-        // weights streamed from L2; the DIR_CAT column permutation needs the LDS copy
-        if (a.enc == TN_ENC_DIR_CAT) return tn::fail(TN_E_CONFIG, "mlp: dir_cat head too large for LDS staging");
+        // weights streamed from L2
         auto kern = mlp_fwd_kernel<H, false, WPB>;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
         kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act);

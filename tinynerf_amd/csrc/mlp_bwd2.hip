@@ -23,6 +23,9 @@
 
 extern "C" int tn_mlp_bwd_fused1(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, void *stream);
+extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
+extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
+                                 float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
 
 namespace {
 
@@ -407,6 +410,20 @@ bool v2_supported(const tn_mlp_desc *d) {
     return true;
 }
 
+// the single-kernel form (mlp_bwd.hip) covers narrow, shallow heads only
+bool v1_supported(const tn_mlp_desc *d) {
+    if (!d) return false;
+    const int L = d->n_layers, H = d->dims[1];
+    if (L < 2 || L > 5) return false;
+    if (H != 32 && H != 64 && H != 128) return false;
+    if ((L - 1) * H > 256) return false;
+    for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
+    if (d->dims[L] < 1 || d->dims[L] > H) return false;
+    int acc = 0;                                       // its LDS gradient image + 8 wave scratches must fit 160 KiB
+    for (int l = 0; l < L; ++l) acc += ((d->dims[l + 1] * d->dims[l] + 3) & ~3) + ((d->dims[l + 1] + 3) & ~3);
+    return acc + 8 * 2 * 32 * 34 <= 160 * 1024 / 4;
+}
+
 template <int H, int NH>
 int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
               float *const *gw, float *const *gb, float *gx, float *stash, hipStream_t s)
@@ -454,7 +471,8 @@ int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const fl
 
 extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n)
 {
-    if (!v2_supported(desc) || n <= 0) return 0;
+    if (n <= 0 || !desc) return 0;
+    if (!v2_supported(desc)) return v1_supported(desc) ? 0 : tn_mlp_bwd_layers_workspace_bytes(desc, n);
     const int H = desc->dims[1], NH = desc->n_layers - 1;
     const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
     return ((n + 31) / 32) * (int64_t)(2 * NH * H + 4 + extra) * 32 * (int64_t)sizeof(float);
@@ -465,6 +483,13 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
                           int64_t workspace_bytes, void *stream)
 {
     const int64_t need = tn_mlp_bwd_workspace_bytes(desc, n);
+    if (!v2_supported(desc) && !v1_supported(desc)) {          // wide / deep stack: layer-by-layer form
+        if (n == 0) return TN_OK;
+        TN_REQUIRE(need > 0, TN_E_CONFIG, "tn_mlp_bwd: unsupported layer configuration");
+        TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: this configuration needs the workspace");
+        TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_bwd: workspace must be 16-byte aligned");
+        return tn_mlp_bwd_layers(desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stream);
+    }
     if (need == 0 || workspace == nullptr || workspace_bytes < need)
         return tn_mlp_bwd_fused1(desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, stream);
     MlpArgs a;

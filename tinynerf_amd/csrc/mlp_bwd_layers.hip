@@ -1,0 +1,419 @@
+// Backward of WIDE / DEEP fused MLPs (Vanilla feature stack 60->256x9->256, Cobafa 36->128x6), layer by
+// layer.  The register-resident forms (mlp_bwd.hip, mlp_bwd2.hip) need every hidden activation of a tile on
+// chip; a 9 x 256 stack does not fit.  This path keeps the same transposed MFMA building blocks but runs
+//
+//   1 launch   forward that streams every hidden activation H_l to the workspace ([feature][32 samples]
+//              rows, as in mlp_bwd2.hip) and leaves the output gradient g = dL/dy * act'(pre) there too;
+//   per layer  wgrad (dW_l += G_l H_l^T, sample-reducing MFMA tiles) and dgrad
+//              (G_{l-1} = relu'(H_l) * W_l^T G_l, or grad_x for the first layer),
+//
+// i.e. 2L+1 launches with all activations crossing HBM exactly once in each direction (the reference's
+// autograd does the same through cuBLAS with NHW-major activations and separate bias / ReLU kernels).
+// Weights are read from L2 (256x256 fp32 = 256 KiB per layer does not fit LDS next to anything else).
+#include "mlp_stage.h"
+#include <algorithm>
+
+namespace {
+
+using tn::f32x16;
+using tn::f32x4;
+using namespace tn::mlp;
+
+__device__ __forceinline__ float act_grad(float pre, int act) {
+    if (act == TN_ACT_EXP_M1) return expf(fminf(fmaxf(pre - 1.0f, -15.0f), 15.0f));     // models.py:50-53
+    if (act == TN_ACT_SIGMOID) { const float s = 1.0f / (1.0f + expf(-pre)); return s * (1.0f - s); }
+    return 1.0f;
+}
+__device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }     // D-layout row of reg r
+
+__device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[(32 * ob + frow(r, h)) * 32 + j] = t[r];
+}
+
+struct Layout {            // rows (of 32 floats) per 32-sample tile
+    int rowsH, rowsE, rowsG, total;
+    int xs;                // first-layer slots that are plain x columns
+};
+__host__ __device__ inline Layout make_layout(int H, int n_layers, int enc, int in_dim, int K0_pad, int out_dim) {
+    Layout L;
+    L.xs = enc == TN_ENC_POSENC ? 0 : in_dim;
+    L.rowsH = (n_layers - 1) * H;
+    L.rowsE = enc == TN_ENC_NONE ? 0 : K0_pad - L.xs;
+    const int outp = (out_dim + 31) & ~31;
+    L.rowsG = H > outp ? H : outp;
+    L.total = L.rowsH + L.rowsE + 2 * L.rowsG;
+    return L;
+}
+
+__device__ __forceinline__ int col0(const MlpArgs &a, int q) { return layer0_col(a, q); }
+
+// ------------------------------------------------------------------------------------------------
+// forward with activation stash + output gradient
+// ------------------------------------------------------------------------------------------------
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+                                                             const float *__restrict__ gy, int64_t n, float *__restrict__ stash)
+{
+    constexpr int T = H / 32;
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int L = a.n_layers, G0 = a.K0_pad >> 3, out = a.out_dim;
+    const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        float aux3[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
+            else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
+        }
+        float *st = stash + tile * (int64_t)lay.total * 32;
+        float *stE = st + lay.rowsH * 32;
+        float *stG = stE + lay.rowsE * 32;               // buffer A: receives the output gradient
+        f32x16 act[T];
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(a.B[0], ob, h);
+#pragma clang loop unroll(disable)
+        for (int g = 0; g < G0; ++g) {
+            const f32x4 b = fetch_input(a, xrow, aux3, valid, g, h);
+            f32x4 w[T];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = 8 * g + 4 * h + u;
+                    w[ob][u] = q < a.K0 ? a.W[0][(int64_t)(32 * ob + j) * a.K0 + col0(a, q)] : 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
+            if (a.enc != TN_ENC_NONE && 8 * g + 4 * h + 3 >= lay.xs) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = 8 * g + 4 * h + u;
+                    if (q >= lay.xs) stE[(q - lay.xs) * 32 + j] = b[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) {
+            tn::pin16(act[ob]);
+            act[ob] = tn::relu16(act[ob]);
+            store_rows(st, act[ob], ob, j, h);
+        }
+        for (int l = 1; l + 1 < L; ++l) {
+            tn::hidden_layer<H>(a.W[l], a.B[l], H, act, j, h);
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) store_rows(st + l * H * 32, act[ob], ob, j, h);
+        }
+        // output layer -> g = gy * act'(pre) as rows [out feature][32 samples]
+        const float *Wf = a.W[L - 1];
+        const float *Bf = a.B[L - 1];
+        if (out <= 4) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float g = 0.0f;
+                if (o < out) {
+                    const float pre = tn::small_out<H>(Wf + o * H, Bf[o], act, h);
+                    g = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
+                }
+                if (h == 0) stG[o * 32 + j] = g;
+            }
+            // rows 4..31 of the first tile are read as zeros by the consumers (they clamp to `out`)
+        } else {
+            const int n_ob = (out + 31) >> 5;
+            for (int ob = 0; ob < n_ob; ++ob) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const int f = 32 * ob + frow(r, h); acc[r] = f < out ? Bf[f] : 0.f; }
+                const int arow = 32 * ob + j;
+#pragma unroll
+                for (int kb = 0; kb < T; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                        if (arow < out) w = *reinterpret_cast<const f32x4 *>(Wf + (int64_t)arow * H + 32 * kb + 8 * q + 4 * h);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], act[kb][4 * q + u], acc);
+                    }
+                tn::pin16(acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 32 * ob + frow(r, h);
+                    stG[f * 32 + j] = (valid && f < out) ? gy[row * out + f] * act_grad(acc[r], a.out_act) : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// data gradient of one layer:  Gout = relu'(Hmask) * (W^T Gin)      (FIRST: grad_x, no mask, row-major out)
+// ------------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float *W;       // [N][K] torch layout
+    int N, K;             // rows / columns of W
+    int rows_total;       // stash rows per tile
+    int off_gin, off_gout, off_mask;    // row offsets inside a tile
+    int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
+};
+
+template <int H, bool FIRST, int WPB>
+__global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ gx)
+{
+    constexpr int T = H / 32;
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int TN = (a.N + 31) >> 5, ng = (a.N + 7) >> 3;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        float *st = stash + tile * (int64_t)a.rows_total * 32;
+        const float *gin = st + a.off_gin * 32;
+        f32x16 G[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * t + frow(r, h);
+                G[t][r] = (t < TN && nn < a.N) ? gin[nn * 32 + j] : 0.0f;
+            }
+        const int n_kt = FIRST ? (a.in_dim + 31) >> 5 : T;
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < n_kt; ++kt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const int k = 32 * kt + j;
+            int kc = k;
+            bool kok = true;
+            if (FIRST) {
+                kok = k < a.in_dim;
+                kc = a.enc == TN_ENC_DIR_CAT ? 6 * a.n_freqs + 3 + k : k;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (4 * t + q < ng) {
+                        float w[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int nn = 32 * t + 8 * q + 4 * h + u;
+                            w[u] = (nn < a.N && kok) ? a.W[(int64_t)nn * a.K + kc] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], G[t][4 * q + u], acc);
+                    }
+                }
+            }
+            tn::pin16(acc);
+            if (FIRST) {
+                const int64_t row = tile * 32 + j;
+                if (row < n) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * kt + frow(r, h);
+                        if (f < a.in_dim) gx[row * a.in_dim + f] = acc[r];
+                    }
+                }
+            } else {
+                const float *hm = st + a.off_mask * 32;
+                float *gout = st + a.off_gout * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 32 * kt + frow(r, h);
+                    gout[f * 32 + j] = hm[f * 32 + j] > 0.0f ? acc[r] : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    float *gW, *gB;
+    int N, K, K_pad;
+    int rows_total, off_g, off_a, off_e;
+    int first, enc, in_dim, n_freqs, xs;
+};
+
+template <int MAXS>
+__global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const float *__restrict__ x, int64_t n,
+                                                          const float *__restrict__ stash)
+{
+    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int Tn = (a.N + 31) >> 5, Tk = (a.K_pad + 31) >> 5;
+    const int total = Tn * Tk;
+    f32x16 acc[MAXS];
+    float dbacc[MAXS];
+    int ttn[MAXS], ttk[MAXS];
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+        dbacc[m] = 0.0f;
+        const int id = wave + 8 * m;
+        ttn[m] = id < total ? id / Tk : -1;
+        ttk[m] = id < total ? id - (id / Tk) * Tk : 0;
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *st = stash + tile * (int64_t)a.rows_total * 32;
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) {
+            if (ttn[m] < 0) continue;
+            const int nrow = 32 * ttn[m] + i;
+            f32x4 gv[4], av[4];
+            {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + (a.off_g + (nrow < a.N ? nrow : 0)) * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; gv[e] = nrow < a.N ? v : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+            const int q0 = 32 * ttk[m], q = q0 + i;
+            if (a.first) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q0 < a.xs) {
+                    const int qx = q < a.xs ? q : 0;
+                    const int64_t r0 = tile * 32 + 16 * h;
+                    float xv[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) { const int64_t rc = r0 + t < n ? r0 + t : n - 1; xv[t] = x[rc * a.in_dim + qx]; }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = (q < a.xs && r0 + t < n) ? xv[t] : 0.0f;
+                }
+                if (a.enc != TN_ENC_NONE && q0 + 31 >= a.xs) {
+                    const bool ise = q >= a.xs && q < a.K_pad;
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(st + (a.off_e + (ise ? q - a.xs : 0)) * 32 + 16 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; if (ise) av[e] = v; }
+                }
+            } else {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + (a.off_a + (q < a.K ? q : 0)) * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; av[e] = q < a.K ? v : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[e][u], av[e][u], acc[m]);
+            if (ttk[m] == 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += (gv[e][0] + gv[e][1]) + (gv[e][2] + gv[e][3]);
+                dbacc[m] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+        if (ttn[m] < 0) continue;
+        tn::pin16(acc[m]);
+        const int k = 32 * ttk[m] + i;
+        const bool kok = k < a.K;
+        int kc = k;
+        if (a.first && a.enc == TN_ENC_DIR_CAT) { const int pe = 6 * a.n_freqs + 3; kc = k < a.in_dim ? pe + k : k - a.in_dim; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = 32 * ttn[m] + frow(r, h);
+            if (kok && nn < a.N) atomicAdd(&a.gW[(int64_t)nn * a.K + kc], acc[m][r]);
+        }
+        if (ttk[m] == 0) {
+            float s = dbacc[m];
+            s += __shfl_xor(s, 32, 64);
+            const int nn = 32 * ttn[m] + i;
+            if (h == 0 && nn < a.N) atomicAdd(&a.gB[nn], s);
+        }
+    }
+}
+
+template <int H>
+int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *gy, int64_t n, float *const *gw,
+               float *const *gb, float *gx, float *stash, hipStream_t s)
+{
+    const int L = a.n_layers;
+    const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim);
+    const int64_t n_tiles = (n + 31) / 32;
+    constexpr int WPB = H <= 64 ? 8 : 4;
+    {
+        const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
+        fwd_stash_kernel<H, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, gy, n, stash);
+        if (int rc = tn::check_launch("fwd_stash_kernel")) return rc;
+    }
+    const int offE = lay.rowsH, offGA = lay.rowsH + lay.rowsE, offGB = offGA + lay.rowsG;
+    int cur = offGA, nxt = offGB;
+    for (int l = L - 1; l >= 0; --l) {
+        WgradArgs w;
+        w.gW = gw[l]; w.gB = gb[l]; w.N = a.N[l]; w.K = a.K[l]; w.K_pad = l == 0 ? a.K0_pad : a.K[l];
+        w.rows_total = lay.total; w.off_g = cur; w.off_a = l > 0 ? (l - 1) * H : 0; w.off_e = offE;
+        w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
+        const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
+        const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
+        if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
+        else if (tiles <= 64) wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
+        else return tn::fail(TN_E_CONFIG, "mlp_bwd: layer too large for the wgrad tiling");
+        if (int rc = tn::check_launch("wgrad_layer_kernel")) return rc;
+
+        DgradArgs d;
+        d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
+        d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? (l - 1) * H : 0;
+        d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs;
+        const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
+        if (l > 0) {
+            dgrad_layer_kernel<H, false, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, nullptr);
+            if (int rc = tn::check_launch("dgrad_layer_kernel")) return rc;
+            std::swap(cur, nxt);
+        } else if (gx != nullptr && a.enc != TN_ENC_POSENC) {
+            dgrad_layer_kernel<H, true, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, gx);
+            if (int rc = tn::check_launch("dgrad_layer_kernel(first)")) return rc;
+        }
+    }
+    return TN_OK;
+}
+
+}  // namespace
+
+// internal entry points used by the dispatcher in mlp_bwd2.hip
+extern "C" __attribute__((visibility("hidden"))) int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n)
+{
+    if (!desc || n <= 0) return 0;
+    const int L = desc->n_layers, H = desc->dims[1];
+    if (L < 2 || L > TN_MLP_MAX_LAYERS) return 0;
+    if (H != 32 && H != 64 && H != 128 && H != 256) return 0;
+    for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
+    if (desc->dims[L] > H && desc->dims[L] > 256) return 0;
+    const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L]);
+    return ((n + 31) / 32) * (int64_t)lay.total * 32 * (int64_t)sizeof(float);
+}
+
+extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux,
+                                                                      const float *grad_y, int64_t n, float *const *grad_weights,
+                                                                      float *const *grad_biases, float *grad_x, float *workspace,
+                                                                      void *stream)
+{
+    MlpArgs a;
+    int H = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    TN_REQUIRE(x && grad_y && grad_weights && grad_biases && workspace, TN_E_NULL, "tn_mlp_bwd(layers): null pointer");
+    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_bwd(layers): dir_cat needs aux");
+    for (int l = 0; l < a.n_layers; ++l)
+        TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd(layers): null gradient pointer");
+    hipStream_t s = (hipStream_t)stream;
+    switch (H) {
+    case 32: return run_layers<32>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
+    case 64: return run_layers<64>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
+    case 128: return run_layers<128>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
+    default: return run_layers<256>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
+    }
+}

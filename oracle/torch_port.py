@@ -142,3 +142,63 @@ def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
     loss = loss_fn(leaves)
     loss.backward()
     return {k: v.grad.numpy() for k, v in leaves.items() if isinstance(v, torch.Tensor) and v.grad is not None}, float(loss)
+
+
+def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d: np.ndarray, rgbs: np.ndarray, *,
+                       method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
+                       bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10):
+    """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
+    shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
+    including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts)."""
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v.clone())
+          for k, v in sd0.items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    bs_ratio = 4096 / batch_size
+    steps = int(2048 * bs_ratio)
+    occ_updates = int(16 * bs_ratio)
+    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[steps // 2, steps * 3 // 4, steps * 5 // 6, steps * 9 // 10], gamma=0.33)
+    aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
+    step_size = float(orc.aabb_step_size(aabb, n_samples))
+    decay = 0.01 ** (1 / 16)
+    grid = np.ones((occupancy_res,) * 3, np.float32)
+    mean = 1.0
+    bg_t = torch.tensor(bg, dtype=torch.float32)
+    vf = vanilla_freqs if method == "vanilla" else 0
+    cursor, M = 0, rays_o.shape[0]
+    target_size = batch_size * n_samples
+    losses, counts = [], []
+
+    def sigma_np(pts: np.ndarray) -> np.ndarray:
+        with torch.no_grad():
+            x = torch.from_numpy(np.ascontiguousarray(pts))
+            feat = mlp(sd, "feature_module.net.net.", posenc(x, sd["feature_module.encoding.freqs"])) if vf else kplanes_features(sd, x)
+            return torch.exp(mlp(sd, "sigma_decoder.net.net.", feat) - 1.).numpy()
+
+    for step in range(n_steps):
+        thr = min(0.01, mean)
+        # dynamic batch (run.py:215-244) over consecutive loader batches
+        def batches():
+            c = cursor
+            while True:
+                idx = (c + np.arange(batch_size)) % M
+                yield rays_o[idx], rays_d[idx], rgbs[idx]
+                c += batch_size
+        prov = lambda o, d: orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
+                                             n_samples=n_samples, near=0.1, aabb=aabb)
+        packed, info, target, k = orc.dynamic_batch(batches(), prov, target_size)
+        cursor = (cursor + k * batch_size) % M
+        if step % occ_updates == 0:
+            jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
+            grid, mean = orc.occupancy_update(grid, sigma_np, step_size, 0.01, decay, mean, jit)
+        out = render(sd, torch.from_numpy(packed), torch.from_numpy(info), bg_t, vanilla_freqs=vf)
+        loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
+        if method == "kplanes":
+            loss = loss + 1e-4 * loss_tv(sd)
+        opt.zero_grad()
+        (loss * grad_scale).backward()
+        opt.step()
+        sched.step()
+        losses.append(float(loss.detach()))
+        counts.append((int(packed.shape[0]), int(info.shape[0])))
+    return losses, {k: v.detach() for k, v in sd.items()}, counts

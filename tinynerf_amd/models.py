@@ -350,11 +350,13 @@ class KPlanesFeaturePlane(torch.nn.Module):
 
 
 class KPlanesFeatureField(torch.nn.Module):
-    def __init__(self, feature_dim: int = 32):
+    def __init__(self, feature_dim: int = 32, resolutions: Sequence[int] = (128, 256, 512)):
+        """``resolutions`` is an extension (the reference hard-codes 128/256/512, models.py:126-142); the default
+        reproduces the reference."""
         super().__init__()
         self.planes = torch.nn.ModuleList([
             torch.nn.ModuleList([KPlanesFeaturePlane(feature_dim, resolution=(r, r)) for _ in range(3)])
-            for r in (128, 256, 512)
+            for r in resolutions
         ])
         self.dropout = torch.nn.Dropout(0.)
         # coordinate pairs, in this order (models.py:144-146); the kernel hard-codes the same order

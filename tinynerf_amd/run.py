@@ -43,6 +43,9 @@ class TrainConfig:
     scene_scale: float = 1.0           # uniform_range of the unbounded marcher
     grad_scale: float = 2.0 ** 10      # GradScaler(2**10) without unscale (run.py:201,259-260)
     seed: int = 0
+    occupancy_res: int = 128           # run.py:106
+    deterministic: bool = False        # parity runs: consecutive rays, no sampling jitter, voxel-centre occupancy refresh
+    kplanes_resolutions: Tuple[int, ...] = (128, 256, 512)      # models.py:126-142
 
 
 def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: torch.device):
@@ -50,7 +53,7 @@ def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: t
     if cfg.method == "vanilla":
         feature_module: torch.nn.Module = VanillaFeatureMLP(10, 256, 8)
     elif cfg.method == "kplanes":
-        feature_module = KPlanesFeatureField(32)
+        feature_module = KPlanesFeatureField(32, cfg.kplanes_resolutions)
     elif cfg.method == "cobafa":
         feature_module = CobafaFeatureField(
             basis_res=torch.linspace(32., 128, 6).int().tolist(), coef_res=64,
@@ -69,7 +72,7 @@ def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: t
         contraction = ContractionAABB(aabb)
     else:
         raise NotImplementedError(f"Unknown scene type {cfg.scene_type}.")
-    occupancy_grid = OccupancyGrid(size=128, step_size=ray_marcher.step_size, threshold=0.01,
+    occupancy_grid = OccupancyGrid(size=cfg.occupancy_res, step_size=ray_marcher.step_size, threshold=0.01,
                                    decay=0.01 ** (1 / 16)).to(device)
     ray_provider = RayProvider(occupancy_grid=occupancy_grid, contraction=contraction, ray_marcher=ray_marcher)
     renderer = NerfRenderer(feature_module, sigma_decoder, rgb_decoder, bg_color=bg_color).to(device)
@@ -99,6 +102,7 @@ class Trainer:
             self.optimizer, milestones=[self.steps // 2, self.steps * 3 // 4, self.steps * 5 // 6, self.steps * 9 // 10],
             gamma=0.33)
         self.train_step = 0
+        self._cursor = 0                 # deterministic mode: position in the ray table
         self._k_guess = 8
         # per-rank ray stream: same generator family, different seed -> disjoint draws
         self._gen = torch.Generator(device=device)
@@ -116,9 +120,12 @@ class Trainer:
         n_chunks = (S + 63) // 64
         while True:
             n_b = min(4096, max(2, int(self._k_guess * 1.5) + 2))
-            idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
+            if cfg.deterministic:
+                idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
+            else:
+                idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
             o, d = self.rays_o[idx], self.rays_d[idx]
-            desc = rp._desc(dev, True, None)
+            desc = rp._desc(dev, not cfg.deterministic, None)
             desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
             R_all = n_b * B
             maskbits = torch.empty((R_all, n_chunks), dtype=torch.int64, device=dev)
@@ -131,6 +138,7 @@ class Trainer:
                 break
             self._k_guess = n_b * 2                      # not enough rays drawn: redraw a larger block
         self._k_guess = k
+        self._cursor = (self._cursor + R) % self.rays_o.size(0)
         info = torch.empty((R, 2), dtype=torch.int32, device=dev)
         total = torch.empty(1, dtype=torch.int32, device=dev)
         L.call("tn_sample_scan", dev, L.ptr(counts), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
@@ -149,7 +157,11 @@ class Trainer:
         self.renderer.train()
         if self.train_step % self.occupancy_grid_updates == 0:                    # run.py:248-249
             torch.manual_seed(cfg.seed + 7919 * (self.train_step + 1))            # same jitter on every rank
-            self.occupancy_grid.update(self.sigma_fn)
+            jit = None
+            if cfg.deterministic:
+                r = cfg.occupancy_res
+                jit = torch.full((r, r, r, 3), 0.5, device=self.device)
+            self.occupancy_grid.update(self.sigma_fn, jitters=jit)
         rendered = self.renderer(packed, info)                                    # run.py:251
         loss = self.global_mse(rendered, target)
         if cfg.method == "kplanes":                                               # run.py:254-256

@@ -218,6 +218,13 @@ def main():
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None}
             roof.update(kernel=dom, avg_launch_ms=k["avg_ms"], rows_per_launch=k["avg_rows"], row=unit,
                         algorithmic_per_row=unit_work)
+            # HBM-side bytes per launch from the committed PMC passes (scripts/pmc.sh); they cannot be collected live
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+                roof["traffic"] = pmc["per_entry"].get(dom)
+                roof["traffic_source"] = "profiles/round1_pmc_traffic.json"
+            except Exception:
+                pass
         line = {
             "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

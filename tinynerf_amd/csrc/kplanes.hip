@@ -56,15 +56,17 @@ __global__ __launch_bounds__(256) void kplanes_fwd_kernel(KpArgs a, const float 
 // line ~270 G/s.  The forward mapping (lane = sample) is the slow pattern, so the scatter is transposed
 // through a 5 KiB per-wave LDS tile: phase A (lane = sample, channel half) writes the 32x32 tile of
 // d(feat)/d(plane value) plus the 4 tap offsets / weights of every sample; phase B (lane = channel) walks the
-// samples in order -- consecutive samples of a ray fall into the same texel for several steps (a straight
-// line visits the cells of a plane monotonically), so the contribution is accumulated in a register while
-// the texel offset stays the same and ONE full-line atomic is issued when it changes.  Half-wave 0 handles
-// the taps (nw, ne), half-wave 1 (sw, se).
+// samples in order -- consecutive samples of a ray fall into the same cell for several steps (a straight
+// line visits the cells of a plane monotonically), so the contributions of a RUN of samples are accumulated
+// in registers and ONE full-line atomic per tap is issued at the end of the run.  Run boundaries depend on
+// the cell only, so they are the same for all four taps: phase A ballots them into a 32-bit scalar mask and
+// phase B's control flow is scalar (s_bitcmp + s_cbranch, no exec-mask divergence).  Half-wave 0 handles the
+// taps (nw, ne), half-wave 1 (sw, se).
 constexpr int GS = 36;                                   // floats per tile row: conflict-free b128 writes
 constexpr int KP_WAVE_LDS = 32 * GS + 2 * 4 * 32;        // tile + offsets + weights (floats)
 
 template <int NV>
-__global__ __launch_bounds__(256) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
+__global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
                                                           int64_t n, const float *__restrict__ grad_feat)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * KP_WAVE_LDS];
@@ -115,29 +117,37 @@ __global__ __launch_bounds__(256) void kplanes_bwd_kernel(KpArgs a, const float 
                     tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
                     tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
                 }
+                // run boundaries: sample j closes a run when the next sample falls into another cell
+                const int cell = valid ? t[p].cell : -1 - j;
+                const int next_cell = __shfl_down(cell, 1, 64);
+                const unsigned run_end = (unsigned)__ballot(j == 31 || next_cell != cell);    // low 32 bits: half 0 == half 1
                 asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
-                // ---- phase B: lane = (tap pair hw, channel c) ----
+                // ---- phase B: lane = (tap pair h, channel c) ----
                 const int c = j;                       // channel
                 float *gbase = a.grads[s][p] + c;
                 if (c < C) {
+                    const int *O0 = tileO + (2 * h) * 32, *O1 = O0 + 32;
+                    const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
+                    const f32x4k *W1 = W0 + 8;
+                    float gv[32];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int *O = tileO + (2 * h + k) * 32;
-                        const float *Wt = tileW + (2 * h + k) * 32;
-                        float acc = 0.0f;
-                        int cur = -1;
-#pragma unroll 4
-                        for (int sI = 0; sI < 32; ++sI) {
-                            const int o = O[sI];
-                            const float contrib = tileG[sI * GS + c] * Wt[sI];
-                            if (o != cur) {
-                                if (cur >= 0) atomicAdd(gbase + cur, acc);
-                                acc = 0.0f;
-                                cur = o;
+                    for (int sI = 0; sI < 32; ++sI) gv[sI] = tileG[sI * GS + c];
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {
+                        const f32x4k w0 = W0[s4], w1 = W1[s4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sI = 4 * s4 + u;
+                            a0 = fmaf(gv[sI], w0[u], a0);
+                            a1 = fmaf(gv[sI], w1[u], a1);
+                            if ((run_end >> sI) & 1u) {          // wave-uniform
+                                const int o0 = O0[sI], o1 = O1[sI];
+                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                a0 = 0.0f; a1 = 0.0f;
                             }
-                            acc += contrib;
                         }
-                        if (cur >= 0) atomicAdd(gbase + cur, acc);
                     }
                 }
                 asm volatile("" ::: "memory");

@@ -182,7 +182,7 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
     const int64_t n_tiles = (n + 31) / 32;
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
-    constexpr int WPB = H <= 64 ? 8 : 4;
+    constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
     if (wlds) {
         auto kern = mlp_fwd_kernel<H, true, WPB>;
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -287,8 +287,10 @@ __device__ __forceinline__ void decode_tile(const WgradArgs &a, int id, int &l, 
     l = NH; tn_ = 0; tk = id;
 }
 
-template <int H, int NH, int MAXS>
-__global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+// NW waves per workgroup, each owning MAXS accumulator tiles (tile id = wave + NW*m): more, lighter waves
+// hide the HBM latency of the operand loads better than 8 heavy ones (0.97 -> see profiles/)
+template <int H, int NH, int MAXS, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                         int64_t n, const float *__restrict__ stash)
 {
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(512) void mlp_wgrad_kernel(WgradArgs a, const float
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
         dbacc[m] = 0.0f;
         tl[m] = -1; ttn[m] = 0; ttk[m] = 0;
-        const int id = wave + 8 * m;
+        const int id = wave + NW * m;
         if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
     }
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -406,7 +408,7 @@ bool v2_supported(const tn_mlp_desc *d) {
     for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
     if (d->dims[L] > 4) return false;
     const int T = H / 32, Tk0 = (((d->dims[0] + 7) & ~7) + 31) / 32;
-    if (T * Tk0 + (L - 2) * T * T + T > 40) return false;        // MAXS <= 5
+    if (T * Tk0 + (L - 2) * T * T + T > 48) return false;        // 16 waves x 3 accumulator tiles
     return true;
 }
 
@@ -448,10 +450,10 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
     for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
     const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
-    const int slots = (w.total_tiles + 7) / 8;
-    if (slots <= 1) mlp_wgrad_kernel<H, NH, 1><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
-    else if (slots <= 3) mlp_wgrad_kernel<H, NH, 3><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
-    else mlp_wgrad_kernel<H, NH, 5><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
+    if (w.total_tiles <= 8) mlp_wgrad_kernel<H, NH, 1, 8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
+    else if (w.total_tiles <= 16) mlp_wgrad_kernel<H, NH, 1, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
+    else if (w.total_tiles <= 32) mlp_wgrad_kernel<H, NH, 2, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
+    else mlp_wgrad_kernel<H, NH, 3, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
     return tn::check_launch("mlp_wgrad_kernel");
 }
 

@@ -220,6 +220,14 @@ int tn_plane_reg_fwd(const float *plane, int H, int W, int C, double *sums, void
 int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float cy, float cx, float cl1,
                      const float *upstream, float *grad, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * optimizer step of the harness                        (reference run.py:186,258-260: torch.optim.Adam)
+ * One pass per parameter tensor: g' = g + wd*p (coupled L2, as torch), m = b1 m + (1-b1) g',
+ * v = b2 v + (1-b2) g'^2, p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); optionally zeroes g for the
+ * next step.  28 B/element instead of torch's multi-kernel foreach path. */
+int tn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

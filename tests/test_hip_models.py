@@ -309,3 +309,28 @@ def test_wide_deep_mlp_backward_vs_torch(cfg):
         np.testing.assert_allclose(got[k].cpu().numpy(), ref, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
     if gx is not None:
         np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=3e-4, atol=2e-5)
+
+
+def test_fused_adam_matches_torch_adam():
+    """tn_adam_step against torch.optim.Adam (reference run.py:186 settings) over several steps, including a
+    channels_last parameter and the LR scheduler."""
+    from tinynerf_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1, 32, 16, 16), (64, 147), (64,), (3, 64), (1,)]
+    p_ref = [torch.rand(s, device=DEV) for s in shapes]
+    p_ref[0] = p_ref[0].contiguous(memory_format=torch.channels_last)
+    p_new = [torch.nn.Parameter(p.clone(memory_format=torch.preserve_format)) for p in p_ref]
+    p_ref = [torch.nn.Parameter(p) for p in p_ref]
+    o_ref = torch.optim.Adam(p_ref, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    o_new = FusedAdam(p_new, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
+    s_ref = torch.optim.lr_scheduler.MultiStepLR(o_ref, milestones=[3, 5], gamma=0.33)
+    s_new = torch.optim.lr_scheduler.MultiStepLR(o_new, milestones=[3, 5], gamma=0.33)
+    for it in range(8):
+        for a, b in zip(p_ref, p_new):
+            g = torch.randn_like(a) * 1024
+            a.grad = g.clone(memory_format=torch.preserve_format)
+            b.grad = g.clone(memory_format=torch.preserve_format)
+        o_ref.step(); o_new.step(); s_ref.step(); s_new.step()
+        for a, b in zip(p_ref, p_new):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+            assert float(b.grad.abs().max()) == 0.0          # zeroed in the same pass

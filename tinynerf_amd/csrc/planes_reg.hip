@@ -6,6 +6,7 @@
 // the plane's gradient buffer.  HBM-bound: fwd 4 B/element, bwd 12 B/element.
 #include "tn_common.h"
 #include <algorithm>
+#include <math.h>
 
 namespace {
 
@@ -58,6 +59,37 @@ __global__ __launch_bounds__(256) void plane_reg_bwd_kernel(const float *__restr
     }
 }
 
+// torch.optim.Adam (no amsgrad, coupled weight decay) for one tensor, element-wise, any memory layout
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n4, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, int zero_grad)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (4 * i + 3 < n) {
+            f4 pv = reinterpret_cast<f4 *>(p)[i], gv = reinterpret_cast<f4 *>(g)[i];
+            f4 mv = reinterpret_cast<f4 *>(m)[i], vv = reinterpret_cast<f4 *>(v)[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gg = gv[c] + wd * pv[c];
+                mv[c] = mv[c] + (gg - mv[c]) * (1.0f - b1);            // lerp form, as torch
+                vv[c] = b2 * vv[c] + (1.0f - b2) * gg * gg;
+                const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+                pv[c] = pv[c] - (lr / bc1) * (mv[c] / denom);
+            }
+            reinterpret_cast<f4 *>(p)[i] = pv; reinterpret_cast<f4 *>(m)[i] = mv; reinterpret_cast<f4 *>(v)[i] = vv;
+            if (zero_grad) reinterpret_cast<f4 *>(g)[i] = f4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int64_t e = 4 * i; e < n; ++e) {
+                const float gg = g[e] + wd * p[e];
+                m[e] = m[e] + (gg - m[e]) * (1.0f - b1);
+                v[e] = b2 * v[e] + (1.0f - b2) * gg * gg;
+                p[e] = p[e] - (lr / bc1) * (m[e] / (sqrtf(v[e]) / bc2_sqrt + eps));
+                if (zero_grad) g[e] = 0.0f;
+            }
+        }
+    }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -81,4 +113,20 @@ extern "C" int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float c
     const int64_t n = (int64_t)H * W * (C / 4);
     plane_reg_bwd_kernel<<<dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream>>>(plane, H, W, C / 4, cy, cx, cl1, upstream, grad);
     return tn::check_launch("plane_reg_bwd_kernel");
+}
+
+extern "C" int tn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, void *stream)
+{
+    TN_REQUIRE(n >= 0 && step >= 1, TN_E_SIZE, "tn_adam_step: bad size / step");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(param && grad && exp_avg && exp_avg_sq, TN_E_NULL, "tn_adam_step: null pointer");
+    const bool aligned = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));          // host doubles, like torch's python scalars
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    TN_REQUIRE(aligned, TN_E_ALIGN, "tn_adam_step: buffers must be 16-byte aligned");
+    const int64_t n4 = (n + 3) / 4;
+    adam_kernel<<<dim3(blocks_for(n4)), dim3(256), 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n4, n, lr, beta1, beta2, eps,
+                                                                             weight_decay, bc1, bc2_sqrt, zero_grad);
+    return tn::check_launch("adam_kernel");
 }

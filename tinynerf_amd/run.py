@@ -25,6 +25,7 @@ import torch
 from . import _lib as L
 from .core import (ContractionAABB, ContractionMip360, NerfRenderer, OccupancyGrid, RayMarcherAABB,
                    RayMarcherUnbounded, RayProvider)
+from .optim import FusedAdam
 from .models import (CobafaFeatureField, KPlanesFeatureField, VanillaColorDecoder, VanillaFeatureMLP,
                      VanillaOpacityDecoder)
 
@@ -97,7 +98,8 @@ class Trainer:
         for p in params:                                # grads keep the parameter's (channels_last) layout
             p.grad = torch.zeros_like(p)
         self.renderer.accumulate_into_grad = True       # fused path adds into these buffers directly
-        self.optimizer = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+        # torch.optim.Adam's update (run.py:186), one kernel pass per tensor, gradients zeroed in the same pass
+        self.optimizer = FusedAdam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=[self.steps // 2, self.steps * 3 // 4, self.steps * 5 // 6, self.steps * 9 // 10],
             gamma=0.33)
@@ -167,7 +169,7 @@ class Trainer:
         if cfg.method == "kplanes":                                               # run.py:254-256
             reg = self.renderer.feature_module.regulariser(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
             loss = loss + reg / self.world
-        self.optimizer.zero_grad(set_to_none=False)
+        # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
         (loss * cfg.grad_scale).backward()                                        # scaled, never unscaled (quirk)
         if self.world > 1:
             self.all_reduce_grads()

@@ -386,6 +386,7 @@ class NerfRenderer(torch.nn.Module):
         # set to False for the module-by-module path that mirrors the reference's data flow
         self.fused = True
         self.accumulate_into_grad = False      # harness option: add parameter grads straight into param.grad
+        self.reuse_buffers = False             # harness option: capacity-based scratch arena (fused.Arena)
         assert hasattr(self.feature_module, "feature_dim"), "feature module requires a feature_dim attribute"
 
     def _bg(self, device: torch.device) -> Optional[torch.Tensor]:

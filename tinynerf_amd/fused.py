@@ -22,17 +22,43 @@ from . import _lib as L
 from .models import _hwc, _kplanes_desc, _mlp_desc
 
 
-def _workspace(desc: L.MlpDesc, n: int, dev: torch.device):
+class Arena:
+    """Capacity-based scratch buffers for the harness: dynamic batches change N by a few percent every step, and a
+    caching allocator that sees a new 2.4 GB workspace size every few steps falls back to hipMalloc in the middle of
+    the step (measured: +60 ms stalls).  Buffers are allocated once with 25 % headroom and handed out as views.
+    Only valid when each forward's backward runs before the next forward (the training loop); opt-in."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, name: str, shape, dev: torch.device, dtype=torch.float32) -> torch.Tensor:
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        t = self.buf.get(name)
+        if t is None or t.numel() < numel or t.device != dev or t.dtype != dtype:
+            t = torch.empty(int(numel * 1.25) + 1024, device=dev, dtype=dtype)
+            self.buf[name] = t
+        return t[:numel].view(*shape)
+
+
+def _alloc(arena: Optional[Arena], name: str, shape, dev: torch.device) -> torch.Tensor:
+    return arena.get(name, shape, dev) if arena is not None else torch.empty(tuple(shape), device=dev)
+
+
+def _workspace(desc: L.MlpDesc, n: int, dev: torch.device, arena: Optional[Arena] = None, name: str = "ws"):
     fn = L.lib().tn_mlp_bwd_workspace_bytes
     fn.restype = C.c_int64
     nbytes = int(fn(C.byref(desc), C.c_int64(n)))
-    return (torch.empty(nbytes // 4, device=dev) if nbytes else None), nbytes
+    if not nbytes:
+        return None, 0
+    return _alloc(arena, name, (nbytes // 4,), dev), nbytes
 
 
 class _RenderKPlanes(Function):
     @staticmethod
     def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
-                freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool,
+                freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool, arena: Optional[Arena],
                 *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
@@ -41,24 +67,25 @@ class _RenderKPlanes(Function):
         n, R = packed.size(0), info.size(0)
         kdesc, keep = _kplanes_desc(planes)
         F = kdesc.n_scales * kdesc.channels
-        feat = torch.empty((n, F), device=dev)
+        feat = _alloc(arena, "feat", (n, F), dev)
         L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
-        sigma = torch.empty(n, device=dev)
+        sigma = _alloc(arena, "sigma", (n,), dev)
         L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
-        steps = packed[:, 6].contiguous()
-        dirs = packed[:, 3:6].contiguous()
-        weights = torch.empty(n, device=dev)
+        steps = _alloc(arena, "steps", (n,), dev).copy_(packed[:, 6])
+        dirs = _alloc(arena, "dirs", (n, 3), dev).copy_(packed[:, 3:6])
+        weights = _alloc(arena, "weights", (n,), dev)
         L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                C.c_int64(n), C.c_int64(R))
         rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
-        rgbs = torch.empty((n, 3), device=dev)
+        rgbs = _alloc(arena, "rgbs", (n, 3), dev)
         L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
         out = torch.empty((R, 3), device=dev)
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, dirs, weights, rgbs, *params)
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate)
+        ctx.arena = arena
         ctx.param_refs = params if accumulate else None
         return out
 
@@ -85,8 +112,9 @@ class _RenderKPlanes(Function):
         g_sig = [b[0] for b in bufs[n_planes:n_planes + n_sigma]]
         g_rgb = [b[0] for b in bufs[n_planes + n_sigma:]]
 
-        g_rgbs = torch.empty_like(rgbs)
-        g_w = torch.empty_like(weights)
+        arena = ctx.arena
+        g_rgbs = _alloc(arena, "g_rgbs", (n, 3), dev)
+        g_w = _alloc(arena, "g_w", (n,), dev)
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
                L.ptr(g_w), C.c_int64(n), C.c_int64(R))
         # colour head: grads of its parameters + d/d feat
@@ -94,20 +122,20 @@ class _RenderKPlanes(Function):
         nl = len(rgb_p) // 2
         gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[0::2]])
         gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[1::2]])
-        g_feat = torch.empty_like(feat)
-        ws, ws_bytes = _workspace(rdesc, n, dev)
+        g_feat = _alloc(arena, "g_feat", (n, F), dev)
+        ws, ws_bytes = _workspace(rdesc, n, dev, arena, "ws_rgb")
         L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), L.ptr(g_rgbs), C.c_int64(n), gw, gb, L.ptr(g_feat),
                L.ptr(ws), C.c_int64(ws_bytes))
         # weights -> sigma
-        g_sigma = torch.zeros_like(sigma)
+        g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
         nl = len(sig_p) // 2
         gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[0::2]])
         gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[1::2]])
-        g_feat2 = torch.empty_like(feat)
-        ws, ws_bytes = _workspace(sdesc, n, dev)
+        g_feat2 = _alloc(arena, "g_feat2", (n, F), dev)
+        ws, ws_bytes = _workspace(sdesc, n, dev, arena, "ws_sigma")
         L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw, gb,
                L.ptr(g_feat2), L.ptr(ws), C.c_int64(ws_bytes))
         g_feat.add_(g_feat2)
@@ -119,7 +147,7 @@ class _RenderKPlanes(Function):
                 gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
         L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         grads = [None if in_place else g for (g, in_place) in bufs]
-        return (None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def supports(renderer) -> bool:
@@ -135,5 +163,8 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
     planes = fm.plane_tensors()
     sig_p, rgb_p = sd.net.params(), cd.net.params()
     bg = renderer._bg(packed.device)
+    arena = None
+    if getattr(renderer, "reuse_buffers", False):
+        arena = renderer.__dict__.setdefault("_arena", Arena())
     return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
-                                len(sig_p), accumulate_into_grad, *planes, *sig_p, *rgb_p)
+                                len(sig_p), accumulate_into_grad, arena, *planes, *sig_p, *rgb_p)

@@ -288,8 +288,9 @@ class _PlaneRegulariser(Function):
     kernels per plane (models.py:115-121,165-181); the gradient is added by a 5-point-stencil pass."""
 
     @staticmethod
-    def forward(ctx: Any, w_tv: float, w_l1: float, *planes: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def forward(ctx: Any, w_tv: float, w_l1: float, accumulate: bool, *planes: torch.Tensor) -> torch.Tensor:  # type: ignore
         dev = planes[0].device
+        ctx.refs = planes if accumulate else None
         if not planes[0].is_cuda:
             raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
         n = len(planes)
@@ -314,12 +315,14 @@ class _PlaneRegulariser(Function):
         grads = []
         for i, p in enumerate(planes):
             _, Cc, H, W = p.shape
-            g = torch.zeros_like(p, memory_format=torch.channels_last)
+            ref = ctx.refs[i] if ctx.refs is not None else None
+            in_place = ref is not None and ref.grad is not None and ref.grad.stride() == p.stride()
+            g = ref.grad if in_place else torch.zeros_like(p, memory_format=torch.channels_last)
             cy, cx, cl1 = (float(v) for v in ctx.coef[i])
             L.call("tn_plane_reg_bwd", dev, L.ptr(_hwc(p)), C.c_int(H), C.c_int(W), C.c_int(Cc), C.c_float(cy), C.c_float(cx),
                    C.c_float(cl1), L.ptr(up), L.ptr(_hwc(g)))
-            grads.append(g)
-        return (None, None, *grads)
+            grads.append(None if in_place else g)
+        return (None, None, None, *grads)
 
 
 class KPlanesFeaturePlane(torch.nn.Module):
@@ -343,10 +346,10 @@ class KPlanesFeaturePlane(torch.nn.Module):
         return out.view([*x.size()[:-1], self.feature_dim])
 
     def loss_tv(self) -> torch.Tensor:
-        return _PlaneRegulariser.apply(1.0, 0.0, self.plane)
+        return _PlaneRegulariser.apply(1.0, 0.0, False, self.plane)
 
     def loss_l1(self) -> torch.Tensor:
-        return _PlaneRegulariser.apply(0.0, 1.0, self.plane)
+        return _PlaneRegulariser.apply(0.0, 1.0, False, self.plane)
 
 
 class KPlanesFeatureField(torch.nn.Module):
@@ -374,14 +377,15 @@ class KPlanesFeatureField(torch.nn.Module):
         return self.dropout(_KPlanesFeatures.apply(x, *self.plane_tensors()))
 
     def loss_tv(self) -> torch.Tensor:
-        return _PlaneRegulariser.apply(1.0, 0.0, *self.plane_tensors())
+        return _PlaneRegulariser.apply(1.0, 0.0, False, *self.plane_tensors())
 
     def loss_l1(self) -> torch.Tensor:
-        return _PlaneRegulariser.apply(0.0, 1.0, *self.plane_tensors())
+        return _PlaneRegulariser.apply(0.0, 1.0, False, *self.plane_tensors())
 
-    def regulariser(self, w_tv: float, w_l1: float) -> torch.Tensor:
-        """w_tv * loss_tv() + w_l1 * loss_l1() in one pass over the planes (run.py:254-256)."""
-        return _PlaneRegulariser.apply(float(w_tv), float(w_l1), *self.plane_tensors())
+    def regulariser(self, w_tv: float, w_l1: float, accumulate_into_grad: bool = False) -> torch.Tensor:
+        """w_tv * loss_tv() + w_l1 * loss_l1() in one pass over the planes (run.py:254-256).  With
+        ``accumulate_into_grad`` the backward adds straight into ``plane.grad`` (harness option)."""
+        return _PlaneRegulariser.apply(float(w_tv), float(w_l1), bool(accumulate_into_grad), *self.plane_tensors())
 
 
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):

@@ -98,6 +98,8 @@ class Trainer:
         for p in params:                                # grads keep the parameter's (channels_last) layout
             p.grad = torch.zeros_like(p)
         self.renderer.accumulate_into_grad = True       # fused path adds into these buffers directly
+        self.renderer.reuse_buffers = True              # and keeps its scratch in a capacity-based arena
+        self._arena: Dict[str, torch.Tensor] = {}
         # torch.optim.Adam's update (run.py:186), one kernel pass per tensor, gradients zeroed in the same pass
         self.optimizer = FusedAdam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
@@ -111,6 +113,17 @@ class Trainer:
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
         self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
         self.last: Dict[str, float] = {}
+
+    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
+        """capacity-based scratch (see fused.Arena): sizes drift by a few percent per step"""
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        t = self._arena.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=self.device)
+            self._arena[name] = t
+        return t[:numel].view(*shape)
 
     # ------------------------------------------------------------------ a8: dynamic batch
     @torch.no_grad()
@@ -130,9 +143,9 @@ class Trainer:
             desc = rp._desc(dev, not cfg.deterministic, None)
             desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
             R_all = n_b * B
-            maskbits = torch.empty((R_all, n_chunks), dtype=torch.int64, device=dev)
-            counts = torch.empty(R_all, dtype=torch.int32, device=dev)
-            plan = torch.empty(4, dtype=torch.int32, device=dev)
+            maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
+            counts = self._buf("counts", (R_all,), torch.int32)
+            plan = self._buf("plan", (4,), torch.int32)
             L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
             L.call("tn_batch_plan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan))
             k, n, R, tripped = plan.tolist()           # the step's single host read-back
@@ -141,10 +154,10 @@ class Trainer:
             self._k_guess = n_b * 2                      # not enough rays drawn: redraw a larger block
         self._k_guess = k
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
-        info = torch.empty((R, 2), dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int32, device=dev)
+        info = self._buf("info", (R, 2), torch.int32)
+        total = self._buf("total", (1,), torch.int32)
         L.call("tn_sample_scan", dev, L.ptr(counts), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
-        packed = torch.empty((n, 7), device=dev)
+        packed = self._buf("packed", (n, 7), torch.float32)
         L.call("tn_sample_pack", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(info),
                C.c_void_p(None), L.ptr(packed), C.c_void_p(None), C.c_int64(n))
         return packed, info, self.rgbs[idx[:R]], k
@@ -167,7 +180,7 @@ class Trainer:
         rendered = self.renderer(packed, info)                                    # run.py:251
         loss = self.global_mse(rendered, target)
         if cfg.method == "kplanes":                                               # run.py:254-256
-            reg = self.renderer.feature_module.regulariser(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
+            reg = self.renderer.feature_module.regulariser(self.tv_reg_alpha, self.l1_reg_alpha, True)   # type: ignore
             loss = loss + reg / self.world
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
         (loss * cfg.grad_scale).backward()                                        # scaled, never unscaled (quirk)

@@ -287,15 +287,26 @@ __device__ __forceinline__ void decode_tile(const WgradArgs &a, int id, int &l, 
     l = NH; tn_ = 0; tk = id;
 }
 
-// NW waves per workgroup, each owning MAXS accumulator tiles (tile id = wave + NW*m): more, lighter waves
-// hide the HBM latency of the operand loads better than 8 heavy ones (0.97 -> see profiles/)
-template <int H, int NH, int MAXS, int NW>
+// The workgroup (NW waves) stages one 32-sample tile of the workspace (all rows, plus the x rows of the tile) in
+// LDS, so every byte is read from HBM exactly once (PMC: reading operands straight from global re-fetched each
+// row ~2x), then each wave runs the MFMA tiles it owns (tile id = wave + NW*m) from LDS.  The next tile is
+// prefetched into registers while the current one is being multiplied (issue early / write late).
+constexpr int RS = 36;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128 across 16 lanes
+
+template <int H, int NH, int MAXS, int NW, int NCH>
 __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
-                                                        int64_t n, const float *__restrict__ stash)
+                                                            int64_t n, const float *__restrict__ stash)
 {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int64_t n_tiles = (n + 31) >> 5;
+    const int xs = x_slots(a.enc, a.in_dim);
+    const int R = stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad));
+    const int row_chunks = R * 8;                         // float4 chunks of the workspace tile
+    const int x_chunks = xs > 0 ? (32 * a.in_dim) / 4 : 0;   // float4 chunks of the x rows of the tile (contiguous)
+    float *ldsR = lds;
+    float *ldsX = lds + R * RS;
     f32x16 acc[MAXS];
     float dbacc[MAXS];
     int tl[MAXS], ttn[MAXS], ttk[MAXS];
@@ -308,56 +319,74 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
         const int id = wave + NW * m;
         if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
     }
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int xs = x_slots(a.enc, a.in_dim);
-        const float *st = stash + tile * (int64_t)(stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad)) * 32);
-        const float *stE = st + (2 * NH * H + 4) * 32;
+    f32x4 pre[NCH];
+    auto prefetch = [&](int64_t tile) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)R * 32);
+        const int64_t x0 = tile * 32 * (int64_t)a.in_dim;          // first float of the tile's x rows
+        const int64_t xend = n * (int64_t)a.in_dim;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < row_chunks) v = src[c];
+            else if (c < row_chunks + x_chunks) {
+                const int64_t e = x0 + 4 * (int64_t)(c - row_chunks);
+                if (e + 3 < xend) v = *reinterpret_cast<const f32x4 *>(x + e);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = e + u < xend ? x[e + u] : 0.0f;
+                }
+            }
+            pre[k] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            if (c < row_chunks) *reinterpret_cast<f32x4 *>(ldsR + (c >> 3) * RS + (c & 7) * 4) = pre[k];
+            else if (c < row_chunks + x_chunks) *reinterpret_cast<f32x4 *>(ldsX + 4 * (c - row_chunks)) = pre[k];
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) prefetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                   // everyone finished reading the previous tile
+        commit();
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);      // in flight during the MFMAs below
+        const float *rowsE = ldsR + (2 * NH * H + 4) * RS;
 #pragma unroll
         for (int m = 0; m < MAXS; ++m) {
             const int l = tl[m];
             if (l < 0) continue;
-            // ---- G operand: 16 samples of row (32 tn + i) ----
-            f32x4 gv[4];
-            if (l < NH) {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + ((NH + l) * H + 32 * ttn[m] + i) * 32 + 16 * h);
+            f32x4 gv[4], av[4];
+            {
+                const int grow = l < NH ? (NH + l) * H + 32 * ttn[m] + i : 2 * NH * H + (i < 4 ? i : 0);
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(ldsR + grow * RS + 16 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gv[e] = p[e];
-            } else {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + (2 * NH * H + (i < 4 ? i : 0)) * 32 + 16 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gv[e] = i < 4 ? p[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; gv[e] = (l < NH || i < 4) ? v : f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            // ---- A operand ----
-            f32x4 av[4];
             if (l == 0) {
-                // first-layer input, slot q = 32 tk + i: plain x columns are read straight from x (all 16 loads
-                // unconditional on clamped rows so they are issued back to back), encoded slots from the E rows
                 const int q0 = 32 * ttk[m], q = q0 + i;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (q0 < xs) {                                     // wave-uniform: this tile holds x columns
+                if (q0 < xs) {                                     // wave-uniform: x columns (sample-major rows in LDS)
                     const int qx = q < xs ? q : 0;
-                    const int64_t r0 = tile * 32 + 16 * h;
-                    float xv[16];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const int64_t rc = r0 + t < n ? r0 + t : n - 1;
-                        xv[t] = x[rc * a.in_dim + qx];
+                        const float v = ldsX[(16 * h + t) * a.in_dim + qx];
+                        av[t >> 2][t & 3] = q < xs ? v : 0.0f;
                     }
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = (q < xs && r0 + t < n) ? xv[t] : 0.0f;
                 }
-                if (a.enc != TN_ENC_NONE && q0 + 31 >= xs) {       // wave-uniform: this tile holds encoded slots
-                    const int qe = (q >= xs && q < a.K0_pad) ? q - xs : 0;
-                    const f32x4 *p = reinterpret_cast<const f32x4 *>(stE + qe * 32 + 16 * h);
+                if (a.enc != TN_ENC_NONE && q0 + 31 >= xs) {       // wave-uniform: encoded slots (E rows)
+                    const bool ise = q >= xs && q < a.K0_pad;
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(rowsE + (ise ? q - xs : 0) * RS + 16 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 v = p[e];
-                        if (q >= xs && q < a.K0_pad) av[e] = v;
-                    }
+                    for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; if (ise) av[e] = v; }
                 }
             } else {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + ((l - 1) * H + 32 * ttk[m] + i) * 32 + 16 * h);
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(ldsR + ((l - 1) * H + 32 * ttk[m] + i) * RS + 16 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = p[e];
             }
@@ -366,10 +395,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[e][u], av[e][u], acc[m]);
             if (ttk[m] == 0) {
-                float s = 0.f;
+                float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s += (gv[e][0] + gv[e][1]) + (gv[e][2] + gv[e][3]);
-                dbacc[m] += s;
+                for (int e = 0; e < 4; ++e) sum += (gv[e][0] + gv[e][1]) + (gv[e][2] + gv[e][3]);
+                dbacc[m] += sum;
             }
         }
     }
@@ -389,10 +418,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
             if (kok && nn < Nl) atomicAdd(&a.gW[l][(int64_t)nn * Kl + kc], acc[m][r]);
         }
         if (ttk[m] == 0) {
-            float s = dbacc[m];
-            s += __shfl_xor(s, 32, 64);
+            float sum = dbacc[m];
+            sum += __shfl_xor(sum, 32, 64);
             const int nn = 32 * ttn[m] + i;
-            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], s);
+            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], sum);
         }
     }
 }
@@ -407,8 +436,16 @@ bool v2_supported(const tn_mlp_desc *d) {
     if (H != 32 && H != 64) return false;
     for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
     if (d->dims[L] > 4) return false;
-    const int T = H / 32, Tk0 = (((d->dims[0] + 7) & ~7) + 31) / 32;
-    if (T * Tk0 + (L - 2) * T * T + T > 48) return false;        // 16 waves x 3 accumulator tiles
+    const int K0_pad = (d->dims[0] + 7) & ~7;
+    const int T = H / 32, Tk0 = (K0_pad + 31) / 32;
+    const int tiles = T * Tk0 + (L - 2) * T * T + T;
+    if (tiles > 48) return false;                                 // 16 waves x 3 accumulator tiles
+    const int xs = x_slots(d->encoding, d->in_dim);
+    if (xs > 0 && (d->in_dim & 3)) return false;
+    const int R = 2 * (L - 1) * H + 4 + extra_rows(d->encoding, d->in_dim, K0_pad);
+    const int chunks = R * 8 + (xs > 0 ? 8 * d->in_dim : 0);
+    if (chunks > 10 * 1024) return false;                         // prefetch registers of the wgrad kernel
+    if (((size_t)R * 36 + (xs > 0 ? 32 * (size_t)d->in_dim : 0)) * 4 > 160 * 1024) return false;
     return true;
 }
 
@@ -449,11 +486,26 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     w.Tk0 = (a.K0_pad + 31) / 32;
     w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
     for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
-    const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
-    if (w.total_tiles <= 8) mlp_wgrad_kernel<H, NH, 1, 8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, aux, n, stash);
-    else if (w.total_tiles <= 16) mlp_wgrad_kernel<H, NH, 1, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
-    else if (w.total_tiles <= 32) mlp_wgrad_kernel<H, NH, 2, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
-    else mlp_wgrad_kernel<H, NH, 3, 16><<<dim3((unsigned)wblocks), dim3(1024), 0, s>>>(w, x, aux, n, stash);
+    const int R = stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad));
+    const int xs = x_slots(a.enc, a.in_dim);
+    const size_t wlds = ((size_t)R * RS + (xs > 0 ? 32 * (size_t)a.in_dim : 0)) * 4;
+    if (wlds > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: workspace tile does not fit LDS");
+    if (xs > 0 && (a.in_dim & 3)) return tn::fail(TN_E_CONFIG, "mlp_bwd: in_dim must be a multiple of 4");
+    const int chunks = R * 8 + (xs > 0 ? 8 * a.in_dim : 0);
+    const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * (wlds * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
+#define TN_WGRAD(MAXS_, NW_, NCH_)                                                                                         \
+    do {                                                                                                                    \
+        auto wk = mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_>;                                                                \
+        hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);      \
+        if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", wlds, hipGetErrorString(we)); return (int)we; } \
+        wk<<<dim3((unsigned)wblocks), dim3(NW_ * 64), wlds, s>>>(w, x, aux, n, stash);                                      \
+    } while (0)
+    if (w.total_tiles <= 8 && chunks <= 4 * 512) TN_WGRAD(1, 8, 4);
+    else if (w.total_tiles <= 16 && chunks <= 4 * 1024) TN_WGRAD(1, 16, 4);
+    else if (w.total_tiles <= 32 && chunks <= 6 * 1024) TN_WGRAD(2, 16, 6);
+    else if (w.total_tiles <= 48 && chunks <= 10 * 1024) TN_WGRAD(3, 16, 10);
+    else return tn::fail(TN_E_CONFIG, "mlp_bwd: configuration outside the wgrad tiling");
+#undef TN_WGRAD
     return tn::check_launch("mlp_wgrad_kernel");
 }
 

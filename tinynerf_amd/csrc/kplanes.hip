@@ -117,10 +117,16 @@ __global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const flo
                     tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
                     tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
                 }
-                // run boundaries: sample j closes a run when the next sample falls into another cell
+                // run boundaries: sample j closes a run when the next sample falls into another cell.  When the next
+                // cell is a 4-neighbour, two of the four texels are shared with it: instead of flushing them, their
+                // partial sums are carried into the next run (x moves: within the half-wave; y moves: across halves).
                 const int cell = valid ? t[p].cell : -1 - j;
                 const int next_cell = __shfl_down(cell, 1, 64);
-                const unsigned run_end = (unsigned)__ballot(j == 31 || next_cell != cell);    // low 32 bits: half 0 == half 1
+                const int dcell = (j < 31) ? next_cell - cell : 0x40000000;
+                const int rowlen = a.W[s] + 4;
+                const unsigned run_end = (unsigned)__ballot(dcell != 0);                       // low 32 bits: half 0 == half 1
+                const unsigned mv_xp = (unsigned)__ballot(dcell == 1), mv_xm = (unsigned)__ballot(dcell == -1);
+                const unsigned mv_yp = (unsigned)__ballot(dcell == rowlen), mv_ym = (unsigned)__ballot(dcell == -rowlen);
                 asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
                 // ---- phase B: lane = (tap pair h, channel c) ----
                 const int c = j;                       // channel
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const flo
                     float gv[32];
 #pragma unroll
                     for (int sI = 0; sI < 32; ++sI) gv[sI] = tileG[sI * GS + c];
-                    float a0 = 0.0f, a1 = 0.0f;
+                    float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
 #pragma unroll
                     for (int s4 = 0; s4 < 8; ++s4) {
                         const f32x4k w0 = W0[s4], w1 = W1[s4];
@@ -141,11 +147,33 @@ __global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const flo
                             const int sI = 4 * s4 + u;
                             a0 = fmaf(gv[sI], w0[u], a0);
                             a1 = fmaf(gv[sI], w1[u], a1);
-                            if ((run_end >> sI) & 1u) {          // wave-uniform
+                            if ((run_end >> sI) & 1u) {          // wave-uniform (scalar) control flow from here on
                                 const int o0 = O0[sI], o1 = O1[sI];
-                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
-                                a0 = 0.0f; a1 = 0.0f;
+                                if ((mv_xp >> sI) & 1u) {        // next cell = x+1: right texel becomes the left one
+                                    if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                    a0 = a1; a1 = 0.0f;
+                                } else if ((mv_xm >> sI) & 1u) { // next cell = x-1
+                                    if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                    a1 = a0; a0 = 0.0f;
+                                } else if ((mv_yp >> sI) & 1u) { // next cell = y+1: the lower row (half 1) becomes the upper row
+                                    const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
+                                    if (h == 0) {
+                                        if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                        if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                    }
+                                    a0 = h == 0 ? t0 : 0.0f; a1 = h == 0 ? t1 : 0.0f;
+                                } else if ((mv_ym >> sI) & 1u) { // next cell = y-1
+                                    const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
+                                    if (h == 1) {
+                                        if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                        if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                    }
+                                    a0 = h == 1 ? t0 : 0.0f; a1 = h == 1 ? t1 : 0.0f;
+                                } else {
+                                    if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                    if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                    a0 = 0.0f; a1 = 0.0f;
+                                }
                             }
                         }
                     }

@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views", type=int, default=20, help="synthetic 800x800 cameras (640k rays each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 16)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     return ap.parse_args()
 
 
@@ -110,17 +110,22 @@ def cpu_baseline(trainer, n_target: int):
     packed, info, target = packed[:n].cpu(), info[:R].cpu(), target[:R].cpu()
     sd = {k: v.detach().cpu().contiguous() for k, v in trainer.renderer.state_dict().items()}
     bg = trainer.renderer.bg_color.cpu() if trainer.renderer.bg_color is not None else None
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        tp.grads_of(sd, lambda p: tp.training_loss(p, packed, info, target, bg))
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]
+    # torch's CPU kernels stop scaling well before all hardware threads of the GPU box's host (256 threads ran
+    # 140x slower than 32 on the same input): time 32 and 64 threads and report the better one
+    best, cores = None, 1
+    for threads in sorted({min(32, os.cpu_count() or 1), min(64, os.cpu_count() or 1)}):
+        torch.set_num_threads(threads)
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            tp.grads_of(sd, lambda p: tp.training_loss(p, packed, info, target, bg))
+            times.append(time.perf_counter() - t0)
+        t = min(times[1:])
+        if best is None or t < best:
+            best, cores = t, threads
     return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"render fwd+loss+bwd of {n} packed samples / {R} rays of the same batch (no Adam step), "
-                      f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, best of 2 after warm-up"}
+                      f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, {cores} threads (best of 32/64), best of 2 after warm-up"}
 
 
 def main():

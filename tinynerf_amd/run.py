@@ -243,3 +243,74 @@ class Trainer:
             samples, info = self.ray_provider(rays_o[k:k + bs], rays_d[k:k + bs], training=False)
             out.append(self.renderer(samples, info))
         return torch.cat(out, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# train() counterpart (run.py:97-319): loop, periodic eval, final test render, metrics_*.json, model.pt
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class EvalMetrics:
+    mse_loss: float = 0.
+    psnr: float = 0.
+    ssim: float = 0.          # never computed by the reference either (run.py:56-60)
+
+
+@torch.no_grad()
+def infer(trainer: "Trainer", dataset, indices: List[int], folder=None, name: str = "render", batch_size: Optional[int] = None):
+    """Render whole images (run.py:15-50); PNGs are written when `folder` is given."""
+    out = []
+    for i in indices:
+        item = dataset[i]
+        o, d = item["rays_o"].reshape(-1, 3).to(trainer.device), item["rays_d"].reshape(-1, 3).to(trainer.device)
+        img = trainer.render_rays(o, d, batch_size).reshape(*item["rays_o"].shape[:-1], 3)
+        out.append(img)
+        if folder is not None:
+            from PIL import Image
+            Image.fromarray((255. * img).clamp(0, 255).to(torch.uint8).cpu().numpy()).save(folder / f"{name}_{i:04d}.png")
+    return out
+
+
+def evaluate(dataset, rendered: List[torch.Tensor], indices: List[int]) -> List[EvalMetrics]:
+    """run.py:62-76."""
+    res = []
+    for i, img in zip(indices, rendered):
+        true = dataset[i]["rgbs"].to(img.device)
+        res.append(EvalMetrics(mse_loss=torch.nn.functional.mse_loss(true, img).item(), psnr=psnr(true, img).item()))
+    return res
+
+
+def train(cfg: TrainConfig, train_rays, eval_set=None, test_set=None, output=None, eval_every: Optional[int] = None,
+          eval_n: int = 1, max_steps: Optional[int] = None, device: Optional[torch.device] = None, log_every: int = 100):
+    """The reference's train() on the HIP path.  `train_rays` is a data.RaysDataset on the device."""
+    import json
+    from dataclasses import asdict
+    device = device or train_rays.rays_o.device
+    cfg.scene_scale = getattr(train_rays, "scene_scale", cfg.scene_scale)
+    tr = Trainer(cfg, train_rays.rays_o, train_rays.rays_d, train_rays.rgbs,
+                 None if train_rays.bg_color is None else train_rays.bg_color.to(device), device)
+    n_steps = tr.steps if max_steps is None else min(tr.steps, max_steps)
+    train_metrics, eval_metrics, eval_step = [], [], 0
+    for step in range(n_steps + 1):                       # the reference runs steps+1 iterations (run.py:290)
+        tr.step()
+        if step % log_every == 0 or step == n_steps:
+            train_metrics.append({"step": step, "loss": tr.loss_value(), "occupancy": tr.occupancy_grid.occupancy()})
+            print(f"step {step}/{n_steps} loss {train_metrics[-1]['loss']:.5f} occupancy {train_metrics[-1]['occupancy']:.3f} "
+                  f"samples {int(tr.last['n_samples'])}")
+        if eval_every and eval_set is not None and step % eval_every == 0 and step > 0:
+            idx = list(range(eval_step, min(eval_step + eval_n, len(eval_set))))
+            eval_metrics.extend(asdict(m) for m in evaluate(eval_set, infer(tr, eval_set, idx, output, f"test_{step}"), idx))
+            eval_step += eval_n
+    test_metrics = None
+    if test_set is not None:
+        idx = list(range(len(test_set)))
+        rendered = infer(tr, test_set, idx, output, "test_full")
+        if test_set.rgbs:
+            test_metrics = [asdict(m) for m in evaluate(test_set, rendered, idx)]
+    if output is not None:
+        torch.save(tr.renderer.state_dict(), output / "model.pt")            # run.py:308
+        json.dump(train_metrics, open(output / "metrics_train.json", "w"))
+        if eval_metrics:
+            json.dump(eval_metrics, open(output / "metrics_eval.json", "w"))
+        if test_metrics:
+            json.dump(test_metrics, open(output / "metrics_test.json", "w"))
+    return tr, train_metrics, eval_metrics, test_metrics

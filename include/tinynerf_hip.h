@@ -221,6 +221,29 @@ int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float cy, float cx
                      const float *upstream, float *grad, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a20  Cobafa factorised field                                  (reference models.py:209-266)
+ * feat[n, off_i + c] = trilinear(basis_i, saw_i(x))[c] * trilinear(coef, x)[i],
+ * saw_i(x) = 2*((f_i*x) mod 1) - 1 (models.py:213), levels concatenated (models.py:263-265).
+ * f_i <= 0 selects saw_i(x) = x: with a 1x1x1 coefficient grid holding 1 this is the plain trilinear
+ * lookup of CobafaGrid.forward (models.py:223-232).
+ * Grids are channel-last [D,H,W,C] (torch channels_last_3d of the reference's [1,C,D,H,W]).
+ * ------------------------------------------------------------------------------------------ */
+#define TN_COBAFA_MAX_LEVELS 8
+typedef struct tn_cobafa_desc {
+    int32_t n_levels;
+    int32_t coef_res[3];                           /* D,H,W of the coefficient grid (C = n_levels) */
+    int32_t res[TN_COBAFA_MAX_LEVELS][3];          /* D,H,W of basis grid i                        */
+    int32_t channels[TN_COBAFA_MAX_LEVELS];        /* <= 8                                         */
+    float freqs[TN_COBAFA_MAX_LEVELS];
+    const float *coef;                             /* [D,H,W,n_levels]                             */
+    const float *basis[TN_COBAFA_MAX_LEVELS];      /* [D,H,W,channels[i]]                          */
+} tn_cobafa_desc;
+int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t n, float *feat, void *stream);
+/* grad_coef / grad_basis[i]: same layouts as the grids, += with fp32 atomics (caller initialises) */
+int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
+                  float *const *grad_basis, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * optimizer step of the harness                        (reference run.py:186,258-260: torch.optim.Adam)
  * One pass per parameter tensor: g' = g + wd*p (coupled L2, as torch), m = b1 m + (1-b1) g',
  * v = b2 v + (1-b2) g'^2, p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); optionally zeroes g for the

@@ -386,6 +386,17 @@ def trilinear_channels(grid: np.ndarray, coords: np.ndarray) -> np.ndarray:
     return np.stack([trilinear_zeros_align(g[c], coords) for c in range(g.shape[0])], -1)
 
 
+def cobafa_gather(x, basis_grids, coef_grid, freqs):
+    """reference models.py:259-265: the concatenated basis x coefficient features, before dropout + MLP."""
+    x = np.asarray(x, f32)
+    coefs = trilinear_channels(np.asarray(coef_grid, f32)[0], x)
+    feats = []
+    for i, (fr, bg) in enumerate(zip(freqs, basis_grids)):
+        saw = (f32(2) * np.mod((f32(fr) * x).astype(f32), f32(1)) - f32(1)).astype(f32)   # models.py:213
+        feats.append(trilinear_channels(np.asarray(bg, f32)[0], saw) * coefs[:, [i]])
+    return np.concatenate(feats, -1).astype(f32)
+
+
 def cobafa_features(x, basis_grids, coef_grid, freqs, mlp):
     """reference models.py:257-266 in eval mode (Dropout(0.01) inactive)."""
     x = np.asarray(x, f32)

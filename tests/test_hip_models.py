@@ -165,13 +165,72 @@ def test_kplanes_full_resolution_vs_oracle():
 
 
 def test_cobafa_forward():
+    """tn_cobafa_fwd against the reference's own output (G11): HIP gathers -> oracle MLP (the golden's MLP is 16
+    wide, below the MFMA kernel's 32) must reproduce the captured features; and against the oracle's gathers."""
     m = models()
     g = load_golden("G11_cobafa")
-    cf = m.CobafaFeatureField(basis_res=[4, 5, 6], coef_res=4, freqs=[float(f) for f in g["freqs"]], channels=[2, 2, 2], mlp_hidden_dim=16 * 2)
-    # golden was captured with hidden 16; the kernel's minimum width is 32 -> shape-only check here, values via the MLP tests
+    sd = {k: np.asarray(v) for k, v in sub(g, "sd.").items()}
+    freqs = [float(f) for f in g["freqs"]]
+    cf = m.CobafaFeatureField(basis_res=[4, 5, 6], coef_res=4, freqs=freqs, channels=[2, 2, 2], mlp_hidden_dim=32)
+    with torch.no_grad():
+        for i in range(3):
+            cf.basis_grids[i].grid.copy_(torch.from_numpy(sd[f"basis_grids.{i}.grid"]))
+        cf.coef_grid.grid.copy_(torch.from_numpy(sd["coef_grid.grid"]))
     cf.to(DEV).eval()
+    assert cf.coef_grid.grid.is_contiguous(memory_format=torch.channels_last_3d)
+    with torch.no_grad():
+        gathered = cf.features(cu(g["x"])).cpu().numpy()
+    basis = [sd[f"basis_grids.{i}.grid"] for i in range(3)]
+    np.testing.assert_allclose(gathered, orc.cobafa_gather(g["x"], basis, sd["coef_grid.grid"], freqs), rtol=0, atol=TOL)
+    np.testing.assert_allclose(orc.mlp_forward(gathered, orc.mlp_layers(sd, "mlp.net.")), g["feat"], rtol=0, atol=TOL)
     out = cf(cu(g["x"]))
     assert out.shape == (128, 32)
+
+
+def test_cobafa_default_config_against_grid_sample():
+    """run.py:176-181's Cobafa configuration (6 levels, 36 features): forward and every grid gradient against ATen's
+    CPU grid_sampler_3d (what the reference runs), points partly outside [-1,1] (zeros padding)."""
+    m = models()
+    torch.manual_seed(3)
+    res, ch, freqs = [32, 51, 70, 89, 108, 128], [8, 8, 8, 4, 4, 4], [2., 3.2, 4.4, 5.6, 6.8, 8.]
+    cf = m.CobafaFeatureField(basis_res=res, coef_res=64, freqs=freqs, channels=ch, mlp_hidden_dim=128).to(DEV)
+    x = (torch.rand(20000, 3, device=DEV) * 2.4 - 1.2)
+    feat = cf.features(x)
+    gfeat = torch.randn_like(feat)
+    (feat * gfeat).sum().backward()
+    got = {n: p.grad.clone() for n, p in cf.named_parameters() if p.grad is not None}
+
+    def lookup(grid, pts):
+        return torch.nn.functional.grid_sample(grid, pts.view(1, -1, 1, 1, 3), align_corners=True).view(grid.size(1), -1).t()
+
+    leaves = {n: p.detach().cpu().contiguous().clone().requires_grad_(True) for n, p in cf.named_parameters() if "grid" in n}
+    xc = x.cpu()
+    coefs = lookup(leaves["coef_grid.grid"], xc)
+    ref = torch.cat([lookup(leaves[f"basis_grids.{i}.grid"], 2. * ((f * xc) % 1.) - 1.) * coefs[:, [i]] for i, f in enumerate(freqs)], -1)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=TOL)
+    (ref * gfeat.cpu()).sum().backward()
+    for n, leaf in leaves.items():
+        r = leaf.grad.cpu().numpy()
+        np.testing.assert_allclose(got[n].cpu().numpy(), r, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(r).max()), err_msg=n)
+    # single-grid module
+    y = cf.coef_grid(x[:64])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), lookup(leaves["coef_grid.grid"], xc[:64]).detach().numpy(), rtol=0, atol=TOL)
+    # empty input
+    assert cf.features(x[:0]).shape == (0, 36)
+
+
+def test_cobafa_renderer_trains():
+    """method == cobafa (run.py:176-181) through build_renderer: optimisation steps run and the loss moves down."""
+    from tinynerf_amd import rays
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb, K, cams = rays.synthetic_scene(n_views=2, res=48, seed=3, device="cpu")
+    cfg = TrainConfig(method="cobafa", batch_size=256, n_samples=64, occupancy_res=32, deterministic=True)
+    tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+    losses = []
+    for _ in range(6):
+        tr.step()
+        losses.append(tr.loss_value())
+    assert all(np.isfinite(l) for l in losses) and min(losses[1:]) < losses[0], losses
 
 
 def _grads(module):

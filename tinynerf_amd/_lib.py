@@ -51,6 +51,17 @@ class KPlanesDesc(C.Structure):
     ]
 
 
+TN_COBAFA_MAX_LEVELS = 8
+
+
+class CobafaDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int32), ("coef_res", C.c_int32 * 3), ("res", (C.c_int32 * 3) * TN_COBAFA_MAX_LEVELS),
+        ("channels", C.c_int32 * TN_COBAFA_MAX_LEVELS), ("freqs", C.c_float * TN_COBAFA_MAX_LEVELS),
+        ("coef", C.c_void_p), ("basis", C.c_void_p * TN_COBAFA_MAX_LEVELS),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 

@@ -32,6 +32,7 @@ SOURCES = {
     "sampler.hip": STRICT,
     "planes_reg.hip": FAST,
     "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
+    "cobafa.hip": STRICT + ["-munsafe-fp-atomics"],   # sawtooth warp x (res-1): an fma in f*x - floor moves taps
     "mlp.hip": FAST,
     "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],

@@ -416,48 +416,111 @@ class KPlanesExplicitColorDecoder(torch.nn.Module):
 
 
 # --------------------------------------------------------------------------------------------
-# CoBaFa (models.py:209-266) -- API-compatible; grids sampled by torch on the device, the
-# 128-wide MLP by the fused kernel.  Fused Cobafa gathers are SURVEY 8(f)-3 (next).
+# CoBaFa (models.py:209-266): coefficient grid x sawtooth-warped basis grids -> 128-wide MLP.
+# All 7 trilinear lookups, the products and the concat are one launch (tn_cobafa_fwd / _bwd); the
+# grids are channels_last_3d parameters with the reference's [1,C,D,H,W] logical shape.
 # --------------------------------------------------------------------------------------------
+def _dhwc(grid: torch.Tensor) -> torch.Tensor:
+    """[1,C,D,H,W] channels_last_3d parameter -> the [D,H,W,C] memory the kernels index (no copy)."""
+    g = grid if grid.is_contiguous(memory_format=torch.channels_last_3d) else grid.contiguous(memory_format=torch.channels_last_3d)
+    return g.permute(0, 2, 3, 4, 1)
+
+
+def _cobafa_desc(coef: torch.Tensor, basis: Sequence[torch.Tensor], freqs: Sequence[float]) -> Tuple[L.CobafaDesc, list]:
+    d = L.CobafaDesc()
+    n = len(basis)
+    if n > L.TN_COBAFA_MAX_LEVELS or coef.size(1) != n:
+        raise ValueError(f"Cobafa: {n} basis grids need a {n}-channel coefficient grid (max {L.TN_COBAFA_MAX_LEVELS})")
+    keep = [_dhwc(coef)]
+    d.n_levels = n
+    d.coef = keep[0].data_ptr()
+    for c in range(3):
+        d.coef_res[c] = coef.size(2 + c)
+    for i, (b, f) in enumerate(zip(basis, freqs)):
+        v = _dhwc(b)
+        keep.append(v)
+        d.basis[i] = v.data_ptr()
+        d.channels[i] = b.size(1)
+        d.freqs[i] = float(f)
+        for c in range(3):
+            d.res[i][c] = b.size(2 + c)
+    return d, keep
+
+
+class _CobafaFeatures(Function):
+    @staticmethod
+    def forward(ctx: Any, x: torch.Tensor, freqs: Tuple[float, ...], coef: torch.Tensor, *basis: torch.Tensor) -> torch.Tensor:  # type: ignore
+        x = x.contiguous()
+        dev = L.require_cuda(x)
+        if not all(g.is_cuda for g in (coef, *basis)):
+            raise RuntimeError("tinynerf_amd: Cobafa grids must be CUDA (HIP) tensors -- there is no CPU path")
+        desc, keep = _cobafa_desc(coef, basis, freqs)
+        feat = torch.empty((x.size(0), sum(b.size(1) for b in basis)), device=dev)
+        L.call("tn_cobafa_fwd", dev, C.byref(desc), L.ptr(x), C.c_int64(x.size(0)), L.ptr(feat))
+        ctx.save_for_backward(x, coef, *basis)
+        ctx.freqs = freqs
+        return feat
+
+    @staticmethod
+    def backward(ctx: Any, g: torch.Tensor):  # type: ignore
+        x, coef, *basis = ctx.saved_tensors
+        desc, keep = _cobafa_desc(coef, basis, ctx.freqs)
+        g_coef = torch.zeros_like(coef, memory_format=torch.channels_last_3d)
+        g_basis = [torch.zeros_like(b, memory_format=torch.channels_last_3d) for b in basis]
+        gb = (C.c_void_p * len(basis))(*[_dhwc(t).data_ptr() for t in g_basis])
+        L.call("tn_cobafa_bwd", x.device, C.byref(desc), L.ptr(x), C.c_int64(x.size(0)), L.ptr(g.contiguous()),
+               L.ptr(_dhwc(g_coef)), gb)
+        return (None, None, g_coef, *g_basis)
+
+
 class SawtoothEncoding(torch.nn.Module):
+    """models.py:209-215.  Inside CobafaFeatureField the warp happens in the gather kernel; the module itself
+    is only evaluated when called on its own."""
+
     def __init__(self, f):
         super().__init__()
         self.f = f
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return 2. * ((self.f * x) % 1.) - 1.
+        return 2. * torch.remainder(self.f * x, 1.) - 1.
 
 
 class CobafaGrid(torch.nn.Module):
+    """models.py:217-232: a dense [1,C,D,H,W] feature grid with trilinear lookup."""
+
     def __init__(self, res: int | Tuple[int, int, int], feature_dim: int, init: Callable = torch.nn.init.uniform_):
         super().__init__()
-        resolution = (res, res, res) if isinstance(res, int) else res
-        self.grid = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution))
+        resolution = (res, res, res) if isinstance(res, int) else tuple(res)
+        if feature_dim > 8:
+            raise ValueError("CobafaGrid: the gather kernel holds at most 8 channels per voxel")
+        self.grid = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution).contiguous(memory_format=torch.channels_last_3d))
         self.feature_dim = feature_dim
         init(self.grid)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        new_shape = [*x.size()[:-1], self.feature_dim]
-        output = torch.nn.functional.grid_sample(self.grid, x.view(1, -1, 1, 1, 3), align_corners=True)
-        return output.view(self.feature_dim, -1).transpose(0, 1).contiguous().view(new_shape)
+        one = torch.ones((1, 1, 1, 1, 1), device=x.device)
+        out = _CobafaFeatures.apply(x.reshape(-1, 3), (0.0,), one, self.grid)
+        return out.view(*x.size()[:-1], self.feature_dim)
 
 
 class CobafaFeatureField(torch.nn.Module):
+    """models.py:234-266."""
+
     def __init__(self, basis_res: List[int | Tuple[int, int, int]], coef_res: int | Tuple[int, int, int],
                  freqs: List[float], channels: List[int], mlp_hidden_dim: int):
         super().__init__()
-        assert len(basis_res) == len(freqs) == len(channels)
-        n = len(basis_res)
-        self.basis_grids = torch.nn.ModuleList([CobafaGrid(res, c) for res, c in zip(basis_res, channels)])
+        if not (len(basis_res) == len(freqs) == len(channels)):
+            raise ValueError("Cobafa: basis_res, freqs and channels must have one entry per level")
+        self.freqs = tuple(float(f) for f in freqs)
+        self.basis_grids = torch.nn.ModuleList([CobafaGrid(r, c) for r, c in zip(basis_res, channels)])
         self.encoders = torch.nn.ModuleList([SawtoothEncoding(f) for f in freqs])
-        self.coef_grid = CobafaGrid(coef_res, n)
+        self.coef_grid = CobafaGrid(coef_res, len(basis_res))
         self.dropout = torch.nn.Dropout(0.01)
         self.mlp = MLP(sum(channels), mlp_hidden_dim, 5)
         self.feature_dim = mlp_hidden_dim
 
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        return _CobafaFeatures.apply(x.reshape(-1, 3), self.freqs, self.coef_grid.grid, *[b.grid for b in self.basis_grids])
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        coefs = self.coef_grid(x)
-        features = []
-        for i, (encoder, basis) in enumerate(zip(self.encoders, self.basis_grids)):
-            features.append(basis(encoder(x)) * coefs[:, [i]])
-        return self.mlp(self.dropout(torch.cat(features, -1)))
+        return self.mlp(self.dropout(self.features(x)))

@@ -38,7 +38,8 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 same = g.stride() == p.stride() == m.stride() == v.stride()
-                dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+                dense = (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                         or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d)))
                 if not (same and dense and p.dtype == torch.float32):
                     raise RuntimeError("tinynerf_amd.FusedAdam: parameter, gradient and state must be dense fp32 with equal strides")
                 L.call("tn_adam_step", p.device, L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()),

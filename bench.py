@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views", type=int, default=20, help="synthetic 800x800 cameras (640k rays each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rates (profiling runs)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     return ap.parse_args()
 
@@ -185,7 +186,7 @@ def main():
 
     # stage rates on one batch of the same workload (sampler / render fwd / render fwd+bwd)
     stages = None
-    if rank == 0:
+    if rank == 0 and not args.no_stages:
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
             t = time.perf_counter()

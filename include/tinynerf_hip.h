@@ -155,6 +155,7 @@ enum { TN_ENC_NONE = 0,
        TN_ENC_POSENC = 1,       /* input = PE_F(x[:, :3])                      (models.py:67)    */
        TN_ENC_DIR_CAT = 2 };    /* input = cat[PE_F(dirs), dirs, x]            (models.py:87)    */
 #define TN_MLP_MAX_LAYERS 12
+#define TN_MLP_ACCUM_GRAD_X 1   /* tn_mlp_bwd: grad_x += instead of = (two heads sharing one feature tensor) */
 
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
@@ -163,7 +164,7 @@ typedef struct tn_mlp_desc {
     int32_t encoding;                         /* TN_ENC_*                                     */
     int32_t n_freqs;                          /* F for the encodings                          */
     int32_t out_activation;                   /* TN_ACT_*                                     */
-    int32_t reserved;
+    int32_t flags;                            /* TN_MLP_*                                     */
     const float *freqs;                       /* [n_freqs] encoding frequencies (models.py:34); NULL = 2^j*pi */
     const float *weights[TN_MLP_MAX_LAYERS];  /* [dims[l+1], dims[l]]                         */
     const float *biases[TN_MLP_MAX_LAYERS];   /* [dims[l+1]]                                  */
@@ -175,7 +176,7 @@ int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_
                float *pre_act, void *stream);
 /* Backward of tn_mlp_fwd: recomputes the hidden activations, accumulates (+=) weight/bias
  * gradients into grad_weights[l]/grad_biases[l] (same shapes; must be initialised by the caller)
- * and writes grad_x [n,in_dim] when non-NULL (TN_ENC_POSENC: no grad_x, coords carry no grad;
+ * and writes (flags & TN_MLP_ACCUM_GRAD_X: adds to) grad_x [n,in_dim] when non-NULL (TN_ENC_POSENC: no grad_x, coords carry no grad;
  * TN_ENC_DIR_CAT: gradient w.r.t. the feature part x only).
  * workspace (optional, tn_mlp_bwd_workspace_bytes(desc, n) bytes, uninitialised) selects the two-pass
  * form (data-gradient chain with LDS-resident weights, then a sample-reducing weight-gradient kernel);
@@ -220,6 +221,19 @@ int tn_plane_reg_fwd(const float *plane, int H, int W, int C, double *sums, void
 int tn_plane_reg_bwd(const float *plane, int H, int W, int C, float cy, float cx, float cl1,
                      const float *upstream, float *grad, void *stream);
 
+/* Every plane of the field in one launch, forward and backward fused for a constant upstream gradient
+ * (the harness: d(loss * grad_scale)/d(regulariser) is a host scalar): sums[3*i + {0,1,2}] += the three sums
+ * of tn_plane_reg_fwd for item i (sums may be NULL), grad_i += upstream * (cy, cx, cl1 terms) (grad may be NULL).
+ * `items` is a HOST array. */
+#define TN_MULTI_MAX 32
+typedef struct tn_plane_reg_item {
+    const float *plane;       /* [H,W,C] channel-last */
+    float *grad;              /* same layout, += ; NULL = value only */
+    int32_t H, W, C;
+    float cy, cx, cl1;
+} tn_plane_reg_item;
+int tn_plane_reg_multi(const tn_plane_reg_item *items, int32_t n_items, float upstream, double *sums, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * a20  Cobafa factorised field                                  (reference models.py:209-266)
  * feat[n, off_i + c] = trilinear(basis_i, saw_i(x))[c] * trilinear(coef, x)[i],
@@ -250,6 +264,14 @@ int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const f
  * next step.  28 B/element instead of torch's multi-kernel foreach path. */
 int tn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, void *stream);
+
+/* the same update for many tensors in one launch (`items` is a HOST array; all tensors share the step count) */
+typedef struct tn_adam_item {
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    int64_t n;
+} tn_adam_item;
+int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, int32_t zero_grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ def _free_port():
 class _Stub:
     """the two attributes Trainer.all_reduce_grads / global_mse read"""
     def __init__(self, renderer, world):
-        self.renderer, self.world = renderer, world
+        self.renderer, self.world, self.device = renderer, world, torch.device("cpu")
 
 
 def _make_model():

@@ -318,6 +318,13 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     for g, p in zip(got, ref_params):
         np.testing.assert_allclose(g.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(field.regulariser(1e-4, 0.0).item(), 1e-4 * tv.item(), rtol=1e-6)
+    # harness form (tn_plane_reg_multi): value + upstream-scaled gradient added to the existing .grad, one launch
+    before = [p.plane.grad.clone() for s in field.planes for p in s]
+    val = field.regulariser_step(0.7, 0.3, upstream=1024.0)
+    np.testing.assert_allclose(val.item(), ref.item(), rtol=1e-6)
+    for b, pl, p in zip(before, [p.plane for s in field.planes for p in s], ref_params):
+        want = b.cpu().numpy() + 1024.0 * p.grad.cpu().numpy()
+        np.testing.assert_allclose(pl.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("cfg", [
@@ -371,8 +378,8 @@ def test_wide_deep_mlp_backward_vs_torch(cfg):
 
 
 def test_fused_adam_matches_torch_adam():
-    """tn_adam_step against torch.optim.Adam (reference run.py:186 settings) over several steps, including a
-    channels_last parameter and the LR scheduler."""
+    """tn_adam_multi (FusedAdam) and tn_adam_step against torch.optim.Adam (reference run.py:186 settings) over several
+    steps, including a channels_last parameter and the LR scheduler."""
     from tinynerf_amd.optim import FusedAdam
     torch.manual_seed(0)
     shapes = [(1, 32, 16, 16), (64, 147), (64,), (3, 64), (1,)]
@@ -393,3 +400,13 @@ def test_fused_adam_matches_torch_adam():
         for a, b in zip(p_ref, p_new):
             np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
             assert float(b.grad.abs().max()) == 0.0          # zeroed in the same pass
+    # single-tensor entry point: one more step on a fresh pair
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    a = torch.nn.Parameter(torch.rand(1000, device=DEV)); b = a.detach().clone()
+    g = torch.randn(1000, device=DEV); a.grad = g.clone()
+    torch.optim.Adam([a], lr=1e-2, eps=1e-15, weight_decay=1e-5).step()
+    mm, vv = torch.zeros_like(b), torch.zeros_like(b)
+    L.call("tn_adam_step", b.device, L.ptr(b), L.ptr(g), L.ptr(mm), L.ptr(vv), C.c_int64(1000), C.c_float(1e-2), C.c_float(0.9),
+           C.c_float(0.999), C.c_float(1e-15), C.c_float(1e-5), C.c_int32(1), C.c_int32(0))
+    np.testing.assert_allclose(b.cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)

@@ -37,7 +37,7 @@ class SamplerDesc(C.Structure):
 class MlpDesc(C.Structure):
     _fields_ = [
         ("n_layers", C.c_int32), ("in_dim", C.c_int32), ("dims", C.c_int32 * (TN_MLP_MAX_LAYERS + 1)),
-        ("encoding", C.c_int32), ("n_freqs", C.c_int32), ("out_activation", C.c_int32), ("reserved", C.c_int32),
+        ("encoding", C.c_int32), ("n_freqs", C.c_int32), ("out_activation", C.c_int32), ("flags", C.c_int32),
         ("freqs", C.c_void_p),
         ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
     ]
@@ -52,6 +52,18 @@ class KPlanesDesc(C.Structure):
 
 
 TN_COBAFA_MAX_LEVELS = 8
+TN_MULTI_MAX = 32
+MLP_ACCUM_GRAD_X = 1
+
+
+class PlaneRegItem(C.Structure):
+    _fields_ = [("plane", C.c_void_p), ("grad", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("cy", C.c_float), ("cx", C.c_float), ("cl1", C.c_float)]
+
+
+class AdamItem(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64)]
+
 
 
 class CobafaDesc(C.Structure):

@@ -47,6 +47,7 @@ struct BwdArgs {
     int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];
     int dw_off[TN_MLP_MAX_LAYERS], db_off[TN_MLP_MAX_LAYERS];
     int acc_floats;          // size of the gradient image
+    int accum_gx;            // grad_x += (TN_MLP_ACCUM_GRAD_X)
 };
 
 __device__ __forceinline__ int col0(const BwdArgs &a, int q) {   // slot -> torch column of layer 0
@@ -384,11 +385,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_bwd_kernel(BwdArgs a, const floa
                                 f32x4 v;
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) v[u] = acc[4 * q + u];
-                                *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + f0) = v;
+                                f32x4 *dst = reinterpret_cast<f32x4 *>(gx + row * a.in_dim + f0);
+                                if (a.accum_gx) v += *dst;
+                                *dst = v;
                             } else {
 #pragma unroll
                                 for (int u = 0; u < 4; ++u)
-                                    if (f0 + u < a.in_dim) gx[row * a.in_dim + f0 + u] = acc[4 * q + u];
+                                    if (f0 + u < a.in_dim) {
+                                        float *dst = gx + row * a.in_dim + f0 + u;
+                                        *dst = a.accum_gx ? *dst + acc[4 * q + u] : acc[4 * q + u];
+                                    }
                             }
                         }
                     }
@@ -427,7 +433,7 @@ int plan(const tn_mlp_desc *d, float *const *gw, float *const *gb, BwdArgs &a, i
     for (int l = 1; l < L; ++l) TN_REQUIRE(d->dims[l] == H, TN_E_CONFIG, "mlp_bwd: all hidden layers must share one width");
     TN_REQUIRE(gw && gb, TN_E_NULL, "mlp_bwd: null gradient pointer arrays");
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
-    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L];
+    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
     a.freqs = d->freqs;
     TN_REQUIRE(a.out_dim >= 1 && a.out_dim <= H, TN_E_SIZE, "mlp_bwd: out width must be in [1, hidden]");
     switch (a.enc) {

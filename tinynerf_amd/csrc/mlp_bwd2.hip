@@ -244,11 +244,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                             f32x4 v;
 #pragma unroll
                             for (int u = 0; u < 4; ++u) v[u] = acc[4 * q + u];
-                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + f0) = v;
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(gx + row * a.in_dim + f0);
+                            if (a.accum_gx) v += *dst;
+                            *dst = v;
                         } else {
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
-                                if (f0 + u < a.in_dim) gx[row * a.in_dim + f0 + u] = acc[4 * q + u];
+                                if (f0 + u < a.in_dim) {
+                                    float *dst = gx + row * a.in_dim + f0 + u;
+                                    *dst = a.accum_gx ? *dst + acc[4 * q + u] : acc[4 * q + u];
+                                }
                         }
                     }
                 }

@@ -162,6 +162,7 @@ struct DgradArgs {
     int rows_total;       // stash rows per tile
     int off_gin, off_gout, off_mask;    // row offsets inside a tile
     int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
+    int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
 };
 
 template <int H, bool FIRST, int WPB>
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * kt + frow(r, h);
-                        if (f < a.in_dim) gx[row * a.in_dim + f] = acc[r];
+                        if (f < a.in_dim) gx[row * a.in_dim + f] = a.accum_gx ? gx[row * a.in_dim + f] + acc[r] : acc[r];
                     }
                 }
             } else {
@@ -368,7 +369,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         DgradArgs d;
         d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
         d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? (l - 1) * H : 0;
-        d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs;
+        d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {
             dgrad_layer_kernel<H, false, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, nullptr);

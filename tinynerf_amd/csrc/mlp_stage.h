@@ -17,6 +17,7 @@ struct MlpArgs {
     int w_off[TN_MLP_MAX_LAYERS], b_off[TN_MLP_MAX_LAYERS], stride[TN_MLP_MAX_LAYERS];
     int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];     // true in / out width of each layer
     int lds_floats;
+    int accum_gx;          // grad_x += (TN_MLP_ACCUM_GRAD_X)
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
@@ -104,7 +105,7 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     for (int l = 1; l < L; ++l) TN_REQUIRE(d->dims[l] == H, TN_E_CONFIG, "mlp: all hidden layers must share one width");
     for (int l = 0; l < L; ++l) TN_REQUIRE(d->weights[l] && d->biases[l], TN_E_NULL, "mlp: null weight / bias pointer");
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
-    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L];
+    a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
     a.freqs = d->freqs;
     TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
     switch (a.enc) {

@@ -130,15 +130,13 @@ class _RenderKPlanes(Function):
         g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
-        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X)   # g_feat += d sigma / d feat
         nl = len(sig_p) // 2
         gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[0::2]])
         gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[1::2]])
-        g_feat2 = _alloc(arena, "g_feat2", (n, F), dev)
         ws, ws_bytes = _workspace(sdesc, n, dev, arena, "ws_sigma")
         L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw, gb,
-               L.ptr(g_feat2), L.ptr(ws), C.c_int64(ws_bytes))
-        g_feat.add_(g_feat2)
+               L.ptr(g_feat), L.ptr(ws), C.c_int64(ws_bytes))
         # plane scatter
         kdesc, keep = _kplanes_desc(planes)
         gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()

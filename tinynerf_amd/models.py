@@ -24,7 +24,7 @@ from . import _lib as L
 # fused MLP plumbing
 # --------------------------------------------------------------------------------------------
 def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,
-              freqs: Optional[torch.Tensor]) -> L.MlpDesc:
+              freqs: Optional[torch.Tensor], flags: int = 0) -> L.MlpDesc:
     n_layers = len(params) // 2
     if n_layers > L.TN_MLP_MAX_LAYERS:
         raise RuntimeError(f"MLP with {n_layers} layers exceeds the kernel limit {L.TN_MLP_MAX_LAYERS}")
@@ -34,6 +34,7 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
     d.encoding = encoding
     d.n_freqs = n_freqs
     d.out_activation = out_act
+    d.flags = flags
     d.freqs = freqs.data_ptr() if freqs is not None else None
     d.dims[0] = params[0].size(1)
     for l in range(n_layers):
@@ -386,6 +387,36 @@ class KPlanesFeatureField(torch.nn.Module):
         """w_tv * loss_tv() + w_l1 * loss_l1() in one pass over the planes (run.py:254-256).  With
         ``accumulate_into_grad`` the backward adds straight into ``plane.grad`` (harness option)."""
         return _PlaneRegulariser.apply(float(w_tv), float(w_l1), bool(accumulate_into_grad), *self.plane_tensors())
+
+    @torch.no_grad()
+    def regulariser_step(self, w_tv: float, w_l1: float, upstream: float) -> torch.Tensor:
+        """Harness form of ``regulariser``: value AND gradient in one launch over all planes (tn_plane_reg_multi).
+        ``upstream`` = d(total loss)/d(regulariser) as a host scalar; ``upstream * d reg / d plane`` is added to every
+        ``plane.grad`` (which must exist).  Returns the regulariser value (0-dim fp32 tensor, no graph)."""
+        planes = self.plane_tensors()
+        n = len(planes)
+        dev = planes[0].device
+        if not planes[0].is_cuda:
+            raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
+        items = (L.PlaneRegItem * n)()
+        coef = torch.empty((n, 3), dtype=torch.float64)
+        for i, p in enumerate(planes):
+            _, Cc, H, W = p.shape
+            if p.grad is None or p.grad.stride() != p.stride():
+                raise RuntimeError("regulariser_step: every plane needs a .grad buffer with the plane's layout")
+            cy = w_tv / (n * Cc * max(H - 1, 1) * W)
+            cx = w_tv / (n * Cc * H * max(W - 1, 1))
+            cl = w_l1 / (n * Cc * H * W)
+            it = items[i]
+            it.plane, it.grad, it.H, it.W, it.C = _hwc(p).data_ptr(), _hwc(p.grad).data_ptr(), H, W, Cc
+            it.cy, it.cx, it.cl1 = cy, cx, cl
+            coef[i, 0], coef[i, 1], coef[i, 2] = cy, cx, cl
+        key = (float(w_tv), float(w_l1), str(dev))
+        if getattr(self, "_reg_coef_key", None) != key:
+            self._reg_coef, self._reg_coef_key = coef.to(dev), key
+        sums = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        L.call("tn_plane_reg_multi", dev, items, C.c_int32(n), C.c_float(upstream), L.ptr(sums))
+        return (sums * self._reg_coef).sum().to(torch.float32)
 
 
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):

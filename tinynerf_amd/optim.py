@@ -1,5 +1,5 @@
 """Adam with the update of ``torch.optim.Adam`` (reference run.py:186: lr 1e-2, eps 1e-15, coupled weight decay)
-as ONE kernel pass per parameter tensor (``tn_adam_step``: 28 B/element) instead of torch's multi-kernel
+as ONE kernel pass over all parameter tensors (``tn_adam_multi``: 28 B/element, one launch) instead of torch's multi-kernel
 foreach path (~8 passes over the 126 MiB of K-Planes planes).  ``param_groups`` behave as in torch, so
 ``MultiStepLR`` drives it unchanged."""
 from __future__ import annotations
@@ -24,6 +24,7 @@ class FusedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            by_step = {}
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -42,7 +43,12 @@ class FusedAdam(torch.optim.Optimizer):
                          or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d)))
                 if not (same and dense and p.dtype == torch.float32):
                     raise RuntimeError("tinynerf_amd.FusedAdam: parameter, gradient and state must be dense fp32 with equal strides")
-                L.call("tn_adam_step", p.device, L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()),
-                       C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]),
-                       C.c_float(group["weight_decay"]), C.c_int32(st["step"]), C.c_int32(1 if self.zero_grad_in_step else 0))
+                by_step.setdefault((st["step"], p.device), []).append((p, g, m, v))
+            # one launch per (step count, device): every tensor of the harness shares both
+            for (t, dev), tensors in by_step.items():
+                items = (L.AdamItem * len(tensors))()
+                for it, (p, g, m, v) in zip(items, tensors):
+                    it.param, it.grad, it.exp_avg, it.exp_avg_sq, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                L.call("tn_adam_multi", dev, items, C.c_int32(len(tensors)), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2),
+                       C.c_float(group["eps"]), C.c_float(group["weight_decay"]), C.c_int32(t), C.c_int32(1 if self.zero_grad_in_step else 0))
         return loss

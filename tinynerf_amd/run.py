@@ -113,6 +113,9 @@ class Trainer:
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
         self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
         self.last: Dict[str, float] = {}
+        self._pending: Optional[dict] = None             # sampler pass of the next step, already in flight
+        self._plan_host: Optional[torch.Tensor] = None
+        self.prefetch = True
 
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
         """capacity-based scratch (see fused.Arena): sizes drift by a few percent per step"""
@@ -127,40 +130,58 @@ class Trainer:
 
     # ------------------------------------------------------------------ a8: dynamic batch
     @torch.no_grad()
-    def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
-        """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass."""
+    def _launch_plan(self, n_b: Optional[int] = None) -> None:
+        """First half of the dynamic-batch rule (run.py:215-244): draw a block of rays, count their live samples
+        (tn_sample_mask) and find the cut (tn_batch_plan).  The 16-byte plan goes to pinned host memory behind an
+        event, so ``step()`` can enqueue this right after the forward pass: the numbers are on the host long before
+        the backward pass has drained, and the host never waits for the whole queue (one read-back per step, but no
+        pipeline bubble).  The draw depends on the occupancy grid and the ray stream only, not on the parameters."""
         cfg, dev = self.cfg, self.device
         B, S = cfg.batch_size, cfg.n_samples
-        rp = self.ray_provider
         n_chunks = (S + 63) // 64
+        n_b = n_b or min(4096, max(2, int(self._k_guess * 1.5) + 2))
+        if cfg.deterministic:
+            idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
+        else:
+            idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
+        o, d = self.rays_o[idx], self.rays_d[idx]
+        desc = self.ray_provider._desc(dev, not cfg.deterministic, None)
+        desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
+        R_all = n_b * B
+        maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
+        counts = self._buf("counts", (R_all,), torch.int32)
+        plan = self._buf("plan", (4,), torch.int32)
+        L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
+        L.call("tn_batch_plan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan))
+        if self._plan_host is None:
+            self._plan_host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            self._plan_event = torch.cuda.Event()
+        self._plan_host.copy_(plan, non_blocking=True)
+        self._plan_event.record(torch.cuda.current_stream(dev))
+        self._pending = dict(n_b=n_b, idx=idx, o=o, d=d, desc=desc, maskbits=maskbits, counts=counts)
+
+    @torch.no_grad()
+    def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
+        """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass."""
+        dev, B = self.device, self.cfg.batch_size
         while True:
-            n_b = min(4096, max(2, int(self._k_guess * 1.5) + 2))
-            if cfg.deterministic:
-                idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
-            else:
-                idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
-            o, d = self.rays_o[idx], self.rays_d[idx]
-            desc = rp._desc(dev, not cfg.deterministic, None)
-            desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
-            R_all = n_b * B
-            maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
-            counts = self._buf("counts", (R_all,), torch.int32)
-            plan = self._buf("plan", (4,), torch.int32)
-            L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
-            L.call("tn_batch_plan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan))
-            k, n, R, tripped = plan.tolist()           # the step's single host read-back
-            if tripped or n_b >= 4096:
+            if self._pending is None:
+                self._launch_plan()
+            pend, self._pending = self._pending, None
+            self._plan_event.synchronize()              # the step's single host read-back
+            k, n, R, tripped = self._plan_host.tolist()
+            if tripped or pend["n_b"] >= 4096:
                 break
-            self._k_guess = n_b * 2                      # not enough rays drawn: redraw a larger block
+            self._k_guess = pend["n_b"] * 2             # not enough rays drawn: redraw a larger block
         self._k_guess = k
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         info = self._buf("info", (R, 2), torch.int32)
         total = self._buf("total", (1,), torch.int32)
-        L.call("tn_sample_scan", dev, L.ptr(counts), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
+        L.call("tn_sample_scan", dev, L.ptr(pend["counts"]), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
         packed = self._buf("packed", (n, 7), torch.float32)
-        L.call("tn_sample_pack", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(info),
-               C.c_void_p(None), L.ptr(packed), C.c_void_p(None), C.c_int64(n))
-        return packed, info, self.rgbs[idx[:R]], k
+        L.call("tn_sample_pack", dev, C.byref(pend["desc"]), L.ptr(pend["o"]), L.ptr(pend["d"]), C.c_int64(R), L.ptr(pend["maskbits"]),
+               L.ptr(info), C.c_void_p(None), L.ptr(packed), C.c_void_p(None), C.c_int64(n))
+        return packed, info, self.rgbs[pend["idx"][:R]], k
 
     # ------------------------------------------------------------------ one optimizer step
     def sigma_fn(self, t: torch.Tensor) -> torch.Tensor:
@@ -178,12 +199,18 @@ class Trainer:
                 jit = torch.full((r, r, r, 3), 0.5, device=self.device)
             self.occupancy_grid.update(self.sigma_fn, jitters=jit)
         rendered = self.renderer(packed, info)                                    # run.py:251
-        loss = self.global_mse(rendered, target)
-        if cfg.method == "kplanes":                                               # run.py:254-256
-            reg = self.renderer.feature_module.regulariser(self.tv_reg_alpha, self.l1_reg_alpha, True)   # type: ignore
-            loss = loss + reg / self.world
+        if self.prefetch:
+            self._launch_plan()            # next step's sampler pass runs between this forward and backward
+        # loss * grad_scale, scaled and never unscaled (run.py:259-260 quirk).  The MSE and its gradient are written out
+        # by hand (4 small kernels instead of ~12 through autograd); the regulariser's value and gradient are one launch.
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
-        (loss * cfg.grad_scale).backward()                                        # scaled, never unscaled (quirk)
+        diff = rendered.detach() - target
+        inv = 1.0 / (3.0 * self.global_ray_count(rendered.size(0)))               # python float or 0-dim tensor
+        rendered.backward(diff * (inv * (2.0 * cfg.grad_scale)))
+        loss = (diff * diff).sum() * inv
+        if cfg.method == "kplanes":                                               # run.py:254-256
+            reg = self.renderer.feature_module.regulariser_step(self.tv_reg_alpha, self.l1_reg_alpha, cfg.grad_scale / self.world)   # type: ignore
+            loss = loss + reg / self.world
         if self.world > 1:
             self.all_reduce_grads()
         self.optimizer.step()
@@ -193,14 +220,18 @@ class Trainer:
         self._loss = loss.detach()
         return self.last
 
-    def global_mse(self, rendered: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    def global_ray_count(self, local_rays: int):
         """MSE over ALL ranks' rays: sum of local squared errors / (3 * global ray count).  Dynamic batches
         give every rank a different ray count, so a per-rank mean followed by gradient averaging would not
         equal the single-GPU loss; with this normalisation the SUM of rank gradients does."""
-        n_rays = torch.tensor([float(rendered.size(0))], device=rendered.device)
-        if self.world > 1:
-            torch.distributed.all_reduce(n_rays)
-        return ((rendered - target) ** 2).sum() / (3.0 * n_rays[0])
+        if self.world == 1:
+            return float(local_rays)
+        n_rays = torch.tensor([float(local_rays)], device=self.device)
+        torch.distributed.all_reduce(n_rays)
+        return n_rays[0]
+
+    def global_mse(self, rendered: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return ((rendered - target) ** 2).sum() / (3.0 * Trainer.global_ray_count(self, rendered.size(0)))
 
     def loss_value(self) -> float:
         v = self._loss.clone()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TN_ABI_VERSION 1
+#define TN_ABI_VERSION 2
 
 enum {
     TN_OK = 0,
@@ -153,9 +153,13 @@ int tn_posenc_fwd(const float *x, int64_t n, int n_channels, const float *freqs,
 enum { TN_ACT_NONE = 0, TN_ACT_EXP_M1 = 1 /* exp(y-1), models.py:74 */, TN_ACT_SIGMOID = 2 };
 enum { TN_ENC_NONE = 0,
        TN_ENC_POSENC = 1,       /* input = PE_F(x[:, :3])                      (models.py:67)    */
-       TN_ENC_DIR_CAT = 2 };    /* input = cat[PE_F(dirs), dirs, x]            (models.py:87)    */
+       TN_ENC_DIR_CAT = 2,      /* input = cat[PE_F(dirs), dirs, x]            (models.py:87)    */
+       TN_ENC_AUX_CAT = 3 };    /* input = cat[aux_table[aux_index[row]], x]: the same colour-head input with
+                                 * cat[PE_F(d), d] evaluated once per RAY (tn_dir_encode) instead of per sample */
 #define TN_MLP_MAX_LAYERS 12
 #define TN_MLP_ACCUM_GRAD_X 1   /* tn_mlp_bwd: grad_x += instead of = (two heads sharing one feature tensor) */
+#define TN_MLP_STASHED 2        /* tn_mlp_bwd: workspace holds the activations written by tn_mlp_fwd_stash
+                                 * (same desc, x, aux, n): no forward recomputation */
 
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
@@ -168,12 +172,26 @@ typedef struct tn_mlp_desc {
     const float *freqs;                       /* [n_freqs] encoding frequencies (models.py:34); NULL = 2^j*pi */
     const float *weights[TN_MLP_MAX_LAYERS];  /* [dims[l+1], dims[l]]                         */
     const float *biases[TN_MLP_MAX_LAYERS];   /* [dims[l+1]]                                  */
+    /* TN_ENC_AUX_CAT: `aux` is a table [n_aux, aux_stride] whose rows hold dims[0]-in_dim values followed by
+     * zeros (aux_stride and in_dim multiples of 4); row i of x uses table row aux_index[i] (NULL: row i). */
+    const int32_t *aux_index;
+    int32_t aux_stride;
+    int32_t reserved;
 } tn_mlp_desc;
 
 /* y [n, dims[n_layers]] = MLP(x [n,in_dim], aux [n,3] (dirs for TN_ENC_DIR_CAT, else NULL)).
  * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */
 int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
                float *pre_act, void *stream);
+/* Training forward: y as tn_mlp_fwd, plus the hidden activations, their ReLU bit masks and the last layer's
+ * pre-activation into `workspace` (tn_mlp_bwd_workspace_bytes(desc, n) bytes) in the layout tn_mlp_bwd's two-pass
+ * form uses; pass the same workspace to tn_mlp_bwd with TN_MLP_STASHED set.  Returns TN_E_CONFIG for
+ * configurations the two-pass form does not cover (workspace size 0). */
+int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+/* out[r, :] = [PE_F(dirs[r]) (6F, models.py:36-39 order), dirs[r] (3), 0 ...] with row stride `stride` >= 6F+3:
+ * the aux table of TN_ENC_AUX_CAT for the colour head (models.py:87). */
+int tn_dir_encode(const float *dirs, int64_t n, const float *freqs, int n_freqs, float *out, int stride, void *stream);
 /* Backward of tn_mlp_fwd: recomputes the hidden activations, accumulates (+=) weight/bias
  * gradients into grad_weights[l]/grad_biases[l] (same shapes; must be initialised by the caller)
  * and writes (flags & TN_MLP_ACCUM_GRAD_X: adds to) grad_x [n,in_dim] when non-NULL (TN_ENC_POSENC: no grad_x, coords carry no grad;

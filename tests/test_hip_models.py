@@ -410,3 +410,72 @@ def test_fused_adam_matches_torch_adam():
     L.call("tn_adam_step", b.device, L.ptr(b), L.ptr(g), L.ptr(mm), L.ptr(vv), C.c_int64(1000), C.c_float(1e-2), C.c_float(0.9),
            C.c_float(0.999), C.c_float(1e-15), C.c_float(1e-5), C.c_int32(1), C.c_int32(0))
     np.testing.assert_allclose(b.cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("head", ["sigma", "rgb"])
+def test_mlp_stashed_forward_and_ray_table_match_recompute_path(head):
+    """Training forward with activation stash (tn_mlp_fwd_stash + TN_MLP_STASHED) and the per-ray aux table
+    (TN_ENC_AUX_CAT + tn_dir_encode) against the recompute path with per-sample directions (TN_ENC_DIR_CAT):
+    same outputs, same parameter gradients, same grad_x (incl. TN_MLP_ACCUM_GRAD_X)."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    from tinynerf_amd.models import _mlp_desc
+    m = models()
+    torch.manual_seed(11)
+    n, R, F = 4133, 97, 96                                   # ragged: not a multiple of 32
+    dev = torch.device(DEV)
+    if head == "sigma":
+        net = m.VanillaOpacityDecoder(F).to(dev).net
+        params = [p.detach().contiguous() for p in net.params()]
+        enc_a, enc_b, nf, act, freqs, out = L.ENC_NONE, L.ENC_NONE, 0, L.ACT_EXP_M1, None, 1
+    else:
+        cd = m.VanillaColorDecoder(8, F, 64, 3).to(dev)
+        params = [p.detach().contiguous() for p in cd.net.params()]
+        enc_a, enc_b, nf, act, freqs, out = L.ENC_DIR_CAT, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, cd.pe.freqs, 3
+    x = torch.rand(n, F, device=dev)
+    counts = torch.randint(0, 90, (R,), device=dev)
+    counts[-1] += n - counts.sum() if counts.sum() < n else 0
+    while int(counts.sum()) > n:
+        counts[int(torch.argmax(counts))] -= min(int(counts.sum()) - n, int(counts.max()))
+    ray_ids = torch.repeat_interleave(torch.arange(R, dtype=torch.int32, device=dev), counts, output_size=n)
+    dirs_ray = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+    dirs = dirs_ray[ray_ids.long()].contiguous()
+    table = torch.full((R, 56), float("nan"), device=dev)
+    if head == "rgb":
+        L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(freqs), C.c_int(8), L.ptr(table), C.c_int(56))
+        ref_tab = torch.cat([torch.sin(dirs_ray[..., None] * freqs), torch.cos(dirs_ray[..., None] * freqs)], -1).flatten(-2)
+        np.testing.assert_allclose(table[:, :48].cpu().numpy(), ref_tab.cpu().numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(table[:, 48:51], dirs_ray) and float(table[:, 51:].abs().max()) == 0.0
+    gy = torch.randn(n, out, device=dev)
+
+    def run(enc, aux, idx, stash, accum):
+        flags = (L.MLP_ACCUM_GRAD_X if accum else 0)
+        d = _mlp_desc(params, F, enc, nf, act, freqs, flags, idx, 56 if enc == L.ENC_AUX_CAT else 0)
+        fn = L.lib().tn_mlp_bwd_workspace_bytes
+        fn.restype = C.c_int64
+        nbytes = int(fn(C.byref(d), C.c_int64(n)))
+        assert nbytes > 0
+        ws = torch.empty(nbytes // 4, device=dev)
+        y = torch.empty(n, out, device=dev)
+        if stash:
+            L.call("tn_mlp_fwd_stash", dev, C.byref(d), L.ptr(x), L.ptr(aux), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nbytes))
+            d.flags = flags | L.MLP_STASHED
+        else:
+            L.call("tn_mlp_fwd", dev, C.byref(d), L.ptr(x), L.ptr(aux), C.c_int64(n), L.ptr(y), C.c_void_p(None))
+        gs = [torch.zeros_like(p) for p in params]
+        nl = len(params) // 2
+        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in gs[0::2]])
+        gb = (C.c_void_p * nl)(*[g.data_ptr() for g in gs[1::2]])
+        gx = torch.ones(n, F, device=dev) if accum else torch.empty(n, F, device=dev)
+        L.call("tn_mlp_bwd", dev, C.byref(d), L.ptr(x), L.ptr(aux), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx), L.ptr(ws), C.c_int64(nbytes))
+        return y, gs, gx
+
+    aux_a = dirs if head == "rgb" else None
+    aux_b = table if head == "rgb" else None
+    y0, g0, gx0 = run(enc_a, aux_a, None, False, False)
+    for stash, accum in ((True, False), (False, True), (True, True)):
+        y1, g1, gx1 = run(enc_b, aux_b, ray_ids if head == "rgb" else None, stash, accum)
+        np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-6)
+        for a_, b_ in zip(g1, g0):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b_.abs().max())))
+        np.testing.assert_allclose((gx1 - (1.0 if accum else 0.0)).cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=2e-6)

@@ -20,7 +20,7 @@ TN_KPLANES_MAX_SCALES = 4
 MARCH_AABB, MARCH_UNBOUNDED = 0, 1
 CONTRACT_AABB, CONTRACT_MIP360_INF, CONTRACT_MIP360_L2 = 0, 1, 2
 ACT_NONE, ACT_EXP_M1, ACT_SIGMOID = 0, 1, 2
-ENC_NONE, ENC_POSENC, ENC_DIR_CAT = 0, 1, 2
+ENC_NONE, ENC_POSENC, ENC_DIR_CAT, ENC_AUX_CAT = 0, 1, 2, 3
 
 
 class SamplerDesc(C.Structure):
@@ -40,6 +40,7 @@ class MlpDesc(C.Structure):
         ("encoding", C.c_int32), ("n_freqs", C.c_int32), ("out_activation", C.c_int32), ("flags", C.c_int32),
         ("freqs", C.c_void_p),
         ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
+        ("aux_index", C.c_void_p), ("aux_stride", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -54,6 +55,7 @@ class KPlanesDesc(C.Structure):
 TN_COBAFA_MAX_LEVELS = 8
 TN_MULTI_MAX = 32
 MLP_ACCUM_GRAD_X = 1
+MLP_STASHED = 2
 
 
 class PlaneRegItem(C.Structure):

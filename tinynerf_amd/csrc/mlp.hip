@@ -22,10 +22,14 @@ using tn::f32x16;
 using tn::f32x4;
 using namespace tn::mlp;
 
-template <int H, bool WLDS, int WPB>
+// STASH (training forward, out <= 4, weights in LDS): hidden activations, their ReLU bit masks and the last layer's
+// pre-activation also go to the workspace of the two-pass backward (layout: mlp_stage.h), which then starts at the
+// output gradient instead of recomputing the forward.
+template <int H, bool WLDS, int WPB, bool STASH>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const float *__restrict__ x,
                                                            const float *__restrict__ aux, int64_t n,
-                                                           float *__restrict__ y, float *__restrict__ pre_act)
+                                                           float *__restrict__ y, float *__restrict__ pre_act,
+                                                           float *__restrict__ stash)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
@@ -47,9 +51,23 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
         const bool valid = row < n;
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
         float aux3[3] = {0.f, 0.f, 0.f};
+        const float *auxrow = nullptr;
         if (valid) {
             if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
             else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
+            else if (a.enc == TN_ENC_AUX_CAT) auxrow = aux + (int64_t)(a.aux_index ? a.aux_index[row] : row) * a.aux_stride;
+        }
+        float *stH = nullptr, *stE = nullptr, *stQ = nullptr;
+        unsigned *stM = nullptr;
+        int xs = 0, extra = 0;
+        if constexpr (STASH) {
+            const int NH = L - 1;
+            extra = extra_rows(a.enc, a.in_dim, a.K0_pad);
+            xs = x_slots(a.enc, a.in_dim);
+            stH = stash + tile * (int64_t)(stash_rows(H, NH, extra) * 32);
+            stE = stH + (2 * NH * H + 4) * 32;
+            stQ = stH + stash_rows_w(H, NH, extra) * 32;
+            stM = reinterpret_cast<unsigned *>(stQ + 4 * 32);
         }
         // ---- layer 0: inputs streamed 4 slots at a time, prefetched one group ahead ----
         const float *W0 = WLDS ? lds + a.w_off[0] : a.W[0];
@@ -57,15 +75,15 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
         f32x16 act[T];
 #pragma unroll
         for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(B0, ob, h);
-        f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h);
+        f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h, auxrow);
         for (int g = 0; g < G0; ++g) {
             f32x4 bn = {0.f, 0.f, 0.f, 0.f};
-            if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h);
+            if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h, auxrow);
             f32x4 w[T];
 #pragma unroll
             for (int ob = 0; ob < T; ++ob) {
                 if constexpr (WLDS) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
-                else if (a.enc != TN_ENC_DIR_CAT) w[ob] = load_a4<false>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.K0);
+                else if (a.enc != TN_ENC_DIR_CAT && a.enc != TN_ENC_AUX_CAT) w[ob] = load_a4<false>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.K0);
                 else {   // global first layer of a dir_cat head: slot -> torch column, one dword at a time
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -78,15 +96,35 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
+            if constexpr (STASH) {
+                if (extra > 0 && 8 * g + 4 * h + 3 >= xs) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = 8 * g + 4 * h + u;
+                        if (q >= xs) stE[(q - xs) * 32 + j] = b[u];
+                    }
+                }
+            }
             b = bn;
         }
 #pragma unroll
-        for (int ob = 0; ob < T; ++ob) { tn::pin16(act[ob]); act[ob] = tn::relu16(act[ob]); }
+        for (int ob = 0; ob < T; ++ob) {
+            tn::pin16(act[ob]);
+            act[ob] = tn::relu16(act[ob]);
+            if constexpr (STASH) { stM[ob * 64 + lane] = relu_bits(act[ob]); store_rows(stH, act[ob], ob, j, h); }
+        }
         // ---- hidden layers H -> H ----
         for (int l = 1; l + 1 < L; ++l) {
             const float *Wl = WLDS ? lds + a.w_off[l] : a.W[l];
             const float *Bl = WLDS ? lds + a.b_off[l] : a.B[l];
             tn::hidden_layer<H>(Wl, Bl, WLDS ? a.stride[l] : H, act, j, h);
+            if constexpr (STASH) {
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) {
+                    stM[(l * T + ob) * 64 + lane] = relu_bits(act[ob]);
+                    store_rows(stH + l * H * 32, act[ob], ob, j, h);
+                }
+            }
         }
         // ---- output layer ----
         const float *Wf = WLDS ? lds + a.w_off[L - 1] : a.W[L - 1];
@@ -99,6 +137,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
             for (int o = 0; o < 4; ++o) {
                 o4[o] = 0.f;
                 if (o < out) o4[o] = tn::small_out<H>(Wf + o * sf, Bf[o], act, h);
+                if constexpr (STASH) { if (h == 0) stQ[o * 32 + j] = o4[o]; }
             }
             if (valid && h == 0) {
 #pragma unroll
@@ -177,32 +216,46 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t n, int C, con
 }
 
 template <int H>
-int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, hipStream_t s)
+int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s)
 {
     const int64_t n_tiles = (n + 31) / 32;
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
     if (wlds) {
-        auto kern = mlp_fwd_kernel<H, true, WPB>;
+        auto kern = mlp_fwd_kernel<H, true, WPB, false>;
+        if constexpr (H <= 64) { if (stash) kern = mlp_fwd_kernel<H, true, WPB, true>; }
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash);
     } else {
+        if (stash) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: weights must fit LDS");
         // weights streamed from L2
-        auto kern = mlp_fwd_kernel<H, false, WPB>;
+        auto kern = mlp_fwd_kernel<H, false, WPB, false>;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act, nullptr);
     }
     return tn::check_launch("mlp_fwd_kernel");
 }
 
-}  // namespace
+// aux table of TN_ENC_AUX_CAT for the colour head: [PE(d), d, 0...] per ray
+__global__ void dir_encode_kernel(const float *__restrict__ d, int64_t n, const float *__restrict__ freqs, int F, float *__restrict__ out, int stride)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * stride) return;
+    const int64_t row = e / stride;
+    const int p = (int)(e - row * stride);
+    const float dc[3] = {d[3 * row], d[3 * row + 1], d[3 * row + 2]};
+    float v = 0.0f;
+    if (p < 6 * F) v = tn::posenc_value(dc, p, F, freqs);
+    else if (p < 6 * F + 3) v = dc[p - 6 * F];
+    out[e] = v;
+}
 
-extern "C" int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act,
-                          void *stream)
+int fwd_common(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash,
+               hipStream_t s, const char *who)
 {
     MlpArgs a;
     int H = 0;
@@ -210,15 +263,52 @@ extern "C" int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *
     TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mlp_fwd: negative n");
     if (n == 0) return TN_OK;
     TN_REQUIRE(x && y, TN_E_NULL, "tn_mlp_fwd: null pointer");
-    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_fwd: dir_cat needs aux (ray directions)");
+    TN_REQUIRE((a.enc != TN_ENC_DIR_CAT && a.enc != TN_ENC_AUX_CAT) || aux, TN_E_NULL, "tn_mlp_fwd: dir_cat / aux_cat need aux");
     TN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: x / y must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+    TN_REQUIRE(a.enc != TN_ENC_AUX_CAT || ((uintptr_t)aux & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: aux table must be 16-byte aligned");
     switch (H) {
-    case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, s);
-    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, s);
-    case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, s);
-    default: return launch_fwd<256>(a, x, aux, n, y, pre_act, s);
+    case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, stash, s);
+    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, stash, s);
+    case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, stash, s);
+    default: return launch_fwd<256>(a, x, aux, n, y, pre_act, stash, s);
     }
+}
+
+}  // namespace
+
+extern "C" int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act,
+                          void *stream)
+{
+    return fwd_common(desc, x, aux, n, y, pre_act, nullptr, (hipStream_t)stream, "tn_mlp_fwd");
+}
+
+extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
+
+extern "C" int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, void *workspace,
+                                int64_t workspace_bytes, void *stream)
+{
+    TN_REQUIRE(desc, TN_E_NULL, "tn_mlp_fwd_stash: null descriptor");
+    const int H = desc->dims[1];
+    TN_REQUIRE((H == 32 || H == 64) && desc->n_layers >= 2 && desc->n_layers <= 5 && desc->dims[desc->n_layers] <= 4, TN_E_CONFIG,
+               "tn_mlp_fwd_stash: outside the two-pass backward's configurations (hidden 32/64, <= 5 layers, <= 4 outputs)");
+    if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_mlp_fwd_stash: negative n");
+    const int64_t need = tn_mlp_bwd_workspace_bytes(desc, n);
+    const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
+    TN_REQUIRE(need == ((n + 31) / 32) * (int64_t)stash_rows(H, desc->n_layers - 1, extra) * 128, TN_E_CONFIG,
+               "tn_mlp_fwd_stash: configuration not covered by the two-pass backward");
+    TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_fwd_stash: workspace missing or too small");
+    TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd_stash: workspace must be 16-byte aligned");
+    return fwd_common(desc, x, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_mlp_fwd_stash");
+}
+
+extern "C" int tn_dir_encode(const float *dirs, int64_t n, const float *freqs, int n_freqs, float *out, int stride, void *stream)
+{
+    TN_REQUIRE(n >= 0 && n_freqs > 0 && stride >= 6 * n_freqs + 3, TN_E_SIZE, "tn_dir_encode: bad size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(dirs && out, TN_E_NULL, "tn_dir_encode: null pointer");
+    const int64_t total = n * stride;
+    dir_encode_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(dirs, n, freqs, n_freqs, out, stride);
+    return tn::check_launch("dir_encode_kernel");
 }
 
 extern "C" int tn_posenc_fwd(const float *x, int64_t n, int n_channels, const float *freqs, int n_freqs, float *out,

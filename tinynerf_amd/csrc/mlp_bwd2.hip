@@ -47,30 +47,12 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
     return 1.0f;
 }
 
-// D-layout tile -> workspace rows [feature][32 samples]; two fully used 128-B lines per store instruction
-__device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rows[(32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = t[r];
-}
-
-__device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
-    unsigned m = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (t[r] > 0.0f ? 1u : 0u) << r;
-    return m;
-}
-
-// workspace rows per 32-sample tile: H_1..H_NH, G_0..G_{NH-1}, g_pre (4), E = encoded first-layer slots that
-// are not plain x columns (PE(d), d, padding), which the chain kernel has in hand and the wgrad kernel would
-// otherwise have to recompute (16 sincos per lane and tile)
-__host__ __device__ inline int x_slots(int enc, int in_dim) { return enc == TN_ENC_POSENC ? 0 : in_dim; }
-__host__ __device__ inline int extra_rows(int enc, int in_dim, int K0_pad) { return enc == TN_ENC_NONE ? 0 : K0_pad - x_slots(enc, in_dim); }
-template <int H> __host__ __device__ inline int stash_rows(int nh, int extra) { return 2 * nh * H + 4 + extra; }
-
 // ------------------------------------------------------------------------------------------------
 // chain kernel
 // ------------------------------------------------------------------------------------------------
-template <int H, int NH, int WPB>
+// STASHED: the training forward (tn_mlp_fwd_stash) already wrote H_l, the ReLU masks and the pre-activation of the
+// last layer; the kernel starts at the output gradient.
+template <int H, int NH, int WPB, bool STASHED>
 __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
                                                              float *__restrict__ stash)
@@ -91,30 +73,54 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         asm volatile("" : "+v"(j), "+v"(h));           // keep per-lane LDS addresses out of LICM's reach
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
-        const float *xrow = x + (valid ? row : 0) * a.in_dim;
-        float aux3[3] = {0.f, 0.f, 0.f};
-        if (valid) {
-            if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
-            else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
-        }
-        const int xs = x_slots(a.enc, a.in_dim);
-        float *st = stash + tile * (int64_t)(stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad)) * 32);
+        const int extra = extra_rows(a.enc, a.in_dim, a.K0_pad);
+        float *st = stash + tile * (int64_t)(stash_rows(H, NH, extra) * 32);
         float *stH = st;                                // H_1 .. H_NH
         float *stG = st + NH * H * 32;                  // G_0 .. G_{NH-1}
         float *stP = st + 2 * NH * H * 32;              // g_pre (4 rows)
         float *stE = stP + 4 * 32;                      // encoded extras
+        float *stQ = st + stash_rows_w(H, NH, extra) * 32;             // pre-activation of the last layer (4 rows)
+        unsigned *stM = reinterpret_cast<unsigned *>(stQ + 4 * 32);    // ReLU masks
+        const float *Wf = lds + a.w_off[L - 1];
+        const float *Bf = lds + a.b_off[L - 1];
+        const int sf = a.stride[L - 1];
+        unsigned mask[NH][T];
+        float gp[4];
+        if constexpr (STASHED) {
+#pragma unroll
+            for (int l = 0; l < NH; ++l)
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) mask[l][ob] = stM[(l * T + ob) * 64 + lane];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                gp[o] = 0.0f;
+                if (o < out) {
+                    const float pre = stQ[o * 32 + j];
+                    gp[o] = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
+                }
+                if (h == 0) stP[o * 32 + j] = gp[o];
+            }
+        } else {
+        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        float aux3[3] = {0.f, 0.f, 0.f};
+        const float *auxrow = nullptr;
+        if (valid) {
+            if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
+            else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
+            else if (a.enc == TN_ENC_AUX_CAT) auxrow = aux + (int64_t)(a.aux_index ? a.aux_index[row] : row) * a.aux_stride;
+        }
+        const int xs = x_slots(a.enc, a.in_dim);
 
         // ---------------- forward ----------------
         f32x16 act[T];
-        unsigned mask[NH][T];
         {
             const float *W0 = lds + a.w_off[0];
 #pragma unroll
             for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(lds + a.b_off[0], ob, h);
-            f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h);
+            f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h, auxrow);
             for (int g = 0; g < G0; ++g) {
                 f32x4 bn = {0.f, 0.f, 0.f, 0.f};
-                if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h);
+                if (g + 1 < G0) bn = fetch_input(a, xrow, aux3, valid, g + 1, h, auxrow);
                 f32x4 w[T];
 #pragma unroll
                 for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b[u], act[ob]);
-                if (a.enc != TN_ENC_NONE && 8 * g + 4 * h + 3 >= xs) {
+                if (extra > 0 && 8 * g + 4 * h + 3 >= xs) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int q = 8 * g + 4 * h + u;
@@ -150,10 +156,6 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         });
 
         // ---------------- output gradient (out <= 4) and first data-gradient step on the VALU ----------------
-        const float *Wf = lds + a.w_off[L - 1];
-        const float *Bf = lds + a.b_off[L - 1];
-        const int sf = a.stride[L - 1];
-        float gp[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             gp[o] = 0.0f;
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 gp[o] = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
             }
             if (h == 0) stP[o * 32 + j] = gp[o];
+        }
         }
         f32x16 G[T];
 #pragma unroll
@@ -267,14 +270,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     int n_layers, in_dim, K0, K0_pad, enc, n_freqs, out_dim, Tk0, total_tiles;
+    const int *aux_index;       // TN_ENC_AUX_CAT
+    int aux_stride;
     float *gW[TN_MLP_MAX_LAYERS];
     float *gB[TN_MLP_MAX_LAYERS];
     int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];
 };
 
 __device__ __forceinline__ int wg_col0(const WgradArgs &a, int q) {
-    if (a.enc == TN_ENC_DIR_CAT) {
-        const int pe = 6 * a.n_freqs + 3;
+    if (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) {
+        const int pe = a.K0 - a.in_dim;
         return q < a.in_dim ? pe + q : q - a.in_dim;
     }
     return q;
@@ -298,20 +303,24 @@ __device__ __forceinline__ void decode_tile(const WgradArgs &a, int id, int &l, 
 // prefetched into registers while the current one is being multiplied (issue early / write late).
 constexpr int RS = 36;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128 across 16 lanes
 
-template <int H, int NH, int MAXS, int NW, int NCH>
+template <int H, int NH, int MAXS, int NW, int NCH, bool AUX>
 __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                             int64_t n, const float *__restrict__ stash)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: tile ownership lives in SGPRs
     const int64_t n_tiles = (n + 31) >> 5;
     const int xs = x_slots(a.enc, a.in_dim);
-    const int R = stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad));
+    const int extra = extra_rows(a.enc, a.in_dim, a.K0_pad);
+    const int R = stash_rows_w(H, NH, extra);             // rows staged per tile
+    const int Rt = stash_rows(H, NH, extra);              // rows per tile in the workspace
     const int row_chunks = R * 8;                         // float4 chunks of the workspace tile
     const int x_chunks = xs > 0 ? (32 * a.in_dim) / 4 : 0;   // float4 chunks of the x rows of the tile (contiguous)
+    const int aw = AUX ? a.K0_pad - a.in_dim : 0;         // aux-table columns (multiple of 8, <= 64)
     float *ldsR = lds;
     float *ldsX = lds + R * RS;
+    float *ldsA = ldsX + (xs > 0 ? 32 * a.in_dim : 0);
     f32x16 acc[MAXS];
     float dbacc[MAXS];
     int tl[MAXS], ttn[MAXS], ttk[MAXS];
@@ -324,9 +333,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
         const int id = wave + NW * m;
         if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
     }
+    // staging registers: NCH float4 of workspace rows / x rows per thread, plus (AUX) one float4 of the aux-table row of
+    // one sample: 32 samples x 16 float4 slots = 512 chunks, one per thread of the first 8 waves
     f32x4 pre[NCH];
+    f32x4 preA = {0.f, 0.f, 0.f, 0.f};
     auto prefetch = [&](int64_t tile) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)R * 32);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32);
         const int64_t x0 = tile * 32 * (int64_t)a.in_dim;          // first float of the tile's x rows
         const int64_t xend = n * (int64_t)a.in_dim;
 #pragma unroll
@@ -344,6 +356,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
             }
             pre[k] = v;
         }
+        if constexpr (AUX) {
+            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
+            const int64_t r_ = tile * 32 + s_;
+            preA = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (threadIdx.x < 512 && r_ < n && 4 * part < aw)
+                preA = *reinterpret_cast<const f32x4 *>(aux + (int64_t)(a.aux_index ? a.aux_index[r_] : r_) * a.aux_stride + 4 * part);
+        }
     };
     auto commit = [&]() {
 #pragma unroll
@@ -351,6 +370,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
             const int c = threadIdx.x + k * NW * 64;
             if (c < row_chunks) *reinterpret_cast<f32x4 *>(ldsR + (c >> 3) * RS + (c & 7) * 4) = pre[k];
             else if (c < row_chunks + x_chunks) *reinterpret_cast<f32x4 *>(ldsX + 4 * (c - row_chunks)) = pre[k];
+        }
+        if constexpr (AUX) {
+            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
+            if (threadIdx.x < 512 && 4 * part < aw) *reinterpret_cast<f32x4 *>(ldsA + s_ * aw + 4 * part) = preA;
         }
     };
     int64_t tile = blockIdx.x;
@@ -365,46 +388,39 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
         for (int m = 0; m < MAXS; ++m) {
             const int l = tl[m];
             if (l < 0) continue;
-            f32x4 gv[4], av[4];
-            {
-                const int grow = l < NH ? (NH + l) * H + 32 * ttn[m] + i : 2 * NH * H + (i < 4 ? i : 0);
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(ldsR + grow * RS + 16 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; gv[e] = (l < NH || i < 4) ? v : f32x4{0.f, 0.f, 0.f, 0.f}; }
-            }
+            // G operand: row segment [16 samples of this half]; A-side operand: a row segment (hidden layers, E rows) or
+            // a column of the sample-major x / aux rows.  Four samples (one e) at a time keeps the live set small.
+            const int grow = l < NH ? (NH + l) * H + 32 * ttn[m] + i : 2 * NH * H + (i < 4 ? i : 0);
+            const f32x4 *gp = reinterpret_cast<const f32x4 *>(ldsR + grow * RS + 16 * h);
+            const bool gok = l < NH || i < 4;
+            const f32x4 *rp = nullptr;           // row-type source
+            const float *cp = nullptr;           // column-type source
+            int cstride = 0;
             if (l == 0) {
-                const int q0 = 32 * ttk[m], q = q0 + i;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) av[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (q0 < xs) {                                     // wave-uniform: x columns (sample-major rows in LDS)
-                    const int qx = q < xs ? q : 0;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const float v = ldsX[(16 * h + t) * a.in_dim + qx];
-                        av[t >> 2][t & 3] = q < xs ? v : 0.0f;
-                    }
-                }
-                if (a.enc != TN_ENC_NONE && q0 + 31 >= xs) {       // wave-uniform: encoded slots (E rows)
-                    const bool ise = q >= xs && q < a.K0_pad;
-                    const f32x4 *p = reinterpret_cast<const f32x4 *>(rowsE + (ise ? q - xs : 0) * RS + 16 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const f32x4 v = p[e]; if (ise) av[e] = v; }
-                }
+                const int q = 32 * ttk[m] + i;
+                if (q < xs) { cp = ldsX + 16 * h * a.in_dim + q; cstride = a.in_dim; }
+                else if (AUX && q < a.K0_pad) { cp = ldsA + 16 * h * aw + (q - xs); cstride = aw; }
+                else if (!AUX && extra > 0 && q < a.K0_pad) rp = reinterpret_cast<const f32x4 *>(rowsE + (q - xs) * RS + 16 * h);
             } else {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(ldsR + ((l - 1) * H + 32 * ttk[m] + i) * RS + 16 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) av[e] = p[e];
+                rp = reinterpret_cast<const f32x4 *>(ldsR + ((l - 1) * H + 32 * ttk[m] + i) * RS + 16 * h);
             }
+            float gsum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
+                f32x4 gv = gp[e];
+                if (!gok) gv = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                if (l == 0) {
+                    if (cp != nullptr) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[e][u], av[e][u], acc[m]);
-            if (ttk[m] == 0) {
-                float sum = 0.f;
+                        for (int u = 0; u < 4; ++u) av[u] = cp[(4 * e + u) * cstride];
+                    } else if (rp != nullptr) av = rp[e];
+                } else av = rp[e];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sum += (gv[e][0] + gv[e][1]) + (gv[e][2] + gv[e][3]);
-                dbacc[m] += sum;
+                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[u], av[u], acc[m]);
+                gsum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
             }
+            if (ttk[m] == 0) dbacc[m] += gsum;
         }
     }
     // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
@@ -434,6 +450,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// chunk / LDS budget of the wgrad kernel for a descriptor (host)
+struct WgradPlan { int R, Rt, xs, aw, chunks; size_t lds; };
+WgradPlan wgrad_plan(int enc, int in_dim, int K0_pad, int H, int NH) {
+    WgradPlan p;
+    const int extra = extra_rows(enc, in_dim, K0_pad);
+    p.R = stash_rows_w(H, NH, extra); p.Rt = stash_rows(H, NH, extra);
+    p.xs = x_slots(enc, in_dim);
+    p.aw = enc == TN_ENC_AUX_CAT ? K0_pad - in_dim : 0;
+    p.chunks = p.R * 8 + (p.xs > 0 ? 8 * in_dim : 0);           // float4 chunks of workspace rows + x rows per tile
+    p.lds = ((size_t)p.R * 36 + (p.xs > 0 ? 32 * (size_t)in_dim : 0) + 32 * (size_t)p.aw) * 4;
+    return p;
+}
+
 bool v2_supported(const tn_mlp_desc *d) {
     if (!d) return false;
     const int L = d->n_layers, H = d->dims[1];
@@ -445,12 +474,10 @@ bool v2_supported(const tn_mlp_desc *d) {
     const int T = H / 32, Tk0 = (K0_pad + 31) / 32;
     const int tiles = T * Tk0 + (L - 2) * T * T + T;
     if (tiles > 48) return false;                                 // 16 waves x 3 accumulator tiles
-    const int xs = x_slots(d->encoding, d->in_dim);
-    if (xs > 0 && (d->in_dim & 3)) return false;
-    const int R = 2 * (L - 1) * H + 4 + extra_rows(d->encoding, d->in_dim, K0_pad);
-    const int chunks = R * 8 + (xs > 0 ? 8 * d->in_dim : 0);
-    if (chunks > 10 * 1024) return false;                         // prefetch registers of the wgrad kernel
-    if (((size_t)R * 36 + (xs > 0 ? 32 * (size_t)d->in_dim : 0)) * 4 > 160 * 1024) return false;
+    const WgradPlan p = wgrad_plan(d->encoding, d->in_dim, K0_pad, H, L - 1);
+    if (p.xs > 0 && (d->in_dim & 3)) return false;
+    if (p.chunks > 10 * 1024) return false;                       // prefetch registers of the wgrad kernel
+    if (p.lds > 160 * 1024 || p.aw > 64) return false;
     return true;
 }
 
@@ -470,13 +497,13 @@ bool v1_supported(const tn_mlp_desc *d) {
 
 template <int H, int NH>
 int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
-              float *const *gw, float *const *gb, float *gx, float *stash, hipStream_t s)
+              float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s)
 {
     const int64_t n_tiles = (n + 31) / 32;
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     constexpr int WPB = 8;
-    auto kern = mlp_chain_kernel<H, NH, WPB>;
+    auto kern = stashed ? mlp_chain_kernel<H, NH, WPB, true> : mlp_chain_kernel<H, NH, WPB, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
@@ -491,22 +518,23 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     w.Tk0 = (a.K0_pad + 31) / 32;
     w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
     for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
-    const int R = stash_rows<H>(NH, extra_rows(a.enc, a.in_dim, a.K0_pad));
-    const int xs = x_slots(a.enc, a.in_dim);
-    const size_t wlds = ((size_t)R * RS + (xs > 0 ? 32 * (size_t)a.in_dim : 0)) * 4;
+    w.aux_index = a.aux_index; w.aux_stride = a.aux_stride;
+    const WgradPlan wp = wgrad_plan(a.enc, a.in_dim, a.K0_pad, H, NH);
+    const size_t wlds = wp.lds;
     if (wlds > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: workspace tile does not fit LDS");
-    if (xs > 0 && (a.in_dim & 3)) return tn::fail(TN_E_CONFIG, "mlp_bwd: in_dim must be a multiple of 4");
-    const int chunks = R * 8 + (xs > 0 ? 8 * a.in_dim : 0);
+    if (wp.xs > 0 && (a.in_dim & 3)) return tn::fail(TN_E_CONFIG, "mlp_bwd: in_dim must be a multiple of 4");
+    const int chunks = wp.chunks;
     const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * (wlds * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
 #define TN_WGRAD(MAXS_, NW_, NCH_)                                                                                         \
     do {                                                                                                                    \
-        auto wk = mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_>;                                                                \
+        auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, true> : mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, false>; \
         hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);      \
         if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", wlds, hipGetErrorString(we)); return (int)we; } \
         wk<<<dim3((unsigned)wblocks), dim3(NW_ * 64), wlds, s>>>(w, x, aux, n, stash);                                      \
     } while (0)
     if (w.total_tiles <= 8 && chunks <= 4 * 512) TN_WGRAD(1, 8, 4);
     else if (w.total_tiles <= 16 && chunks <= 4 * 1024) TN_WGRAD(1, 16, 4);
+    else if (w.total_tiles <= 32 && chunks <= 5 * 1024) TN_WGRAD(2, 16, 5);
     else if (w.total_tiles <= 32 && chunks <= 6 * 1024) TN_WGRAD(2, 16, 6);
     else if (w.total_tiles <= 48 && chunks <= 10 * 1024) TN_WGRAD(3, 16, 10);
     else return tn::fail(TN_E_CONFIG, "mlp_bwd: configuration outside the wgrad tiling");
@@ -516,13 +544,13 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
 
 template <int H>
 int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
-                float *const *gw, float *const *gb, float *gx, float *stash, hipStream_t s)
+                float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s)
 {
     switch (a.n_layers - 1) {
-    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
-    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
-    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
-    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, s);
+    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
+    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
+    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
+    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
     }
 }
 
@@ -531,18 +559,29 @@ int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const fl
 extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n)
 {
     if (n <= 0 || !desc) return 0;
-    if (!v2_supported(desc)) return v1_supported(desc) ? 0 : tn_mlp_bwd_layers_workspace_bytes(desc, n);
+    if (!v2_supported(desc)) {
+        if (desc->encoding == TN_ENC_AUX_CAT) return 0;
+        return v1_supported(desc) ? 0 : tn_mlp_bwd_layers_workspace_bytes(desc, n);
+    }
     const int H = desc->dims[1], NH = desc->n_layers - 1;
     const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
-    return ((n + 31) / 32) * (int64_t)(2 * NH * H + 4 + extra) * 32 * (int64_t)sizeof(float);
+    return ((n + 31) / 32) * (int64_t)stash_rows(H, NH, extra) * 32 * (int64_t)sizeof(float);
 }
 
 extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                           float *const *grad_weights, float *const *grad_biases, float *grad_x, void *workspace,
                           int64_t workspace_bytes, void *stream)
 {
+    TN_REQUIRE(desc, TN_E_NULL, "tn_mlp_bwd: null descriptor");
     const int64_t need = tn_mlp_bwd_workspace_bytes(desc, n);
-    if (!v2_supported(desc) && !v1_supported(desc)) {          // wide / deep stack: layer-by-layer form
+    const bool stashed = (desc->flags & TN_MLP_STASHED) != 0;
+    const bool v2 = v2_supported(desc);
+    if (stashed || desc->encoding == TN_ENC_AUX_CAT) {
+        TN_REQUIRE(v2, TN_E_CONFIG, "tn_mlp_bwd: TN_MLP_STASHED / TN_ENC_AUX_CAT need a configuration of the two-pass form");
+        if (n == 0) return TN_OK;
+        TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: TN_MLP_STASHED / TN_ENC_AUX_CAT need the workspace");
+    }
+    if (!v2 && !v1_supported(desc)) {                          // wide / deep stack: layer-by-layer form
         if (n == 0) return TN_OK;
         TN_REQUIRE(need > 0, TN_E_CONFIG, "tn_mlp_bwd: unsupported layer configuration");
         TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: this configuration needs the workspace");
@@ -555,11 +594,12 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
     int H = 0;
     if (int rc = plan(desc, a, H)) return rc;
     TN_REQUIRE(x && grad_y && grad_weights && grad_biases, TN_E_NULL, "tn_mlp_bwd: null pointer");
-    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_bwd: dir_cat needs aux (ray directions)");
+    TN_REQUIRE((a.enc != TN_ENC_DIR_CAT && a.enc != TN_ENC_AUX_CAT) || aux, TN_E_NULL, "tn_mlp_bwd: dir_cat / aux_cat need aux");
     TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_bwd: workspace must be 16-byte aligned");
+    TN_REQUIRE(a.enc != TN_ENC_AUX_CAT || ((uintptr_t)aux & 15) == 0, TN_E_ALIGN, "tn_mlp_bwd: aux table must be 16-byte aligned");
     for (int l = 0; l < a.n_layers; ++l)
         TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd: null gradient pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (H == 32) return launch_v2_h<32>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, s);
-    return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, s);
+    if (H == 32) return launch_v2_h<32>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
+    return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
 }

@@ -18,12 +18,14 @@ struct MlpArgs {
     int K[TN_MLP_MAX_LAYERS], N[TN_MLP_MAX_LAYERS];     // true in / out width of each layer
     int lds_floats;
     int accum_gx;          // grad_x += (TN_MLP_ACCUM_GRAD_X)
+    const int *aux_index;  // TN_ENC_AUX_CAT: x row -> aux table row (nullptr: identity)
+    int aux_stride;
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
 __device__ __forceinline__ int layer0_col(const MlpArgs &a, int q) {
-    if (a.enc == TN_ENC_DIR_CAT) {
-        const int pe = 6 * a.n_freqs + 3;
+    if (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) {
+        const int pe = a.K0 - a.in_dim;                    // 6F + 3 for the colour head
         return q < a.in_dim ? pe + q : q - a.in_dim;       // torch order: [PE(d), d, feat]
     }
     return q;
@@ -52,12 +54,15 @@ __device__ inline void stage_weights(const MlpArgs &a, float *lds) {
 //   TN_ENC_NONE    slot q = x[q]
 //   TN_ENC_POSENC  slot q = PE(x)[q]
 //   TN_ENC_DIR_CAT slot q = x[q] (q < in_dim), PE(d)[q-in_dim], d[..], 0 padding
+//   TN_ENC_AUX_CAT slot q = x[q] (q < in_dim), auxrow[q-in_dim] (table row, zero padded to K0_pad)
 __device__ __forceinline__ f32x4 fetch_input(const MlpArgs &a, const float *__restrict__ xrow, const float *aux3,
-                                             bool valid, int g, int h)
+                                             bool valid, int g, int h, const float *__restrict__ auxrow = nullptr)
 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!valid) return v;
     const int q0 = 8 * g + 4 * h;
+    if (a.enc == TN_ENC_AUX_CAT)
+        return q0 < a.in_dim ? *reinterpret_cast<const f32x4 *>(xrow + q0) : *reinterpret_cast<const f32x4 *>(auxrow + (q0 - a.in_dim));
     if (a.enc == TN_ENC_POSENC) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -95,6 +100,31 @@ __device__ __forceinline__ f32x4 load_a4(const float *__restrict__ W, int row, i
 
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;
 
+// ---- activation workspace of the two-pass backward (mlp_bwd2.hip), also written by the training forward ----
+// Rows of [32 samples] floats (128 B) per 32-sample tile:
+//   H_1..H_NH | G_0..G_{NH-1} | g_pre (4) | E (encoded first-layer slots of TN_ENC_DIR_CAT / POSENC that are not plain
+//   x columns) | pre (4, last layer's pre-activation) | ReLU bit masks (2 rows per (layer, 32-feature block))
+// The weight-gradient kernel stages the first stash_rows_w() rows; pre and masks are for the chain kernel only.
+__host__ __device__ inline int x_slots(int enc, int in_dim) { return enc == TN_ENC_POSENC ? 0 : in_dim; }
+__host__ __device__ inline int extra_rows(int enc, int in_dim, int K0_pad) {
+    return (enc == TN_ENC_NONE || enc == TN_ENC_AUX_CAT) ? 0 : K0_pad - x_slots(enc, in_dim);
+}
+__host__ __device__ inline int stash_rows_w(int H, int nh, int extra) { return 2 * nh * H + 4 + extra; }
+__host__ __device__ inline int stash_rows(int H, int nh, int extra) { return stash_rows_w(H, nh, extra) + 4 + 2 * nh * (H / 32); }
+
+// D-layout tile -> workspace rows [feature][32 samples]; two fully used 128-B lines per store instruction
+__device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[(32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = t[r];
+}
+
+__device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (t[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+
 inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
 {
     TN_REQUIRE(d, TN_E_NULL, "mlp: null descriptor");
@@ -106,7 +136,7 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     for (int l = 0; l < L; ++l) TN_REQUIRE(d->weights[l] && d->biases[l], TN_E_NULL, "mlp: null weight / bias pointer");
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
     a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
-    a.freqs = d->freqs;
+    a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride;
     TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
     switch (a.enc) {
     case TN_ENC_NONE: TN_REQUIRE(a.K0 == a.in_dim, TN_E_CONFIG, "mlp: dims[0] must equal in_dim"); break;
@@ -115,6 +145,10 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
         break;
     case TN_ENC_DIR_CAT:
         TN_REQUIRE(a.K0 == a.in_dim + 6 * a.n_freqs + 3, TN_E_CONFIG, "mlp: dir_cat expects dims[0] = in_dim + 6F + 3");
+        break;
+    case TN_ENC_AUX_CAT:
+        TN_REQUIRE(a.K0 > a.in_dim && (a.in_dim & 3) == 0 && (a.aux_stride & 3) == 0 && a.aux_stride >= a.K0_pad - a.in_dim, TN_E_CONFIG,
+                   "mlp: aux_cat expects in_dim % 4 == 0 and aux_stride % 4 == 0, aux_stride >= pad8(dims[0]) - in_dim");
         break;
     default: return tn::fail(TN_E_CONFIG, "mlp: unknown encoding");
     }

@@ -55,11 +55,25 @@ def _workspace(desc: L.MlpDesc, n: int, dev: torch.device, arena: Optional[Arena
     return _alloc(arena, name, (nbytes // 4,), dev), nbytes
 
 
+def _ray_aux(packed: torch.Tensor, info: torch.Tensor, freqs: torch.Tensor, n_freqs: int, arena: Optional[Arena]):
+    """Per-ray inputs of the colour head (models.py:87: cat[PE(d), d]): evaluated once per ray into a table
+    (tn_dir_encode) that the MLP kernels index through the ray id of every sample, instead of 48 sin/cos per sample."""
+    dev = packed.device
+    n, R = packed.size(0), info.size(0)
+    stride = (6 * n_freqs + 3 + 7) & ~7
+    table = _alloc(arena, "aux_table", (R, stride), dev)
+    ray_ids = torch.repeat_interleave(torch.arange(R, dtype=torch.int32, device=dev), info[:, 1].long(), output_size=n)
+    if n > 0:
+        dirs_ray = packed[info[:, 0].long().clamp_(max=n - 1), 3:6].contiguous()     # rays without samples: unused rows
+        L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(freqs), C.c_int(n_freqs), L.ptr(table), C.c_int(stride))
+    return table, ray_ids, stride
+
+
 class _RenderKPlanes(Function):
     @staticmethod
     def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
                 freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool, arena: Optional[Arena],
-                *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                train: bool, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
@@ -69,30 +83,41 @@ class _RenderKPlanes(Function):
         F = kdesc.n_scales * kdesc.channels
         feat = _alloc(arena, "feat", (n, F), dev)
         L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
+        table, ray_ids, stride = _ray_aux(packed, info, freqs, n_freqs, arena)
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, 0, ray_ids, stride)
+        ws_s = ws_r = None
+        sb = rb = 0
+        if train:          # training forward: activations go to the backward's workspace, nothing is recomputed
+            ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
+            ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
         sigma = _alloc(arena, "sigma", (n,), dev)
-        L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
+        if ws_s is not None:
+            L.call("tn_mlp_fwd_stash", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
         steps = _alloc(arena, "steps", (n,), dev).copy_(packed[:, 6])
-        dirs = _alloc(arena, "dirs", (n, 3), dev).copy_(packed[:, 3:6])
         weights = _alloc(arena, "weights", (n,), dev)
         L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                C.c_int64(n), C.c_int64(R))
-        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
         rgbs = _alloc(arena, "rgbs", (n, 3), dev)
-        L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
+        if ws_r is not None:
+            L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
+        else:
+            L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
         out = torch.empty((R, 3), device=dev)
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))
-        ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, dirs, weights, rgbs, *params)
-        ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate)
+        ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
+        ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb)
         ctx.arena = arena
         ctx.param_refs = params if accumulate else None
         return out
 
     @staticmethod
     def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
-        packed, info, bg, freqs, feat, sigma, steps, dirs, weights, rgbs, *params = ctx.saved_tensors
-        n_freqs, n_planes, n_sigma, accumulate = ctx.cfg
+        packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params = ctx.saved_tensors
+        n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb = ctx.cfg
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
@@ -118,25 +143,29 @@ class _RenderKPlanes(Function):
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
                L.ptr(g_w), C.c_int64(n), C.c_int64(R))
         # colour head: grads of its parameters + d/d feat
-        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
+        stashed = L.MLP_STASHED if ws_r is not None else 0
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, stashed, ray_ids, stride)
         nl = len(rgb_p) // 2
         gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[0::2]])
         gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[1::2]])
         g_feat = _alloc(arena, "g_feat", (n, F), dev)
-        ws, ws_bytes = _workspace(rdesc, n, dev, arena, "ws_rgb")
-        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(dirs), L.ptr(g_rgbs), C.c_int64(n), gw, gb, L.ptr(g_feat),
-               L.ptr(ws), C.c_int64(ws_bytes))
+        if ws_r is None:
+            ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
+        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw, gb, L.ptr(g_feat),
+               L.ptr(ws_r), C.c_int64(rb))
         # weights -> sigma
         g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
-        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X)   # g_feat += d sigma / d feat
+        stashed = L.MLP_STASHED if ws_s is not None else 0
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | stashed)   # g_feat += d sigma / d feat
         nl = len(sig_p) // 2
         gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[0::2]])
         gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[1::2]])
-        ws, ws_bytes = _workspace(sdesc, n, dev, arena, "ws_sigma")
+        if ws_s is None:
+            ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
         L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw, gb,
-               L.ptr(g_feat), L.ptr(ws), C.c_int64(ws_bytes))
+               L.ptr(g_feat), L.ptr(ws_s), C.c_int64(sb))
         # plane scatter
         kdesc, keep = _kplanes_desc(planes)
         gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
@@ -145,7 +174,7 @@ class _RenderKPlanes(Function):
                 gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
         L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         grads = [None if in_place else g for (g, in_place) in bufs]
-        return (None, None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def supports(renderer) -> bool:
@@ -164,5 +193,6 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
     arena = None
     if getattr(renderer, "reuse_buffers", False):
         arena = renderer.__dict__.setdefault("_arena", Arena())
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
     return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
-                                len(sig_p), accumulate_into_grad, arena, *planes, *sig_p, *rgb_p)
+                                len(sig_p), accumulate_into_grad, arena, train, *planes, *sig_p, *rgb_p)

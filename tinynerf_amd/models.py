@@ -24,7 +24,7 @@ from . import _lib as L
 # fused MLP plumbing
 # --------------------------------------------------------------------------------------------
 def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,
-              freqs: Optional[torch.Tensor], flags: int = 0) -> L.MlpDesc:
+              freqs: Optional[torch.Tensor], flags: int = 0, aux_index: Optional[torch.Tensor] = None, aux_stride: int = 0) -> L.MlpDesc:
     n_layers = len(params) // 2
     if n_layers > L.TN_MLP_MAX_LAYERS:
         raise RuntimeError(f"MLP with {n_layers} layers exceeds the kernel limit {L.TN_MLP_MAX_LAYERS}")
@@ -35,6 +35,8 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
     d.n_freqs = n_freqs
     d.out_activation = out_act
     d.flags = flags
+    d.aux_index = aux_index.data_ptr() if aux_index is not None else None
+    d.aux_stride = aux_stride
     d.freqs = freqs.data_ptr() if freqs is not None else None
     d.dims[0] = params[0].size(1)
     for l in range(n_layers):

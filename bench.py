@@ -74,12 +74,12 @@ class KernelTimer:
 
         def timed_call(name, device, *args):
             tag = name
-            if name in ("tn_mlp_fwd", "tn_mlp_bwd"):
+            if name in ("tn_mlp_fwd", "tn_mlp_fwd_stash", "tn_mlp_bwd"):
                 desc = args[0]._obj
-                tag = name + (":rgb" if desc.encoding == L.ENC_DIR_CAT else ":sigma")
+                tag = name.replace("_stash", "") + (":rgb" if desc.encoding in (L.ENC_DIR_CAT, L.ENC_AUX_CAT) else ":sigma")
             if tag not in KERNEL_MODEL or not timer.enabled:
                 return orig(name, device, *args)
-            rows = int(args[3].value) if name.startswith("tn_kplanes") else int(args[3].value if name == "tn_mlp_fwd" else args[4].value)
+            rows = int(args[3].value) if name.startswith("tn_kplanes") else int(args[3].value if name.startswith("tn_mlp_fwd") else args[4].value)
             s = torch.cuda.current_stream(device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)

@@ -75,6 +75,33 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
         f32x16 act[T];
 #pragma unroll
         for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(B0, ob, h);
+        // Plain x columns (+ aux-table columns): the inputs are loaded UNCONDITIONALLY from clamped addresses, two groups
+        // ahead.  (A load whose result is merged with a constant -- `valid ? x[..] : 0` -- makes the compiler wait for
+        // it at the merge, which turns the prefetch into a blocking load per group.)  Rows past n read row 0, slots past
+        // the input width read slot 0: both only ever meet zero weights or discarded outputs.
+        const bool fast_in = WLDS && (a.enc == TN_ENC_AUX_CAT || (a.enc == TN_ENC_NONE && (a.in_dim & 3) == 0));
+        if (fast_in) {
+            const float *arow = a.enc == TN_ENC_AUX_CAT
+                                    ? aux + (int64_t)(a.aux_index ? a.aux_index[valid ? row : 0] : (valid ? row : 0)) * a.aux_stride
+                                    : xrow;
+            auto in_ptr = [&](int g) {
+                const int q0 = 8 * (g < G0 ? g : G0 - 1) + 4 * h;
+                const float *p = q0 < a.in_dim ? xrow + q0 : (a.enc == TN_ENC_AUX_CAT ? arow + (q0 - a.in_dim) : xrow);
+                return reinterpret_cast<const f32x4 *>(p);
+            };
+            f32x4 b0 = *in_ptr(0), b1 = *in_ptr(1);
+            for (int g = 0; g < G0; ++g) {
+                const f32x4 b2 = *in_ptr(g + 2);
+                f32x4 w[T];
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b0[u], act[ob]);
+                b0 = b1; b1 = b2;
+            }
+        } else {
         f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h, auxrow);
         for (int g = 0; g < G0; ++g) {
             f32x4 bn = {0.f, 0.f, 0.f, 0.f};
@@ -106,6 +133,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
                 }
             }
             b = bn;
+        }
         }
 #pragma unroll
         for (int ob = 0; ob < T; ++ob) {
@@ -222,9 +250,18 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
-    if (wlds) {
+    if (wlds && stash) {
+        if constexpr (H <= 64) {
+            constexpr int WPS = 12;           // stash variant: 3 waves per SIMD keep it inside the 170-VGPR budget (no spills)
+            auto kern = mlp_fwd_kernel<H, true, WPS, true>;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPS * 64)));
+            const int64_t blocks = std::min<int64_t>((n_tiles + WPS - 1) / WPS, 256 * per_cu);
+            kern<<<dim3((unsigned)blocks), dim3(WPS * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash);
+        } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: hidden width must be 32 or 64");
+    } else if (wlds) {
         auto kern = mlp_fwd_kernel<H, true, WPB, false>;
-        if constexpr (H <= 64) { if (stash) kern = mlp_fwd_kernel<H, true, WPB, true>; }
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));

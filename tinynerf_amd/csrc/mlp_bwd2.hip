@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
                                                             int64_t n, const float *__restrict__ stash)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int lane = tn::lane_id(), i_ = lane & 31, h_ = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: tile ownership lives in SGPRs
     const int64_t n_tiles = (n + 31) >> 5;
     const int xs = x_slots(a.enc, a.in_dim);
@@ -337,31 +337,28 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
     // one sample: 32 samples x 16 float4 slots = 512 chunks, one per thread of the first 8 waves
     f32x4 pre[NCH];
     f32x4 preA = {0.f, 0.f, 0.f, 0.f};
+    // Every load below is unconditional (addresses clamped into valid memory, results of idle slots never committed):
+    // a load whose result is merged with a constant at a control-flow join makes the compiler wait for it right there
+    // (s_waitcnt vmcnt(0) after every load), which serialises the prefetch with the MFMA phase it is meant to overlap.
     auto prefetch = [&](int64_t tile) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32);
         const int64_t x0 = tile * 32 * (int64_t)a.in_dim;          // first float of the tile's x rows
-        const int64_t xend = n * (int64_t)a.in_dim;
+        const int64_t xlast = n * (int64_t)a.in_dim - 4;           // in_dim % 4 == 0: chunks never straddle the end
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = threadIdx.x + k * NW * 64;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c < row_chunks) v = src[c];
-            else if (c < row_chunks + x_chunks) {
-                const int64_t e = x0 + 4 * (int64_t)(c - row_chunks);
-                if (e + 3 < xend) v = *reinterpret_cast<const f32x4 *>(x + e);
-                else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = e + u < xend ? x[e + u] : 0.0f;
-                }
-            }
-            pre[k] = v;
+            int64_t e = x0 + 4 * (int64_t)(c - row_chunks);
+            e = e < 0 ? 0 : (e > xlast ? xlast : e);
+            const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
+            const f32x4 *pr = src + (c < row_chunks ? c : 0);
+            pre[k] = *((c < row_chunks || xs == 0) ? pr : px);
         }
         if constexpr (AUX) {
-            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
-            const int64_t r_ = tile * 32 + s_;
-            preA = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (threadIdx.x < 512 && r_ < n && 4 * part < aw)
-                preA = *reinterpret_cast<const f32x4 *>(aux + (int64_t)(a.aux_index ? a.aux_index[r_] : r_) * a.aux_stride + 4 * part);
+            const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;
+            int64_t r_ = tile * 32 + s_;
+            r_ = r_ < n ? r_ : n - 1;
+            if (a.aux_index) r_ = a.aux_index[r_];
+            preA = *reinterpret_cast<const f32x4 *>(aux + r_ * a.aux_stride + (4 * part < aw ? 4 * part : 0));
         }
     };
     auto commit = [&]() {
@@ -383,6 +380,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
         commit();
         __syncthreads();
         if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);      // in flight during the MFMAs below
+        int i = i_, h = h_;
+        asm volatile("" : "+v"(i), "+v"(h));     // per-lane LDS addresses are rebuilt per tile, not kept live (spills)
         const float *rowsE = ldsR + (2 * NH * H + 4) * RS;
 #pragma unroll
         for (int m = 0; m < MAXS; ++m) {
@@ -424,6 +423,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
         }
     }
     // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
+    const int i = i_, h = h_;
 #pragma unroll
     for (int m = 0; m < MAXS; ++m) {
         const int l = tl[m];
@@ -534,6 +534,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     } while (0)
     if (w.total_tiles <= 8 && chunks <= 4 * 512) TN_WGRAD(1, 8, 4);
     else if (w.total_tiles <= 16 && chunks <= 4 * 1024) TN_WGRAD(1, 16, 4);
+    else if (w.total_tiles <= 24 && chunks <= 7 * 768) TN_WGRAD(2, 12, 7);     // 12 waves x 2 tiles: 170-VGPR budget, no spills
     else if (w.total_tiles <= 32 && chunks <= 5 * 1024) TN_WGRAD(2, 16, 5);
     else if (w.total_tiles <= 32 && chunks <= 6 * 1024) TN_WGRAD(2, 16, 6);
     else if (w.total_tiles <= 48 && chunks <= 10 * 1024) TN_WGRAD(3, 16, 10);

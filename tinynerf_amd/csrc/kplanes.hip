@@ -66,7 +66,7 @@ constexpr int GS = 36;                                   // floats per tile row:
 constexpr int KP_WAVE_LDS = 32 * GS + 2 * 4 * 32;        // tile + offsets + weights (floats)
 
 template <int NV>
-__global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
+__global__ __launch_bounds__(256, 3) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
                                                           int64_t n, const float *__restrict__ grad_feat)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * KP_WAVE_LDS];
@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256, 4) void kplanes_bwd_kernel(KpArgs a, const flo
                 float u, v;
                 tn::pair_uv(xs, p, u, v);
                 t[p] = tn::plane_taps(u, v, a.H[s], a.W[s], C);
-                if (a.planes[s][p]) tn::plane_gather<NV>(a.planes[s][p], t[p], h * (C / 2), val[p]);
-                else {
+                if (a.planes[s][p]) {
+                    tn::plane_gather<NV>(a.planes[s][p], t[p], h * (C / 2), val[p]);
+                    __builtin_amdgcn_sched_barrier(0);      // one plane's 16 loads in flight at a time (register budget)
+                } else {
 #pragma unroll
                     for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
                 }

@@ -43,21 +43,28 @@ __device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, 
     return t;
 }
 
-// interpolate NV float4 groups (channels c0 .. c0+4*NV) of one plane
+// interpolate NV float4 groups (channels c0 .. c0+4*NV) of one plane.  All 4*NV loads are unconditional (an
+// out-of-bounds tap reads texel 0 with weight 0): a load under `if (in bounds)` has to be waited for at the end of
+// that branch, which serialises the four taps' L2 latencies instead of overlapping all loads of a plane.
 template <int NV>
 __device__ __forceinline__ void plane_gather(const float *__restrict__ plane, const PlaneTaps &t, int c0, f32x4k (&out)[NV]) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = f32x4k{0.f, 0.f, 0.f, 0.f};
+    f32x4k tex[4][NV];
+    float w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (t.off[k] >= 0) {
-            const f32x4k *p = reinterpret_cast<const f32x4k *>(plane + t.off[k] + c0);
+        const bool in = t.off[k] >= 0;
+        const f32x4k *p = reinterpret_cast<const f32x4k *>(plane + (in ? t.off[k] : 0) + c0);
+        w[k] = in ? t.w[k] : 0.0f;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const f32x4k tex = p[v];
-                out[v] += tex * t.w[k];
-            }
-        }
+        for (int v = 0; v < NV; ++v) tex[k][v] = p[v];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        f32x4k acc = tex[0][v] * w[0];          // same order as before: ((0 + t0 w0) + t1 w1) + ...
+        acc += tex[1][v] * w[1];
+        acc += tex[2][v] * w[2];
+        acc += tex[3][v] * w[3];
+        out[v] = acc;
     }
 }
 

@@ -503,12 +503,14 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     constexpr int WPB = 8;
-    auto kern = stashed ? mlp_chain_kernel<H, NH, WPB, true> : mlp_chain_kernel<H, NH, WPB, false>;
+    constexpr int WPS = 12;        // stashed chain: no forward -> fewer live registers -> 3 waves per SIMD
+    const int wpb = stashed ? WPS : WPB;
+    auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
-    const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
-    kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));
+    const int64_t blocks = std::min<int64_t>((n_tiles + wpb - 1) / wpb, 256 * per_cu);
+    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash);
     if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
 
     WgradArgs w;

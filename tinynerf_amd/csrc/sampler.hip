@@ -199,8 +199,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_mask_kernel(
 }
 
 // Exclusive int32 scan of the per-ray counts (reference core.py:179-181).  One workgroup of 1024
-// threads sweeps the rays in tiles of 1024 with a running carry: R is 10^3..10^6, the pass moves
-// 12 B/ray and is never the bottleneck.
+// threads sweeps the rays in tiles of 4096 (4 consecutive rays per thread) with a running carry: R is
+// 10^3..10^6, the pass moves 12 B/ray; it sits right behind the step's host read-back, so its latency counts.
 __global__ __launch_bounds__(1024) void sample_scan_kernel(
     const int32_t *__restrict__ counts, int64_t n_rays, const int32_t *__restrict__ base_offset,
     int32_t *__restrict__ info, int32_t *__restrict__ total)
@@ -211,10 +211,13 @@ __global__ __launch_bounds__(1024) void sample_scan_kernel(
     const int32_t base = base_offset ? base_offset[0] : 0;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int64_t tile = 0; tile < n_rays; tile += 1024) {
-        const int64_t r = tile + threadIdx.x;
-        const int32_t c = (r < n_rays) ? counts[r] : 0;
-        int32_t v = c;
+    for (int64_t tile = 0; tile < n_rays; tile += 4096) {
+        const int64_t r0 = tile + 4 * (int64_t)threadIdx.x;
+        int32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (r0 + u < n_rays) ? counts[r0 + u] : 0;
+        const int32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+        int32_t v = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int32_t u = __shfl_up(v, o, 64);
@@ -225,9 +228,11 @@ __global__ __launch_bounds__(1024) void sample_scan_kernel(
         int32_t wave_off = 0;
         for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
         const int32_t carry = carry_s;
-        if (r < n_rays) {
-            info[2 * r] = base + carry + wave_off + v - c;
-            info[2 * r + 1] = c;
+        int32_t run = base + carry + wave_off + v - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u < n_rays) { info[2 * (r0 + u)] = run; info[2 * (r0 + u) + 1] = c[u]; }
+            run += c[u];
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wave_off + v;

@@ -139,7 +139,9 @@ class Trainer:
         cfg, dev = self.cfg, self.device
         B, S = cfg.batch_size, cfg.n_samples
         n_chunks = (S + 63) // 64
-        n_b = n_b or min(4096, max(2, int(self._k_guess * 1.5) + 2))
+        # candidate block: the rule trips after k loader batches and k drifts by a batch or two between steps; a block that
+        # turns out too small is redrawn at twice the size (build_batch), so the margin only has to cover the drift
+        n_b = n_b or min(4096, max(2, int(self._k_guess * 1.12) + 3))
         if cfg.deterministic:
             idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
         else:

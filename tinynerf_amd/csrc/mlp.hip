@@ -90,16 +90,22 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
                 return reinterpret_cast<const f32x4 *>(p);
             };
             f32x4 b0 = *in_ptr(0), b1 = *in_ptr(1);
+            f32x4 w[T], wn[T];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 4 * h, a.K0, a.stride[0]);
             for (int g = 0; g < G0; ++g) {
                 const f32x4 b2 = *in_ptr(g + 2);
-                f32x4 w[T];
+                const int gn = g + 1 < G0 ? g + 1 : g;           // weights of the next group, requested before this group's MFMAs
 #pragma unroll
-                for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 8 * g + 4 * h, a.K0, a.stride[0]);
+                for (int ob = 0; ob < T; ++ob) wn[ob] = load_a4<true>(W0, 32 * ob + j, 8 * gn + 4 * h, a.K0, a.stride[0]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], b0[u], act[ob]);
+                __builtin_amdgcn_sched_barrier(0);
                 b0 = b1; b1 = b2;
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) w[ob] = wn[ob];
             }
         } else {
         f32x4 b = fetch_input(a, xrow, aux3, valid, 0, h, auxrow);

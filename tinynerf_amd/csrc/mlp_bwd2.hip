@@ -68,6 +68,33 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     const int G0 = a.K0_pad >> 3;
     const int out = a.out_dim;
 
+    // STASHED: the per-tile inputs (ReLU masks, last pre-activation, output gradient) of the NEXT tile are requested at the
+    // top of the current one.  VMEM operations of a wave retire in order, so a load issued after a tile's ~150 row stores
+    // could only be consumed once all of them had drained: one full store round trip per tile, on every wave.
+    unsigned nmask[NH][T];
+    float npre[4], ngy[4];
+    const int extra_ = extra_rows(a.enc, a.in_dim, a.K0_pad);
+    auto fetch_tile = [&](int64_t t) {
+        const float *q = stash + t * (int64_t)(stash_rows(H, NH, extra_) * 32) + stash_rows_w(H, NH, extra_) * 32;
+        const unsigned *mm = reinterpret_cast<const unsigned *>(q + 4 * 32);
+#pragma unroll
+        for (int l = 0; l < NH; ++l)
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) nmask[l][ob] = mm[(l * T + ob) * 64 + lane];
+        int64_t r = t * 32 + j_;
+        r = r < n ? r : n - 1;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int oc = o < out ? o : out - 1;          // unconditional loads (see mlp.hip): duplicates are ignored
+            npre[o] = q[oc * 32 + j_];
+            ngy[o] = gy[r * out + oc];
+        }
+    };
+    if constexpr (STASHED) {
+        const int64_t t0 = (int64_t)blockIdx.x * WPB + wave;
+        fetch_tile(t0 < n_tiles ? t0 : n_tiles - 1);
+    }
+
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
         asm volatile("" : "+v"(j), "+v"(h));           // keep per-lane LDS addresses out of LICM's reach
@@ -90,16 +117,17 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
             for (int l = 0; l < NH; ++l)
 #pragma unroll
-                for (int ob = 0; ob < T; ++ob) mask[l][ob] = stM[(l * T + ob) * 64 + lane];
+                for (int ob = 0; ob < T; ++ob) mask[l][ob] = nmask[l][ob];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                gp[o] = 0.0f;
-                if (o < out) {
-                    const float pre = stQ[o * 32 + j];
-                    gp[o] = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
-                }
-                if (h == 0) stP[o * 32 + j] = gp[o];
+            for (int o = 0; o < 4; ++o) gp[o] = (valid && o < out) ? ngy[o] * act_grad(npre[o], a.out_act) : 0.0f;
+            {
+                const int64_t tn_ = tile + (int64_t)gridDim.x * WPB;
+                fetch_tile(tn_ < n_tiles ? tn_ : n_tiles - 1);       // before this tile's stores
             }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (h == 0) stP[o * 32 + j] = gp[o];
+            (void)stQ; (void)stM;
         } else {
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
         float aux3[3] = {0.f, 0.f, 0.f};
@@ -196,19 +224,32 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             for (int kt = 0; kt < T; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Gn[kt][r] = 0.0f;
+            // software pipeline over the 4T groups (tn_, q): operands of group g+1 are requested before group g's MFMAs
+            {
+                constexpr int NG = 4 * T;
+                float cur[T][4], nxt[T][4];
 #pragma unroll
-            for (int tn_ = 0; tn_ < T; ++tn_) {
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float w[T][4];
+                    for (int kt = 0; kt < T; ++kt) cur[kt][u] = Wl[(4 * h + u) * sl + 32 * kt + j];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int tn_ = g >> 2, q = g & 3;
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int kt = 0; kt < T; ++kt) nxt[kt][u] = Wl[(8 * (g + 1) + 4 * h + u) * sl + 32 * kt + j];
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int kt = 0; kt < T; ++kt) w[kt][u] = Wl[(32 * tn_ + 8 * q + 4 * h + u) * sl + 32 * kt + j];
+                        for (int kt = 0; kt < T; ++kt) Gn[kt] = tn::mfma32(cur[kt][u], G[tn_][4 * q + u], Gn[kt]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int kt = 0; kt < T; ++kt) Gn[kt] = tn::mfma32(w[kt][u], G[tn_][4 * q + u], Gn[kt]);
+                        for (int kt = 0; kt < T; ++kt) cur[kt][u] = nxt[kt][u];
                 }
             }
 #pragma unroll
@@ -231,13 +272,25 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                {
+                    constexpr int NG = 4 * T;
+                    float cur[4], nxt[4];
 #pragma unroll
-                for (int tn_ = 0; tn_ < T; ++tn_)
+                    for (int u = 0; u < 4; ++u) cur[u] = W0[(4 * h + u) * s0 + 32 * kt + j];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int g = 0; g < NG; ++g) {
+                        const int tn_ = g >> 2, q = g & 3;
+                        if (g + 1 < NG) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            acc = tn::mfma32(W0[(32 * tn_ + 8 * q + 4 * h + u) * s0 + 32 * kt + j], G[tn_][4 * q + u], acc);
+                            for (int u = 0; u < 4; ++u) nxt[u] = W0[(8 * (g + 1) + 4 * h + u) * s0 + 32 * kt + j];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc = tn::mfma32(cur[u], G[tn_][4 * q + u], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                    }
+                }
                 tn::pin16(acc);
                 if (valid) {
 #pragma unroll
@@ -503,7 +556,8 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     const size_t lds_bytes = (size_t)a.lds_floats * 4;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     constexpr int WPB = 8;
-    constexpr int WPS = 12;        // stashed chain: no forward -> fewer live registers -> 3 waves per SIMD
+    constexpr int WPS = NH == 1 ? 10 : 16;   // stashed chain: no forward -> ~100 live registers: 4 waves per SIMD, or 2 x 10
+                                             // waves per CU for the single-hidden-layer head (25 KB of LDS)
     const int wpb = stashed ? WPS : WPB;
     auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

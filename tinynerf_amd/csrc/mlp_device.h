@@ -60,22 +60,30 @@ __device__ __forceinline__ void hidden_layer(const float *__restrict__ W, const 
                                              f32x16 (&x)[H / 32], int i, int h)
 {
     constexpr int T = H / 32;
+    constexpr int NG = 4 * T;               // groups of 4 reduction steps; group g = (kb, q)
     f32x16 y[T];
 #pragma unroll
     for (int ob = 0; ob < T; ++ob) y[ob] = bias_tile(bias, ob, h);
+    // software pipeline: the A operands of group g+1 are requested before the MFMAs of group g are issued (left to
+    // itself the compiler sinks every ds_read to just before its first use: read -> wait -> 2T MFMAs -> read -> ...)
+    f32x4 cur[T], nxt[T];
 #pragma unroll
-    for (int kb = 0; kb < T; ++kb) {
+    for (int ob = 0; ob < T; ++ob) cur[ob] = *reinterpret_cast<const f32x4 *>(W + (32 * ob + i) * stride + 4 * h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a[T];
+    for (int g = 0; g < NG; ++g) {
+        const int kb = g >> 2, q = g & 3;
+        if (g + 1 < NG) {
 #pragma unroll
             for (int ob = 0; ob < T; ++ob)
-                a[ob] = *reinterpret_cast<const f32x4 *>(W + (32 * ob + i) * stride + 32 * kb + 8 * q + 4 * h);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int ob = 0; ob < T; ++ob) y[ob] = mfma32(a[ob][u], x[kb][4 * q + u], y[ob]);
+                nxt[ob] = *reinterpret_cast<const f32x4 *>(W + (32 * ob + i) * stride + 8 * (g + 1) + 4 * h);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) y[ob] = mfma32(cur[ob][u], x[kb][4 * q + u], y[ob]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) cur[ob] = nxt[ob];
     }
 #pragma unroll
     for (int ob = 0; ob < T; ++ob) { pin16(y[ob]); x[ob] = relu16(y[ob]); }

@@ -114,8 +114,9 @@ __host__ __device__ inline int stash_rows(int H, int nh, int extra) { return sta
 
 // D-layout tile -> workspace rows [feature][32 samples]; two fully used 128-B lines per store instruction
 __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
+    float *base = rows + (32 * ob + 4 * h) * 32 + j;       // one address per tile; the 16 rows are immediate offsets
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rows[(32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = t[r];
+    for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * 32] = t[r];
 }
 
 __device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {

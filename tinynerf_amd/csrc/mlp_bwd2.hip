@@ -52,7 +52,9 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 // ------------------------------------------------------------------------------------------------
 // STASHED: the training forward (tn_mlp_fwd_stash) already wrote H_l, the ReLU masks and the pre-activation of the
 // last layer; the kernel starts at the output gradient.
-template <int H, int NH, int WPB, bool STASHED>
+// ACCUM (with STASHED, in_dim % 32 == 0): grad_x += ...; the old values of the next 32-column block are requested before the
+// stores of the current one, for the same in-order-retirement reason as the tile prefetch below.
+template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
                                                              float *__restrict__ stash)
@@ -267,11 +269,22 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
             const int n_kt = (a.in_dim + 31) >> 5;
+            const int64_t rowc = row < n ? row : n - 1;
+            f32x4 old[4], oldn[4];
+            if constexpr (ACCUM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 8 * q + 4 * h);
+            }
 #pragma clang loop unroll(disable)
             for (int kt = 0; kt < n_kt; ++kt) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                if constexpr (ACCUM) {
+                    const int ktn = kt + 1 < n_kt ? kt + 1 : kt;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * ktn + 8 * q + 4 * h);
+                }
                 {
                     constexpr int NG = 4 * T;
                     float cur[4], nxt[4];
@@ -292,7 +305,19 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     }
                 }
                 tn::pin16(acc);
-                if (valid) {
+                if constexpr (ACCUM) {
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = old[q];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] += acc[4 * q + u];
+                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + 32 * kt + 8 * q + 4 * h) = v;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) old[q] = oldn[q];
+                } else if (valid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int f0 = 32 * kt + 8 * q + 4 * h;
@@ -560,6 +585,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
                                              // waves per CU for the single-hidden-layer head (25 KB of LDS)
     const int wpb = stashed ? WPS : WPB;
     auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
+    if (stashed && a.accum_gx && gx != nullptr && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));

@@ -195,6 +195,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / reps
         packed, info, target, _ = tr.build_batch()
+        packed, info, target = packed.clone(), info.clone(), target.clone()    # build_batch hands out views of reused buffers
         nb = packed.size(0)
         t_samp = timed(lambda: tr.build_batch())
         with torch.no_grad():
@@ -226,9 +227,9 @@ def main():
                         algorithmic_per_row=unit_work)
             # HBM-side bytes per launch from the committed PMC passes (scripts/pmc.sh); they cannot be collected live
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v4.json")))
                 roof["traffic"] = pmc["per_entry"].get(dom)
-                roof["traffic_source"] = "profiles/round1_pmc_traffic.json"
+                roof["traffic_source"] = "profiles/round1_pmc_traffic_v4.json"
             except Exception:
                 pass
         line = {

@@ -6,7 +6,7 @@ tag=${1:-gaps}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 rm -rf /tmp/gaps_$tag "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps_$tag -o $tag -- python3 bench.py --no-cpu-baseline --no-stages "$@" > "$out/bench.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps_$tag -o $tag -- python3 bench.py --no-cpu-baseline --no-stages "$@" > "$out/bench.log" 2>&1
 f=$(find /tmp/gaps_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY' | tee "$out/gaps.txt"
 import csv, sys, collections

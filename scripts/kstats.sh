@@ -4,7 +4,7 @@ set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/ks_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o $tag -- python3 "$@" 2>&1 | grep -v "^W2\|rocprofiler" | tail -3
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o $tag -- python3 "$@" 2>&1 | grep -v "^W2\|rocprofiler" | tail -3
 python3 - /tmp/ks_$tag <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag; rm -rf "$out"; mkdir -p "$out"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_$ctr.log" 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_$ctr.log" 2>&1
   f=$(find /tmp/pmc_$ctr -name "*counter_collection.csv" | head -1)
   ls -la /tmp/pmc_$ctr/* | head -5
   python3 - "$f" "$ctr" "$out" <<'PY'

@@ -4,7 +4,7 @@ set -u
 tag=$1; ctrs=$2; pat=$3; shift 4
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/pk_$tag
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pk_$tag -o p -- "$@" > /tmp/pk_$tag.log 2>&1
+timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pk_$tag -o p -- "$@" > /tmp/pk_$tag.log 2>&1
 f=$(find /tmp/pk_$tag -name "*counter_collection.csv" | head -1)
 python3 - "$f" "$pat" <<'PY'
 import csv, sys, collections

@@ -77,6 +77,7 @@ class CobafaDesc(C.Structure):
 
 
 _lib: Optional[C.CDLL] = None
+_TRACE = bool(os.environ.get("TN_TRACE"))
 
 
 def lib() -> C.CDLL:
@@ -130,3 +131,7 @@ def call(name: str, device: torch.device, *args) -> None:
     with torch.cuda.device(device):
         rc = fn(*args, stream(device))
     check(rc, name)
+    if _TRACE:                      # TN_TRACE=1: synchronise after every launch and name it (fault bisection)
+        import sys
+        print("tn:", name, file=sys.stderr, flush=True)
+        torch.cuda.synchronize(device)

@@ -164,7 +164,8 @@ class Trainer:
 
     @torch.no_grad()
     def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
-        """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass."""
+        """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass.
+        packed / info are views of the trainer's reused scratch: valid until the next build_batch() (clone to keep)."""
         dev, B = self.device, self.cfg.batch_size
         while True:
             if self._pending is None:

@@ -526,6 +526,189 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad kernel, double-buffered form (encodings without E rows: TN_ENC_NONE, TN_ENC_AUX_CAT)
+//
+// The single-buffer kernel above spends every iteration as  commit | barrier | MFMA phase | barrier , with the next
+// tile's loads in flight during the MFMA phase only; the tile needs longer from HBM (~25 MB chip-wide per iteration)
+// than the MFMAs take, so the difference is exposed on every iteration.  Here only the rows every wave shares (G_l,
+// g_pre, x, aux: 56 KB) are staged, in TWO LDS buffers, and each wave reads the H_{l-1} rows of its own tiles straight
+// from the workspace in MFMA operand layout (64 contiguous bytes per lane).  Iteration t: write tile t+1 into the other
+// buffer, request tile t+2 (staging registers), multiply tile t (requesting each slot's H operands of tile t+1 right
+// after that slot's operands have been copied out), ONE barrier.  Every
+// load has a full iteration to arrive.  All loads are unconditional (clamped tile indices) so that the compiler keeps
+// exact vmcnt counts instead of draining the queue at control-flow joins.
+// ------------------------------------------------------------------------------------------------
+template <int H, int NH, int MAXS, int NW, int NCH, bool AUX>
+__global__ __launch_bounds__(NW * 64) void mlp_wgrad3_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+                                                             int64_t n, const float *__restrict__ stash)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = tn::lane_id(), i_ = lane & 31, h_ = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int xs = a.in_dim;
+    constexpr int RG = NH * H + 4;                        // staged workspace rows: G_0 .. G_{NH-1}, g_pre
+    const int Rt = stash_rows(H, NH, 0);
+    constexpr int g_chunks = RG * 8;
+    const int x_chunks = (32 * a.in_dim) / 4;
+    const int aw = AUX ? a.K0_pad - a.in_dim : 0;
+    const int buf_floats = RG * RS + 32 * a.in_dim + 32 * aw;
+    f32x16 acc[MAXS];
+    float dbacc[MAXS];
+    int tl[MAXS], ttn[MAXS], ttk[MAXS];
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+        dbacc[m] = 0.0f;
+        tl[m] = -1; ttn[m] = 0; ttk[m] = 0;
+        const int id = wave + NW * m;
+        if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
+    }
+    f32x4 pre[NCH];
+    f32x4 preA = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hn[MAXS][4];
+    int aidx = 0;                                          // aux-table row of sample (threadIdx.x >> 4) & 31 of the tile fetched next
+    auto prefetch = [&](int64_t tile, int64_t tile_after) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + NH * H * 32);
+        const int64_t x0 = tile * 32 * (int64_t)a.in_dim;
+        const int64_t xlast = n * (int64_t)a.in_dim - 4;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            int64_t e = x0 + 4 * (int64_t)(c - g_chunks);
+            e = e < 0 ? 0 : (e > xlast ? xlast : e);
+            const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
+            const f32x4 *pr = src + (c < g_chunks ? c : 0);
+            pre[k] = *(c < g_chunks ? pr : px);
+        }
+        if constexpr (AUX) {
+            // the table row of this thread's sample was looked up one call earlier (aidx): a dependent index load here
+            // would have to drain every load issued above before the row address is known
+            const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;
+            preA = *reinterpret_cast<const f32x4 *>(aux + (int64_t)aidx * a.aux_stride + (4 * part < aw ? 4 * part : 0));
+            int64_t r_ = tile_after * 32 + s_;
+            r_ = r_ < n ? r_ : n - 1;
+            aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
+        }
+    };
+    // branch-free: idle slots write a scratch line behind the buffers (divergent branches around the ds_writes make the
+    // compiler's vmcnt bookkeeping conservative: it then waits for loads issued AFTER the ones being committed)
+    float *dummy = lds + 2 * buf_floats;       // one shared slot (wave-uniform address: no per-lane register)
+    auto commit = [&](float *buf) {
+        float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            float *dst = c < g_chunks ? buf + (c >> 3) * RS + (c & 7) * 4 : (c < g_chunks + x_chunks ? ldsX + 4 * (c - g_chunks) : dummy);
+            *reinterpret_cast<f32x4 *>(dst) = pre[k];
+        }
+        if constexpr (AUX) {
+            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
+            float *dst = (threadIdx.x < 512 && 4 * part < aw) ? ldsA + s_ * aw + 4 * part : dummy;
+            *reinterpret_cast<f32x4 *>(dst) = preA;
+        }
+    };
+    auto fetch_h1 = [&](int64_t tile, int m) {             // H_{l-1} rows of tile slot m, operand layout, sample tile `tile`
+        const int l = tl[m];
+        const int hrow = (l >= 1 ? (l - 1) * H + 32 * ttk[m] : 0) + i_;
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + hrow * 32 + 16 * h_);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hn[m][e] = p[e];
+    };
+    const int64_t last = n_tiles - 1;
+    int64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;                           // (grid <= n_tiles: never taken; keeps the clamps below valid)
+    if constexpr (AUX) {
+        int64_t r_ = tile * 32 + ((threadIdx.x >> 4) & 31);
+        r_ = r_ < n ? r_ : n - 1;
+        aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
+    }
+    {
+        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
+        prefetch(tile, t1 < last ? t1 : last);
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) fetch_h1(tile, m);
+        commit(lds);
+        __syncthreads();
+        prefetch(t1 < last ? t1 : last, t2 < last ? t2 : last);
+    }
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        int i = i_, h = h_;
+        asm volatile("" : "+v"(i), "+v"(h));
+        float *buf = lds + cur * buf_floats;
+        float *nbuf = lds + (cur ^ 1) * buf_floats;
+        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x, t3 = t2 + gridDim.x;
+        commit(nbuf);                                      // tile t+1 (a duplicate of the last tile past the end: never read)
+        prefetch(t2 < last ? t2 : last, t3 < last ? t3 : last);
+        const int64_t t1c = t1 < last ? t1 : last;
+        const float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+#pragma unroll
+        for (int m = 0; m < MAXS; ++m) {
+            const int l = tl[m];
+            if (l < 0) continue;
+            const int grow = l < NH ? l * H + 32 * ttn[m] + i : NH * H + (i < 4 ? i : 0);
+            const f32x4 *gp = reinterpret_cast<const f32x4 *>(buf + grow * RS + 16 * h);
+            f32x4 hc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hc[e] = hn[m][e];
+            fetch_h1(t1c, m);                              // this slot's operands of the next sample tile: a full iteration to arrive
+            const bool gok = l < NH || i < 4;
+            const float *cp = nullptr;
+            int cstride = 0;
+            if (l == 0) {
+                const int q = 32 * ttk[m] + i;
+                if (q < xs) { cp = ldsX + 16 * h * a.in_dim + q; cstride = a.in_dim; }
+                else if (AUX && q < a.K0_pad) { cp = ldsA + 16 * h * aw + (q - xs); cstride = aw; }
+            }
+            float gsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 gv = gp[e];
+                if (!gok) gv = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                if (l == 0) {
+                    if (cp != nullptr) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) av[u] = cp[(4 * e + u) * cstride];
+                    }
+                } else av = hc[e];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[u], av[u], acc[m]);
+                gsum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+            }
+            if (ttk[m] == 0) dbacc[m] += gsum;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
+    const int i = i_, h = h_;
+#pragma unroll
+    for (int m = 0; m < MAXS; ++m) {
+        const int l = tl[m];
+        if (l < 0) continue;
+        tn::pin16(acc[m]);
+        const int Nl = a.N[l], Kl = a.K[l];
+        const int k = 32 * ttk[m] + i;
+        const bool kok = k < Kl;
+        const int kc = kok ? (l == 0 ? wg_col0(a, k) : k) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = 32 * ttn[m] + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (kok && nn < Nl) atomicAdd(&a.gW[l][(int64_t)nn * Kl + kc], acc[m][r]);
+        }
+        if (ttk[m] == 0) {
+            float sum = dbacc[m];
+            sum += __shfl_xor(sum, 32, 64);
+            const int nn = 32 * ttn[m] + i;
+            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 // chunk / LDS budget of the wgrad kernel for a descriptor (host)
@@ -607,6 +790,27 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (wp.xs > 0 && (a.in_dim & 3)) return tn::fail(TN_E_CONFIG, "mlp_bwd: in_dim must be a multiple of 4");
     const int chunks = wp.chunks;
     const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * (wlds * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
+    const int extra_rows_ = extra_rows(a.enc, a.in_dim, a.K0_pad);
+    if (extra_rows_ == 0 && wp.xs > 0 && NH >= 2) {        // double-buffered form (measured slower for the 2-layer sigma head)
+        constexpr int RG = NH * H + 4;
+        const size_t lds3 = 2 * ((size_t)RG * RS + 32 * (size_t)a.in_dim + 32 * (size_t)wp.aw) * 4 + 32 * 16;
+        const int chunks3 = RG * 8 + 8 * a.in_dim;
+        const int64_t blocks3 = std::min<int64_t>(n_tiles, 256 * (lds3 * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
+#define TN_WGRAD3(MAXS_, NW_, NCH_)                                                                                        \
+    do {                                                                                                                    \
+        auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad3_kernel<H, NH, MAXS_, NW_, NCH_, true> : mlp_wgrad3_kernel<H, NH, MAXS_, NW_, NCH_, false>; \
+        hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);      \
+        if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds3, hipGetErrorString(we)); return (int)we; } \
+        wk<<<dim3((unsigned)blocks3), dim3(NW_ * 64), lds3, s>>>(w, x, aux, n, stash);                                      \
+        return tn::check_launch("mlp_wgrad3_kernel");                                                                       \
+    } while (0)
+        if (lds3 <= (size_t)LDS_LIMIT_BYTES) {
+            if (w.total_tiles <= 8 && chunks3 <= 3 * 512) TN_WGRAD3(1, 8, 3);
+            else if (w.total_tiles <= 8 && chunks3 <= 4 * 512) TN_WGRAD3(1, 8, 4);
+            else if (w.total_tiles <= 24 && chunks3 <= 4 * 768) TN_WGRAD3(2, 12, 4);
+        }
+#undef TN_WGRAD3
+    }
 #define TN_WGRAD(MAXS_, NW_, NCH_)                                                                                         \
     do {                                                                                                                    \
         auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, true> : mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, false>; \

@@ -204,6 +204,15 @@ int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y,
                int64_t n, float *const *grad_weights, float *const *grad_biases, float *grad_x,
                void *workspace, int64_t workspace_bytes, void *stream);
+/* Backward of TWO heads that read the same x in one data-gradient pass (the K-Planes colour head `desc` and its
+ * 2-layer sigma head `partner`, models.py:70-89): grad_x = d/dx of both, written once.  Both descriptors carry
+ * TN_MLP_STASHED (workspaces written by tn_mlp_fwd_stash); partner: 2 layers, TN_ENC_NONE, same in_dim (multiple of
+ * 32) and hidden width 64.  Parameter gradients accumulate (+=) as in tn_mlp_bwd. */
+int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
+                    const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
+                    float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
+                    float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                    int64_t partner_workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a15/a16  K-Planes feature field                              (reference models.py:93-163)

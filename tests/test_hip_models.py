@@ -479,3 +479,58 @@ def test_mlp_stashed_forward_and_ray_table_match_recompute_path(head):
         for a_, b_ in zip(g1, g0):
             np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b_.abs().max())))
         np.testing.assert_allclose((gx1 - (1.0 if accum else 0.0)).cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_mlp_bwd_pair_matches_two_single_head_backwards():
+    """tn_mlp_bwd_pair (colour head + 2-layer sigma head sharing x, one data-gradient pass, grad_x written once)
+    against tn_mlp_bwd of the colour head followed by tn_mlp_bwd of the sigma head with TN_MLP_ACCUM_GRAD_X."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    from tinynerf_amd.models import _mlp_desc
+    m = models()
+    torch.manual_seed(21)
+    n, R, F = 5003, 61, 96
+    dev = torch.device(DEV)
+    sp = [p.detach().contiguous() for p in m.VanillaOpacityDecoder(F).to(dev).net.params()]
+    cd = m.VanillaColorDecoder(8, F, 64, 3).to(dev)
+    rp = [p.detach().contiguous() for p in cd.net.params()]
+    x = torch.rand(n, F, device=dev)
+    ray_ids = torch.sort(torch.randint(0, R, (n,), device=dev, dtype=torch.int32)).values.contiguous()
+    dirs_ray = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+    table = torch.empty(R, 56, device=dev)
+    L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(cd.pe.freqs), C.c_int(8), L.ptr(table), C.c_int(56))
+    g_rgb, g_sig = torch.randn(n, 3, device=dev), torch.randn(n, 1, device=dev)
+    fn = L.lib().tn_mlp_bwd_workspace_bytes
+    fn.restype = C.c_int64
+
+    def fwd(params, enc, nf, act, freqs, aux, idx, out):
+        d = _mlp_desc(params, F, enc, nf, act, freqs, 0, idx, 56 if enc == L.ENC_AUX_CAT else 0)
+        nb = int(fn(C.byref(d), C.c_int64(n)))
+        ws = torch.empty(nb // 4, device=dev)
+        y = torch.empty(n, out, device=dev)
+        L.call("tn_mlp_fwd_stash", dev, C.byref(d), L.ptr(x), L.ptr(aux), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nb))
+        d.flags = L.MLP_STASHED
+        return d, ws, nb
+
+    def grads(params):
+        gs = [torch.zeros_like(p) for p in params]
+        k = len(params) // 2
+        return gs, (C.c_void_p * k)(*[g.data_ptr() for g in gs[0::2]]), (C.c_void_p * k)(*[g.data_ptr() for g in gs[1::2]])
+
+    rd, wr, nbr = fwd(rp, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, cd.pe.freqs, table, ray_ids, 3)
+    sd, wsg, nbs = fwd(sp, L.ENC_NONE, 0, L.ACT_EXP_M1, None, None, None, 1)
+    # reference: two launches
+    gr0, gwr, gbr = grads(rp); gs0, gws, gbs = grads(sp)
+    gx0 = torch.empty(n, F, device=dev)
+    L.call("tn_mlp_bwd", dev, C.byref(rd), L.ptr(x), L.ptr(table), L.ptr(g_rgb), C.c_int64(n), gwr, gbr, L.ptr(gx0), L.ptr(wr.clone()), C.c_int64(nbr))
+    sd.flags = L.MLP_STASHED | L.MLP_ACCUM_GRAD_X
+    L.call("tn_mlp_bwd", dev, C.byref(sd), L.ptr(x), C.c_void_p(None), L.ptr(g_sig), C.c_int64(n), gws, gbs, L.ptr(gx0), L.ptr(wsg.clone()), C.c_int64(nbs))
+    # pair
+    sd.flags = L.MLP_STASHED
+    gr1, gwr, gbr = grads(rp); gs1, gws, gbs = grads(sp)
+    gx1 = torch.full((n, F), float("nan"), device=dev)
+    L.call("tn_mlp_bwd_pair", dev, C.byref(rd), C.byref(sd), L.ptr(x), L.ptr(table), L.ptr(g_rgb), L.ptr(g_sig), C.c_int64(n), gwr, gbr, gws, gbs,
+           L.ptr(gx1), L.ptr(wr), C.c_int64(nbr), L.ptr(wsg), C.c_int64(nbs))
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    for a_, b_ in zip(gr1 + gs1, gr0 + gs0):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b_.abs().max())))

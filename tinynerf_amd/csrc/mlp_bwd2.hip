@@ -54,15 +54,44 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 // last layer; the kernel starts at the output gradient.
 // ACCUM (with STASHED, in_dim % 32 == 0): grad_x += ...; the old values of the next 32-column block are requested before the
 // stores of the current one, for the same in-order-retirement reason as the tile prefetch below.
-template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false>
+// PAIR (with STASHED): a second head `b` with ONE hidden layer of the same width that reads the same x (the K-Planes
+// sigma head next to the colour head): its data gradient runs in the same pass, so x's gradient is written once as the
+// sum of both heads instead of written by one launch and read-modified-written by the next.
+struct PairArgs { MlpArgs b; const float *gy; float *stash; };
+
+template <int H>
+__device__ __forceinline__ void first_dgrad(const float *__restrict__ Wf, int sf, int out, const float (&gp)[4],
+                                            const unsigned (&mask)[H / 32], int h, f32x16 (&G)[H / 32])
+{
+#pragma unroll
+    for (int kb = 0; kb < H / 32; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < out) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(Wf + o * sf + 32 * kb + 8 * q + 4 * h);
+                    acc4 += w * gp[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = (mask[kb] >> (4 * q + u)) & 1u ? acc4[u] : 0.0f;
+        }
+    }
+}
+
+template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false, bool PAIR = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
-                                                             float *__restrict__ stash)
+                                                             float *__restrict__ stash, PairArgs pr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     constexpr int L = NH + 1;
     stage_weights(a, lds);
+    const float *ldsb = lds + a.lds_floats;
+    if constexpr (PAIR) stage_weights(pr.b, lds + a.lds_floats);
     __syncthreads();
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = threadIdx.x >> 6;
@@ -75,8 +104,26 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     // could only be consumed once all of them had drained: one full store round trip per tile, on every wave.
     unsigned nmask[NH][T];
     float npre[4], ngy[4];
+    unsigned bmask[T];
+    float bpre[4], bgy[4];
+    const int Rb = stash_rows(H, 1, 0);                    // PAIR: workspace rows per tile of head b (NH = 1, no E rows)
     const int extra_ = extra_rows(a.enc, a.in_dim, a.K0_pad);
     auto fetch_tile = [&](int64_t t) {
+        if constexpr (PAIR) {
+            const float *qb = pr.stash + t * (int64_t)(Rb * 32) + stash_rows_w(H, 1, 0) * 32;
+            const unsigned *mb = reinterpret_cast<const unsigned *>(qb + 4 * 32);
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) bmask[ob] = mb[ob * 64 + lane];
+            int64_t rb = t * 32 + j_;
+            rb = rb < n ? rb : n - 1;
+            const int outb = pr.b.out_dim;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int oc = o < outb ? o : outb - 1;
+                bpre[o] = qb[oc * 32 + j_];
+                bgy[o] = pr.gy[rb * outb + oc];
+            }
+        }
         const float *q = stash + t * (int64_t)(stash_rows(H, NH, extra_) * 32) + stash_rows_w(H, NH, extra_) * 32;
         const unsigned *mm = reinterpret_cast<const unsigned *>(q + 4 * 32);
 #pragma unroll
@@ -115,6 +162,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         const int sf = a.stride[L - 1];
         unsigned mask[NH][T];
         float gp[4];
+        unsigned pmask[T];
+        float gpb[4];
         if constexpr (STASHED) {
 #pragma unroll
             for (int l = 0; l < NH; ++l)
@@ -122,9 +171,26 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 for (int ob = 0; ob < T; ++ob) mask[l][ob] = nmask[l][ob];
 #pragma unroll
             for (int o = 0; o < 4; ++o) gp[o] = (valid && o < out) ? ngy[o] * act_grad(npre[o], a.out_act) : 0.0f;
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) pmask[ob] = bmask[ob];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) gpb[o] = (valid && o < pr.b.out_dim) ? bgy[o] * act_grad(bpre[o], pr.b.out_act) : 0.0f;
+            }
             {
                 const int64_t tn_ = tile + (int64_t)gridDim.x * WPB;
                 fetch_tile(tn_ < n_tiles ? tn_ : n_tiles - 1);       // before this tile's stores
+            }
+            if constexpr (PAIR) {                                    // head b: g_pre rows, G_0 = relu'(H_1) * (W_1^T g_pre), G_0 rows
+                float *stb = pr.stash + tile * (int64_t)(Rb * 32);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (h == 0) stb[(2 * H + o) * 32 + j] = gpb[o];
+                f32x16 Gb[T];
+                first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) store_rows(stb + H * 32, Gb[ob], ob, j, h);
+                // (G_0b is rebuilt from g_pre and the mask where grad_x needs it: 6 live registers instead of 32)
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o)
@@ -269,6 +335,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
             const int n_kt = (a.in_dim + 31) >> 5;
+            f32x16 Gb[T];
+            if constexpr (PAIR) first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
             const int64_t rowc = row < n ? row : n - 1;
             f32x4 old[4], oldn[4];
             if constexpr (ACCUM) {
@@ -303,6 +371,17 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
                         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
                     }
+                }
+                if constexpr (PAIR) {                                 // + W_0b^T G_0b (x slots of head b are columns 0 .. in_dim-1)
+                    const float *W0b = ldsb + pr.b.w_off[0];
+                    const int s0b = pr.b.stride[0];
+#pragma unroll
+                    for (int tn_ = 0; tn_ < T; ++tn_)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                acc = tn::mfma32(W0b[(32 * tn_ + 8 * q + 4 * h + u) * s0b + 32 * kt + j], Gb[tn_][4 * q + u], acc);
                 }
                 tn::pin16(acc);
                 if constexpr (ACCUM) {
@@ -756,25 +835,39 @@ bool v1_supported(const tn_mlp_desc *d) {
     return acc + 8 * 2 * 32 * 34 <= 160 * 1024 / 4;
 }
 
+// phase bit 0: data-gradient chain, bit 1: weight gradient.  pair != nullptr: the chain also runs head `pair->b`.
 template <int H, int NH>
 int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
-              float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s)
+              float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s,
+              const PairArgs *pair = nullptr, int phase = 3)
 {
     const int64_t n_tiles = (n + 31) / 32;
-    const size_t lds_bytes = (size_t)a.lds_floats * 4;
-    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
+    if (phase & 1) {
+    size_t lds_bytes = (size_t)a.lds_floats * 4;
     constexpr int WPB = 8;
     constexpr int WPS = NH == 1 ? 10 : 16;   // stashed chain: no forward -> ~100 live registers: 4 waves per SIMD, or 2 x 10
                                              // waves per CU for the single-hidden-layer head (25 KB of LDS)
-    const int wpb = stashed ? WPS : WPB;
+    constexpr int WPP = 8;
+    int wpb = stashed ? WPS : WPB;
     auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
     if (stashed && a.accum_gx && gx != nullptr && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
+    PairArgs pr;
+    pr.gy = nullptr; pr.stash = nullptr;
+    if (pair) {
+        pr = *pair;
+        kern = mlp_chain_kernel<H, NH, WPP, true, false, true>;
+        wpb = WPP;
+        lds_bytes += (size_t)pr.b.lds_floats * 4;
+    } else pr.b = a;
+    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));
     const int64_t blocks = std::min<int64_t>((n_tiles + wpb - 1) / wpb, 256 * per_cu);
-    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash);
+    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash, pr);
     if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
+    }
+    if (!(phase & 2)) return TN_OK;
 
     WgradArgs w;
     constexpr int T = H / 32;
@@ -831,13 +924,14 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
 
 template <int H>
 int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
-                float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s)
+                float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s,
+                const PairArgs *pair = nullptr, int phase = 3)
 {
     switch (a.n_layers - 1) {
-    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
-    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
-    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
-    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s);
+    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
+    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
+    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
+    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
     }
 }
 
@@ -889,4 +983,40 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
     hipStream_t s = (hipStream_t)stream;
     if (H == 32) return launch_v2_h<32>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
     return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
+}
+
+extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
+                               const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
+                               float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
+                               float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                               int64_t partner_workspace_bytes, void *stream)
+{
+    TN_REQUIRE(desc && partner, TN_E_NULL, "tn_mlp_bwd_pair: null descriptor");
+    TN_REQUIRE((desc->flags & TN_MLP_STASHED) && (partner->flags & TN_MLP_STASHED), TN_E_CONFIG,
+               "tn_mlp_bwd_pair: both heads need TN_MLP_STASHED workspaces (tn_mlp_fwd_stash)");
+    TN_REQUIRE(v2_supported(desc) && v2_supported(partner), TN_E_CONFIG, "tn_mlp_bwd_pair: outside the two-pass form's configurations");
+    TN_REQUIRE(partner->n_layers == 2 && partner->encoding == TN_ENC_NONE && partner->in_dim == desc->in_dim &&
+                   partner->dims[1] == desc->dims[1] && desc->dims[1] == 64 && (desc->in_dim & 31) == 0 && desc->encoding != TN_ENC_POSENC,
+               TN_E_CONFIG, "tn_mlp_bwd_pair: partner must be a 2-layer head on the same x (width 64, in_dim % 32 == 0)");
+    if (n == 0) return TN_OK;
+    const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
+    TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b, TN_E_NULL,
+               "tn_mlp_bwd_pair: workspace missing or too small");
+    TN_REQUIRE(x && grad_y && partner_grad_y && grad_x && grad_weights && grad_biases && partner_grad_weights && partner_grad_biases,
+               TN_E_NULL, "tn_mlp_bwd_pair: null pointer");
+    MlpArgs a, b;
+    int H = 0, Hb = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    if (int rc = plan(partner, b, Hb)) return rc;
+    TN_REQUIRE((a.enc != TN_ENC_DIR_CAT && a.enc != TN_ENC_AUX_CAT) || aux, TN_E_NULL, "tn_mlp_bwd_pair: dir_cat / aux_cat need aux");
+    for (int l = 0; l < a.n_layers; ++l) TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd_pair: null gradient pointer");
+    for (int l = 0; l < b.n_layers; ++l)
+        TN_REQUIRE(partner_grad_weights[l] && partner_grad_biases[l], TN_E_NULL, "tn_mlp_bwd_pair: null gradient pointer");
+    hipStream_t s = (hipStream_t)stream;
+    PairArgs pr;
+    pr.b = b; pr.gy = partner_grad_y; pr.stash = (float *)partner_workspace;
+    a.accum_gx = 0;
+    if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr, 3)) return rc;
+    return launch_v2_h<64>(b, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
+                           (float *)partner_workspace, true, s, nullptr, 2);
 }

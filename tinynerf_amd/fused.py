@@ -42,6 +42,9 @@ class Arena:
         return t[:numel].view(*shape)
 
 
+PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
+
+
 def _alloc(arena: Optional[Arena], name: str, shape, dev: torch.device) -> torch.Tensor:
     return arena.get(name, shape, dev) if arena is not None else torch.empty(tuple(shape), device=dev)
 
@@ -142,30 +145,35 @@ class _RenderKPlanes(Function):
         g_w = _alloc(arena, "g_w", (n,), dev)
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
                L.ptr(g_w), C.c_int64(n), C.c_int64(R))
-        # colour head: grads of its parameters + d/d feat
-        stashed = L.MLP_STASHED if ws_r is not None else 0
-        rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, stashed, ray_ids, stride)
-        nl = len(rgb_p) // 2
-        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[0::2]])
-        gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_rgb[1::2]])
-        g_feat = _alloc(arena, "g_feat", (n, F), dev)
-        if ws_r is None:
-            ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
-        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw, gb, L.ptr(g_feat),
-               L.ptr(ws_r), C.c_int64(rb))
-        # weights -> sigma
+        # weights -> sigma (needs only the composite's gradient, not the colour head's)
         g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
-        stashed = L.MLP_STASHED if ws_s is not None else 0
-        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | stashed)   # g_feat += d sigma / d feat
-        nl = len(sig_p) // 2
-        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[0::2]])
-        gb = (C.c_void_p * nl)(*[g.data_ptr() for g in g_sig[1::2]])
-        if ws_s is None:
-            ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
-        L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw, gb,
-               L.ptr(g_feat), L.ptr(ws_s), C.c_int64(sb))
+        g_feat = _alloc(arena, "g_feat", (n, F), dev)
+        nr, ns = len(rgb_p) // 2, len(sig_p) // 2
+        gw_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[0::2]])
+        gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])
+        gw_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[0::2]])
+        gb_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[1::2]])
+        if ws_r is not None and ws_s is not None and PAIR_BACKWARD and F % 32 == 0 and ns == 2 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
+            # both heads in one data-gradient pass: d/d feat is written once as the sum of the two
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED, ray_ids, stride)
+            sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_STASHED)
+            L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
+                   C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            stashed = L.MLP_STASHED if ws_r is not None else 0
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, stashed, ray_ids, stride)
+            if ws_r is None:
+                ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
+            L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw_r, gb_r, L.ptr(g_feat),
+                   L.ptr(ws_r), C.c_int64(rb))
+            stashed = L.MLP_STASHED if ws_s is not None else 0
+            sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | stashed)   # g_feat += d sigma / d feat
+            if ws_s is None:
+                ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
+            L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s,
+                   L.ptr(g_feat), L.ptr(ws_s), C.c_int64(sb))
         # plane scatter
         kdesc, keep = _kplanes_desc(planes)
         gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()

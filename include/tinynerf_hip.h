@@ -189,6 +189,11 @@ int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_
  * configurations the two-pass form does not cover (workspace size 0). */
 int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
                      void *workspace, int64_t workspace_bytes, void *stream);
+/* Training forward of TWO heads on the same x in one launch (x is read from HBM once): `desc` (TN_ENC_NONE or
+ * TN_ENC_AUX_CAT) and `partner` (TN_ENC_NONE, same in_dim), both of hidden width 64; workspaces as for tn_mlp_fwd_stash. */
+int tn_mlp_fwd_stash_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux, int64_t n,
+                          float *y, float *partner_y, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                          int64_t partner_workspace_bytes, void *stream);
 /* out[r, :] = [PE_F(dirs[r]) (6F, models.py:36-39 order), dirs[r] (3), 0 ...] with row stride `stride` >= 6F+3:
  * the aux table of TN_ENC_AUX_CAT for the colour head (models.py:87). */
 int tn_dir_encode(const float *dirs, int64_t n, const float *freqs, int n_freqs, float *out, int stride, void *stream);

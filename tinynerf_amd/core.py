@@ -26,8 +26,24 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
 
+_HOST_COPIES: dict = {}
+
+
+def _host_floats(t: torch.Tensor) -> list:
+    """Host copy of a small device tensor, cached per (storage, version): descriptors are rebuilt every step and a
+    device -> host read here would drain the whole queue each time (measured: 2.6 ms per training step)."""
+    key = (t.data_ptr(), t._version, str(t.device), tuple(t.shape), tuple(t.stride()))
+    hit = _HOST_COPIES.get(key)
+    if hit is None:
+        if len(_HOST_COPIES) > 64:
+            _HOST_COPIES.clear()
+        vals = [float(v) for v in t.detach().to("cpu", torch.float32).reshape(-1).tolist()]
+        _HOST_COPIES[key] = hit = (t, vals)        # the entry keeps the tensor alive: its address cannot be reused meanwhile
+    return hit[1]
+
+
 def _fill_aabb(desc: L.SamplerDesc, aabb: torch.Tensor) -> None:
-    vals = [float(v) for v in aabb.detach().to("cpu", torch.float32).reshape(-1).tolist()]
+    vals = _host_floats(aabb)
     for i in range(6):
         desc.aabb[i] = vals[i]
 
@@ -144,7 +160,7 @@ class RayMarcherAABB:
         desc.n_samples = self.n_samples
         desc.near = self.near
         desc.far = self.far
-        desc.step_size = float(self.step_size)
+        desc.step_size = _host_floats(self.step_size)[0]
         _fill_aabb(desc, self.aabb)
 
     @torch.no_grad()

@@ -25,25 +25,32 @@ using namespace tn::mlp;
 // STASH (training forward, out <= 4, weights in LDS): hidden activations, their ReLU bit masks and the last layer's
 // pre-activation also go to the workspace of the two-pass backward (layout: mlp_stage.h), which then starts at the
 // output gradient instead of recomputing the forward.
-template <int H, bool WLDS, int WPB, bool STASH>
-__global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const float *__restrict__ x,
-                                                           const float *__restrict__ aux, int64_t n,
-                                                           float *__restrict__ y, float *__restrict__ pre_act,
-                                                           float *__restrict__ stash)
+// PAIR (with STASH): a second head on the same x rows is evaluated right behind the first one for every tile (its
+// weights sit behind the first head's in LDS), so x is read from HBM once for both.
+struct FwdPair { MlpArgs b; const float *aux; float *y; float *stash; };
+
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false>
+__global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
+                                                           const float *__restrict__ aux0, int64_t n,
+                                                           float *__restrict__ y0, float *__restrict__ pre_act0,
+                                                           float *__restrict__ stash0, FwdPair pr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     if constexpr (WLDS) {
-        stage_weights(a, lds);
+        stage_weights(a0, lds);
+        if constexpr (PAIR) stage_weights(pr.b, lds + a0.lds_floats);
         __syncthreads();
     }
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int64_t n_tiles = (n + 31) >> 5;
-    const int L = a.n_layers;
-    const int G0 = a.K0_pad >> 3;
 
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+      auto head = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
+                      float *__restrict__ pre_act, float *__restrict__ stash) {
+        const int L = a.n_layers;
+        const int G0 = a.K0_pad >> 3;
         // keep per-lane weight addresses out of LICM's reach (hoisted, they cost dozens of VGPRs)
         int j = j_, h = h_;
         asm volatile("" : "+v"(j), "+v"(h));
@@ -70,8 +77,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
             stM = reinterpret_cast<unsigned *>(stQ + 4 * 32);
         }
         // ---- layer 0: inputs streamed 4 slots at a time, prefetched one group ahead ----
-        const float *W0 = WLDS ? lds + a.w_off[0] : a.W[0];
-        const float *B0 = WLDS ? lds + a.b_off[0] : a.B[0];
+        const float *W0 = WLDS ? ldsw + a.w_off[0] : a.W[0];
+        const float *B0 = WLDS ? ldsw + a.b_off[0] : a.B[0];
         f32x16 act[T];
 #pragma unroll
         for (int ob = 0; ob < T; ++ob) act[ob] = tn::bias_tile(B0, ob, h);
@@ -149,8 +156,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
         }
         // ---- hidden layers H -> H ----
         for (int l = 1; l + 1 < L; ++l) {
-            const float *Wl = WLDS ? lds + a.w_off[l] : a.W[l];
-            const float *Bl = WLDS ? lds + a.b_off[l] : a.B[l];
+            const float *Wl = WLDS ? ldsw + a.w_off[l] : a.W[l];
+            const float *Bl = WLDS ? ldsw + a.b_off[l] : a.B[l];
             tn::hidden_layer<H>(Wl, Bl, WLDS ? a.stride[l] : H, act, j, h);
             if constexpr (STASH) {
 #pragma unroll
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
             }
         }
         // ---- output layer ----
-        const float *Wf = WLDS ? lds + a.w_off[L - 1] : a.W[L - 1];
-        const float *Bf = WLDS ? lds + a.b_off[L - 1] : a.B[L - 1];
+        const float *Wf = WLDS ? ldsw + a.w_off[L - 1] : a.W[L - 1];
+        const float *Bf = WLDS ? ldsw + a.b_off[L - 1] : a.B[L - 1];
         const int sf = WLDS ? a.stride[L - 1] : H;
         const int out = a.out_dim;
         if (out <= 4) {
@@ -229,6 +236,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a, const floa
                 }
             }
         }
+      };
+      head(a0, lds, aux0, y0, pre_act0, stash0);
+      if constexpr (PAIR) head(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
     }
 }
 
@@ -250,21 +260,25 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t n, int C, con
 }
 
 template <int H>
-int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s)
+int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s,
+               const FwdPair *pair = nullptr)
 {
     const int64_t n_tiles = (n + 31) / 32;
-    const size_t lds_bytes = (size_t)a.lds_floats * 4;
+    size_t lds_bytes = (size_t)a.lds_floats * 4;
+    FwdPair pr;
+    pr.aux = nullptr; pr.y = nullptr; pr.stash = nullptr;
+    if (pair) { pr = *pair; lds_bytes += (size_t)pr.b.lds_floats * 4; } else pr.b = a;
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
     if (wlds && stash) {
         if constexpr (H <= 64) {
             constexpr int WPS = 12;           // stash variant: 3 waves per SIMD keep it inside the 170-VGPR budget (no spills)
-            auto kern = mlp_fwd_kernel<H, true, WPS, true>;
+            auto kern = pair ? mlp_fwd_kernel<H, true, WPS, true, true> : mlp_fwd_kernel<H, true, WPS, true, false>;
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPS * 64)));
             const int64_t blocks = std::min<int64_t>((n_tiles + WPS - 1) / WPS, 256 * per_cu);
-            kern<<<dim3((unsigned)blocks), dim3(WPS * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash);
+            kern<<<dim3((unsigned)blocks), dim3(WPS * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
         } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: hidden width must be 32 or 64");
     } else if (wlds) {
         auto kern = mlp_fwd_kernel<H, true, WPB, false>;
@@ -272,13 +286,13 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
     } else {
         if (stash) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: weights must fit LDS");
         // weights streamed from L2
         auto kern = mlp_fwd_kernel<H, false, WPB, false>;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act, nullptr);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act, nullptr, pr);
     }
     return tn::check_launch("mlp_fwd_kernel");
 }
@@ -298,7 +312,7 @@ __global__ void dir_encode_kernel(const float *__restrict__ d, int64_t n, const 
 }
 
 int fwd_common(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash,
-               hipStream_t s, const char *who)
+               hipStream_t s, const char *who, const FwdPair *pair = nullptr)
 {
     MlpArgs a;
     int H = 0;
@@ -310,10 +324,10 @@ int fwd_common(const tn_mlp_desc *desc, const float *x, const float *aux, int64_
     TN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: x / y must be 16-byte aligned");
     TN_REQUIRE(a.enc != TN_ENC_AUX_CAT || ((uintptr_t)aux & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: aux table must be 16-byte aligned");
     switch (H) {
-    case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, stash, s);
-    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, stash, s);
-    case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, stash, s);
-    default: return launch_fwd<256>(a, x, aux, n, y, pre_act, stash, s);
+    case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, stash, s, pair);
+    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, stash, s, pair);
+    case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, stash, s, pair);
+    default: return launch_fwd<256>(a, x, aux, n, y, pre_act, stash, s, pair);
     }
 }
 
@@ -342,6 +356,32 @@ extern "C" int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const f
     TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_fwd_stash: workspace missing or too small");
     TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd_stash: workspace must be 16-byte aligned");
     return fwd_common(desc, x, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_mlp_fwd_stash");
+}
+
+extern "C" int tn_mlp_fwd_stash_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux, int64_t n,
+                                     float *y, float *partner_y, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                                     int64_t partner_workspace_bytes, void *stream)
+{
+    TN_REQUIRE(desc && partner, TN_E_NULL, "tn_mlp_fwd_stash_pair: null descriptor");
+    const int H = desc->dims[1];
+    TN_REQUIRE(H == 64 && partner->dims[1] == 64 && desc->n_layers >= 2 && desc->n_layers <= 5 && partner->n_layers >= 2 &&
+                   partner->n_layers <= 5 && desc->dims[desc->n_layers] <= 4 && partner->dims[partner->n_layers] <= 4 &&
+                   partner->in_dim == desc->in_dim && (desc->in_dim & 3) == 0 &&
+                   (desc->encoding == TN_ENC_NONE || desc->encoding == TN_ENC_AUX_CAT) && partner->encoding == TN_ENC_NONE,
+               TN_E_CONFIG, "tn_mlp_fwd_stash_pair: two width-64 heads (<= 5 layers, <= 4 outputs) on the same x; partner without encoding");
+    if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_mlp_fwd_stash_pair: negative n");
+    const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
+    TN_REQUIRE(need_a > 0 && need_b > 0, TN_E_CONFIG, "tn_mlp_fwd_stash_pair: configuration not covered by the two-pass backward");
+    TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b, TN_E_NULL,
+               "tn_mlp_fwd_stash_pair: workspace missing or too small");
+    TN_REQUIRE((((uintptr_t)workspace | (uintptr_t)partner_workspace | (uintptr_t)partner_y) & 15) == 0, TN_E_ALIGN,
+               "tn_mlp_fwd_stash_pair: buffers must be 16-byte aligned");
+    TN_REQUIRE(partner_y, TN_E_NULL, "tn_mlp_fwd_stash_pair: null pointer");
+    FwdPair pr;
+    int Hb = 0;
+    if (int rc = plan(partner, pr.b, Hb)) return rc;
+    pr.aux = nullptr; pr.y = partner_y; pr.stash = (float *)partner_workspace;
+    return fwd_common(desc, x, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_mlp_fwd_stash_pair", &pr);
 }
 
 extern "C" int tn_dir_encode(const float *dirs, int64_t n, const float *freqs, int n_freqs, float *out, int stride, void *stream)

@@ -42,6 +42,7 @@ class Arena:
         return t[:numel].view(*shape)
 
 
+PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
 
 
@@ -95,7 +96,12 @@ class _RenderKPlanes(Function):
             ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
             ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
         sigma = _alloc(arena, "sigma", (n,), dev)
-        if ws_s is not None:
+        rgbs = _alloc(arena, "rgbs", (n, 3), dev)
+        pair = (ws_s is not None and ws_r is not None and PAIR_FORWARD and F % 4 == 0 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64)
+        if pair:           # both heads in one launch: the feature rows are read from HBM once
+            L.call("tn_mlp_fwd_stash_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs),
+                   L.ptr(sigma), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+        elif ws_s is not None:
             L.call("tn_mlp_fwd_stash", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), L.ptr(ws_s), C.c_int64(sb))
         else:
             L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
@@ -103,8 +109,9 @@ class _RenderKPlanes(Function):
         weights = _alloc(arena, "weights", (n,), dev)
         L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                C.c_int64(n), C.c_int64(R))
-        rgbs = _alloc(arena, "rgbs", (n, 3), dev)
-        if ws_r is not None:
+        if pair:
+            pass
+        elif ws_r is not None:
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
         else:
             L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))

@@ -137,18 +137,18 @@ __global__ __launch_bounds__(256, 3) void kplanes_bwd_kernel(KpArgs a, const flo
                     const int *O0 = tileO + (2 * h) * 32, *O1 = O0 + 32;
                     const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
                     const f32x4k *W1 = W0 + 8;
-                    float gv[32];
-#pragma unroll
-                    for (int sI = 0; sI < 32; ++sI) gv[sI] = tileG[sI * GS + c];
                     float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
 #pragma unroll
                     for (int s4 = 0; s4 < 8; ++s4) {
                         const f32x4k w0 = W0[s4], w1 = W1[s4];
+                        float gv[4];                   // four samples at a time: 32 at once cost 12 spilled registers
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gv[u] = tileG[(4 * s4 + u) * GS + c];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int sI = 4 * s4 + u;
-                            a0 = fmaf(gv[sI], w0[u], a0);
-                            a1 = fmaf(gv[sI], w1[u], a1);
+                            a0 = fmaf(gv[u], w0[u], a0);
+                            a1 = fmaf(gv[u], w1[u], a1);
                             if ((run_end >> sI) & 1u) {          // wave-uniform (scalar) control flow from here on
                                 const int o0 = O0[sI], o1 = O1[sI];
                                 if ((mv_xp >> sI) & 1u) {        // next cell = x+1: right texel becomes the left one

@@ -71,6 +71,9 @@ int tn_composite_bwd(const float *rgbs, const float *weights, const int32_t *inf
  * ------------------------------------------------------------------------------------------ */
 /* core.py:147-156: out[i] = trilinear(grid, coords[i]) > threshold, bit-exact w.r.t. ATen's
  * grid_sampler_3d (align_corners=True, zeros padding).  values (optional) receives the taps. */
+/* coarse[bz,by,bx] = max of grid over z in [4bz, 4bz+4], y, x likewise (clipped): every tap a point whose floor cell lies
+ * in block (bz,by,bx) can read.  Rebuild after every change of the grid. */
+int tn_occupancy_coarsen(const float *grid, int D, int H, int W, float *coarse, void *stream);
 int tn_occupancy_query(const float *grid, int D, int H, int W, const float *coords, int64_t n,
                        float threshold, uint8_t *out, float *values, void *stream);
 /* core.py:136: jittered voxel centres of depth slice `slice`: out[h*W+w] =
@@ -109,6 +112,9 @@ typedef struct tn_sampler_desc {
     uint64_t seed;            /* training with jitter==NULL && use_rng: counter-based RNG    */
     int32_t use_rng;
     int32_t reserved;
+    const float *coarse;      /* optional [ceil(D/4),ceil(H/4),ceil(W/4)] block maxima written by tn_occupancy_coarsen:
+                               * candidates whose 2x2x2 taps all lie under a block whose maximum is safely below the
+                               * threshold are rejected without reading the taps (same mask, bit for bit); NULL = off */
 } tn_sampler_desc;
 
 /* Stand-alone marcher / contraction calls (core.py:47-59,72-88 and core.py:15-31) with the same

@@ -275,3 +275,32 @@ def test_ray_provider_full_size_properties():
     # empty input
     p0, i0 = rp(o[:0], d[:0], training=False)
     assert p0.shape == (0, 7) and i0.shape == (0, 2)
+
+
+@pytest.mark.parametrize("scene", ["aabb", "unbounded"])
+def test_coarse_reject_leaves_the_mask_unchanged(scene):
+    """The block-maxima early reject (tn_occupancy_coarsen) must not change a single bit of the sampler's output:
+    random grids with most values crowded around the threshold, non-multiple-of-4 sizes, rays leaving the box."""
+    c = core()
+    torch.manual_seed(7)
+    dev = torch.device(DEV)
+    for size, thr in (((37, 41, 30), 0.5), ((64, 64, 64), 0.01), ((5, 3, 9), 0.3)):
+        grid = c.OccupancyGrid(size=size, step_size=0.01, threshold=thr, decay=0.9).to(dev)
+        g = torch.rand(size, device=dev)
+        g = torch.where(g < 0.6, thr * (1 + (torch.rand(size, device=dev) - 0.5) * 4e-3), g * 2 * thr)   # 60 % within 0.2 % of thr
+        g[torch.rand(size, device=dev) < 0.3] = 0.0
+        grid.grid.copy_(g)
+        if scene == "aabb":
+            aabb = torch.tensor([[-1., -1.2, -0.8], [1.1, 1., 0.9]], device=dev)
+            prov = c.RayProvider(grid, c.ContractionAABB(aabb), c.RayMarcherAABB(aabb, 96, 0.05))
+        else:
+            prov = c.RayProvider(grid, c.ContractionMip360(order=float("inf")), c.RayMarcherUnbounded(96, 0.1, 1e5, uniform_range=2.0))
+        o = (torch.rand(700, 3, device=dev) - 0.5) * 3
+        d = torch.nn.functional.normalize(torch.randn(700, 3, device=dev), dim=-1)
+        jit = torch.rand(700, 96, device=dev)
+        outs = []
+        for use in (True, False):
+            grid.use_coarse = use
+            outs.append(prov(o, d, training=True, jitter=jit))
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+        assert 0 < outs[0][0].size(0) < 700 * 96

@@ -31,6 +31,7 @@ class SamplerDesc(C.Structure):
         ("step_size", C.c_float), ("threshold", C.c_float),
         ("t_table", C.c_void_p), ("delta_table", C.c_void_p), ("grid", C.c_void_p), ("jitter", C.c_void_p),
         ("seed", C.c_uint64), ("use_rng", C.c_int32), ("reserved", C.c_int32),
+        ("coarse", C.c_void_p),
     ]
 
 

@@ -200,6 +200,8 @@ class OccupancyGrid(torch.nn.Module):
         self.size = torch.tensor(size, dtype=torch.float)
         self.mean = 1.
         self._dims = tuple(int(s) for s in size)
+        self._n_updates = 0
+        self.use_coarse = True     # sampler early reject through block maxima (identical masks; False: every candidate reads its taps)
 
     @property
     def threshold(self) -> float:
@@ -208,6 +210,18 @@ class OccupancyGrid(torch.nn.Module):
     @property
     def device(self) -> torch.device:
         return self.grid.device
+
+    def coarse_maxima(self) -> torch.Tensor:
+        """Block maxima for the sampler's conservative early reject (tn_occupancy_coarsen), rebuilt whenever the grid has
+        changed: through ``update`` (tracked here) or through in-place torch ops on ``grid`` (its version counter)."""
+        key = (self.grid.data_ptr(), self.grid._version, self._n_updates)
+        if getattr(self, "_coarse_key", None) != key:
+            D, H, W = self._dims
+            dev = L.require_cuda(self.grid)
+            self._coarse = torch.empty(((D + 3) // 4, (H + 3) // 4, (W + 3) // 4), device=dev)
+            L.call("tn_occupancy_coarsen", dev, L.ptr(self.grid), C.c_int(D), C.c_int(H), C.c_int(W), L.ptr(self._coarse))
+            self._coarse_key = key
+        return self._coarse
 
     def _stats(self) -> Tuple[float, float]:
         dev = L.require_cuda(self.grid)
@@ -250,6 +264,7 @@ class OccupancyGrid(torch.nn.Module):
             cells = self.grid[i0:i0 + n_sl]
             L.call("tn_occupancy_apply", dev, L.ptr(cells), L.ptr(sig), C.c_int64(n_sl * H * W),
                    C.c_float(step), C.c_float(thr), C.c_float(self.decay))
+        self._n_updates += 1                       # the kernels write through raw pointers: no version bump
         self.mean = self._stats()[0] / self.grid.numel()
 
     @torch.no_grad()
@@ -281,6 +296,7 @@ class RayProvider:
         desc.grid_d, desc.grid_h, desc.grid_w = g._dims
         desc.grid = g.grid.data_ptr()
         desc.threshold = float(g.threshold)
+        desc.coarse = g.coarse_maxima().data_ptr() if g.use_coarse else None
         if jitter is not None:
             desc.jitter = jitter.data_ptr()
         elif training:

@@ -32,6 +32,7 @@ struct SamplerArgs {
     const float *t_table, *delta_table, *grid, *jitter;
     uint64_t seed;
     int use_rng;
+    const float *coarse;      // block maxima (4^3 voxels + 1 halo) or nullptr
 };
 
 // ATen grid_sampler_3d forward for one point (bilinear, zeros padding, align_corners=True)
@@ -65,6 +66,24 @@ __device__ __forceinline__ float trilinear(const float *__restrict__ grid, int D
     if (bx0 && by1 && bz1) acc = acc + grid[r11 + xi0] * ((wx0 * wy1) * wz1);
     if (bx1 && by1 && bz1) acc = acc + grid[r11 + xi1] * ((wx1 * wy1) * wz1);
     return acc;
+}
+
+// Conservative early reject: the interpolated value is a convex combination of the 8 taps (the rounded weights sum to
+// 1 within a few ulp), so it cannot exceed the maximum of the block that covers every tap the point can read.  When
+// that maximum is below 0.999 * threshold the candidate fails `value > threshold` without reading a tap; otherwise the
+// exact lookup runs.  The mask is therefore identical, bit for bit, with and without the coarse grid.
+__device__ __forceinline__ bool surely_empty(const SamplerArgs &a, float x, float y, float z)
+{
+    const float ix = ((x + 1.0f) / 2.0f) * (float)(a.gw - 1);
+    const float iy = ((y + 1.0f) / 2.0f) * (float)(a.gh - 1);
+    const float iz = ((z + 1.0f) / 2.0f) * (float)(a.gd - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+    // all taps of an axis out of bounds (or NaN): the exact lookup returns 0, and 0 > threshold is false for threshold >= 0
+    const bool inx = x0 >= -1.0f && x0 < (float)a.gw, iny = y0 >= -1.0f && y0 < (float)a.gh, inz = z0 >= -1.0f && z0 < (float)a.gd;
+    if (!(inx && iny && inz)) return a.threshold >= 0.0f;
+    const int bx = max((int)x0, 0) >> 2, by = max((int)y0, 0) >> 2, bz = max((int)z0, 0) >> 2;
+    const int cw = (a.gw + 3) >> 2, ch = (a.gh + 3) >> 2;
+    return a.coarse[((int64_t)bz * ch + by) * cw + bx] < a.threshold * 0.999f;
 }
 
 // per-ray constant of the AABB marcher: slab entry distance (reference core.py:78-81)
@@ -135,6 +154,7 @@ __device__ __forceinline__ bool candidate(const SamplerArgs &a, const float o[3]
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = o[i] + d[i] * t;     // core.py:174
     if (!contract<CONTRACT>(a, p, c)) return false;
+    if (a.coarse != nullptr && surely_empty(a, c[0], c[1], c[2])) return false;
     return trilinear(a.grid, a.gd, a.gh, a.gw, c[0], c[1], c[2]) > a.threshold;   // core.py:156
 }
 
@@ -368,6 +388,24 @@ __global__ __launch_bounds__(256) void occupancy_stats_kernel(const float *__res
     }
 }
 
+__global__ void occupancy_coarsen_kernel(const float *__restrict__ grid, int D, int H, int W, float *__restrict__ coarse)
+{
+    const int cw = (W + 3) >> 2, ch = (H + 3) >> 2, cd = (D + 3) >> 2;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (int64_t)cw * ch * cd) return;
+    const int bx = (int)(b % cw), by = (int)((b / cw) % ch), bz = (int)(b / ((int64_t)cw * ch));
+    float m = 0.0f;                                        // out-of-range taps contribute 0 (zeros padding)
+    bool first = true;
+    for (int z = 4 * bz; z <= min(4 * bz + 4, D - 1); ++z)
+        for (int y = 4 * by; y <= min(4 * by + 4, H - 1); ++y)
+            for (int x = 4 * bx; x <= min(4 * bx + 4, W - 1); ++x) {
+                const float v = grid[((int64_t)z * H + y) * W + x];
+                m = first ? v : fmaxf(m, v);               // (fmaxf drops NaNs; a NaN grid is broken either way)
+                first = false;
+            }
+    coarse[b] = fmaxf(m, 0.0f);
+}
+
 int make_args(const tn_sampler_desc *d, SamplerArgs &a, bool need_grid = true)
 {
     TN_REQUIRE(d, TN_E_NULL, "sampler: null descriptor");
@@ -381,7 +419,7 @@ int make_args(const tn_sampler_desc *d, SamplerArgs &a, bool need_grid = true)
     for (int i = 0; i < 3; ++i) { a.lo[i] = d->aabb[i]; a.hi[i] = d->aabb[3 + i]; }
     a.near = d->near; a.far = d->far; a.step = d->step_size; a.threshold = d->threshold;
     a.t_table = d->t_table; a.delta_table = d->delta_table; a.grid = d->grid; a.jitter = d->jitter;
-    a.seed = d->seed; a.use_rng = d->use_rng;
+    a.seed = d->seed; a.use_rng = d->use_rng; a.coarse = d->coarse;
     return TN_OK;
 }
 
@@ -529,4 +567,13 @@ extern "C" int tn_occupancy_stats(const float *grid, int64_t n, float threshold,
     hipLaunchKernelGGL(occupancy_stats_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream,
                        grid, n, threshold, stats);
     return tn::check_launch("occupancy_stats_kernel");
+}
+
+extern "C" int tn_occupancy_coarsen(const float *grid, int D, int H, int W, float *coarse, void *stream)
+{
+    TN_REQUIRE(D > 0 && H > 0 && W > 0, TN_E_SIZE, "tn_occupancy_coarsen: bad size");
+    TN_REQUIRE(grid && coarse, TN_E_NULL, "tn_occupancy_coarsen: null pointer");
+    const int64_t nb = (int64_t)((D + 3) / 4) * ((H + 3) / 4) * ((W + 3) / 4);
+    occupancy_coarsen_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(grid, D, H, W, coarse);
+    return tn::check_launch("occupancy_coarsen_kernel");
 }

@@ -44,6 +44,8 @@ KERNEL_MODEL = {
     "tn_mlp_bwd:sigma": ("mfma", 2 * FLOP_SIGMA_FWD, "sample"),
     "tn_mlp_fwd:rgb": ("mfma", FLOP_RGB_FWD, "active sample"),
     "tn_mlp_fwd:sigma": ("mfma", FLOP_SIGMA_FWD, "sample"),
+    "tn_mlp_bwd_pair": ("mfma", 2 * (FLOP_RGB_FWD + FLOP_SIGMA_FWD), "sample"),     # both heads: data + weight gradients
+    "tn_mlp_fwd_stash_pair": ("mfma", FLOP_RGB_FWD + FLOP_SIGMA_FWD, "sample"),     # both heads' training forward
     "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample"),            # coords + 36 texel-halves*... + feat row
     "tn_kplanes_bwd": ("hbm", 12 + 384 + 4608 + 2 * 4608, "sample"),  # + gather again + atomic RMW
 }
@@ -79,7 +81,9 @@ class KernelTimer:
                 tag = name.replace("_stash", "") + (":rgb" if desc.encoding in (L.ENC_DIR_CAT, L.ENC_AUX_CAT) else ":sigma")
             if tag not in KERNEL_MODEL or not timer.enabled:
                 return orig(name, device, *args)
-            rows = int(args[3].value) if name.startswith("tn_kplanes") else int(args[3].value if name.startswith("tn_mlp_fwd") else args[4].value)
+            n_arg = {"tn_kplanes_fwd": 3, "tn_kplanes_bwd": 3, "tn_mlp_fwd": 3, "tn_mlp_fwd_stash": 3, "tn_mlp_bwd": 4,
+                     "tn_mlp_fwd_stash_pair": 4, "tn_mlp_bwd_pair": 6}[name]
+            rows = int(args[n_arg].value)
             s = torch.cuda.current_stream(device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
@@ -227,9 +231,9 @@ def main():
                         algorithmic_per_row=unit_work)
             # HBM-side bytes per launch from the committed PMC passes (scripts/pmc.sh); they cannot be collected live
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v4.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v5.json")))
                 roof["traffic"] = pmc["per_entry"].get(dom)
-                roof["traffic_source"] = "profiles/round1_pmc_traffic_v4.json"
+                roof["traffic_source"] = "profiles/round1_pmc_traffic_v5.json"
             except Exception:
                 pass
         line = {

@@ -140,11 +140,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: tinynerf_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL.  TN_BENCH_BACKEND=gloo (debug) lets several ranks share one GPU to exercise the N > 1 path
+    backend = os.environ.get("TN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     from tinynerf_amd import rays
     from tinynerf_amd.run import TrainConfig, Trainer
 

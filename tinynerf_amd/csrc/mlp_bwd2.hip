@@ -847,7 +847,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     constexpr int WPB = 8;
     constexpr int WPS = NH == 1 ? 10 : 16;   // stashed chain: no forward -> ~100 live registers: 4 waves per SIMD, or 2 x 10
                                              // waves per CU for the single-hidden-layer head (25 KB of LDS)
-    constexpr int WPP = 8;
+    constexpr int WPP = 8;                   // pair: both heads' G_0 live at grad_x: 207 VGPRs (9-12 waves are capped at 168 and spill 38)
     int wpb = stashed ? WPS : WPB;
     auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
     if (stashed && a.accum_gx && gx != nullptr && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;

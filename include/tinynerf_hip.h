@@ -295,6 +295,11 @@ int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t n, float *
 int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
                   float *const *grad_basis, void *stream);
 
+/* Loss of the harness (run.py:252,259): grad[i] = scale * (scale_dev ? scale_dev[0] : 1) * (rendered[i] - target[i]) and
+ * sumsq[0] += sum (rendered - target)^2 (fp64, caller zeroes) over n = 3 * rays elements, one pass. */
+int tn_mse_grad(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, float *grad,
+                double *sumsq, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * optimizer step of the harness                        (reference run.py:186,258-260: torch.optim.Adam)
  * One pass per parameter tensor: g' = g + wd*p (coupled L2, as torch), m = b1 m + (1-b1) g',

@@ -12,6 +12,7 @@
 //      formed in fp64 and rounded once, as the reference's double literals do (cuda.cu:25).
 //  bwd (cuda.cu:49-56): gs_k = delta_k (T_{k+1} g_k - sum_{j>k} w_j g_j), NO termination.
 #include "tn_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -182,6 +183,26 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void composite_bwd_kernel(
     }
 }
 
+// d/d rendered of  c * sum (rendered - target)^2  and the sum itself (fp64 accumulator), one pass (run.py:252,259)
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float *__restrict__ r, const float *__restrict__ t, int64_t n, float cg,
+                                                       const float *__restrict__ cg_dev, float *__restrict__ grad, double *__restrict__ sumsq)
+{
+    const float c = cg_dev ? cg * cg_dev[0] : cg;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = r[i] - t[i];
+        grad[i] = d * c;
+        s = fmaf(d, d, s);
+    }
+    double ds = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ds;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+}
+
 inline unsigned ray_blocks(int64_t n_rays) { return (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
 }  // namespace
@@ -231,4 +252,15 @@ extern "C" int tn_composite_bwd(const float *rgbs, const float *weights, const i
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
                        rgbs, weights, info, bg, grad_rendered, grad_rgbs, grad_weights, n_rays);
     return tn::check_launch("composite_bwd_kernel");
+}
+
+extern "C" int tn_mse_grad(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, float *grad,
+                           double *sumsq, void *stream)
+{
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mse_grad: negative size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(rendered && target && grad && sumsq, TN_E_NULL, "tn_mse_grad: null pointer");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 512);
+    mse_grad_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(rendered, target, n, scale, scale_dev, grad, sumsq);
+    return tn::check_launch("mse_grad_kernel");
 }

@@ -391,10 +391,11 @@ class KPlanesFeatureField(torch.nn.Module):
         return _PlaneRegulariser.apply(float(w_tv), float(w_l1), bool(accumulate_into_grad), *self.plane_tensors())
 
     @torch.no_grad()
-    def regulariser_step(self, w_tv: float, w_l1: float, upstream: float) -> torch.Tensor:
+    def regulariser_step(self, w_tv: float, w_l1: float, upstream: float, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Harness form of ``regulariser``: value AND gradient in one launch over all planes (tn_plane_reg_multi).
         ``upstream`` = d(total loss)/d(regulariser) as a host scalar; ``upstream * d reg / d plane`` is added to every
-        ``plane.grad`` (which must exist).  Returns the regulariser value (0-dim fp32 tensor, no graph)."""
+        ``plane.grad`` (which must exist).  Returns the regulariser value (0-dim fp32 tensor, no graph), or -- with a
+        caller-owned accumulator ``sums`` -- the [n,3] coefficients that turn the accumulated sums into the value."""
         planes = self.plane_tensors()
         n = len(planes)
         dev = planes[0].device
@@ -416,6 +417,9 @@ class KPlanesFeatureField(torch.nn.Module):
         key = (float(w_tv), float(w_l1), str(dev))
         if getattr(self, "_reg_coef_key", None) != key:
             self._reg_coef, self._reg_coef_key = coef.to(dev), key
+        if sums is not None:        # caller-owned, zeroed fp64 accumulator [>= 3n]: returns the coefficients, value = (sums * coef).sum()
+            L.call("tn_plane_reg_multi", dev, items, C.c_int32(n), C.c_float(upstream), L.ptr(sums))
+            return self._reg_coef
         sums = torch.zeros((n, 3), dtype=torch.float64, device=dev)
         L.call("tn_plane_reg_multi", dev, items, C.c_int32(n), C.c_float(upstream), L.ptr(sums))
         return (sums * self._reg_coef).sum().to(torch.float32)

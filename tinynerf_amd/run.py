@@ -207,20 +207,27 @@ class Trainer:
         # loss * grad_scale, scaled and never unscaled (run.py:259-260 quirk).  The MSE and its gradient are written out
         # by hand (4 small kernels instead of ~12 through autograd); the regulariser's value and gradient are one launch.
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
-        diff = rendered.detach() - target
-        inv = 1.0 / (3.0 * self.global_ray_count(rendered.size(0)))               # python float or 0-dim tensor
-        rendered.backward(diff * (inv * (2.0 * cfg.grad_scale)))
-        loss = (diff * diff).sum() * inv
+        R = rendered.size(0)
+        acc = self._buf("loss_acc", (1 + 32 * 3,), torch.float64).zero_()          # [0]: sum of squares, [1:]: regulariser sums
+        grad = self._buf("grad_rendered", (R, 3), torch.float32)
+        if self.world == 1:
+            inv, inv_dev = 1.0 / (3.0 * R), None
+        else:                                                                     # MSE over ALL ranks' rays (see global_ray_count)
+            inv, inv_dev = 1.0, (1.0 / (3.0 * self.global_ray_count(R))).reshape(1).float()
+        L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
+               L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
+        rendered.backward(grad)
+        reg_coef = None
         if cfg.method == "kplanes":                                               # run.py:254-256
-            reg = self.renderer.feature_module.regulariser_step(self.tv_reg_alpha, self.l1_reg_alpha, cfg.grad_scale / self.world)   # type: ignore
-            loss = loss + reg / self.world
+            reg_coef = self.renderer.feature_module.regulariser_step(self.tv_reg_alpha, self.l1_reg_alpha, cfg.grad_scale / self.world,   # type: ignore
+                                                                     sums=acc[1:])
+        self._loss_parts = (acc, inv, inv_dev, reg_coef)
         if self.world > 1:
             self.all_reduce_grads()
         self.optimizer.step()
         self.scheduler.step()
         self.train_step += 1
         self.last = {"n_samples": float(packed.size(0)), "n_rays": float(info.size(0)), "k": float(k)}
-        self._loss = loss.detach()
         return self.last
 
     def global_ray_count(self, local_rays: int):
@@ -237,7 +244,13 @@ class Trainer:
         return ((rendered - target) ** 2).sum() / (3.0 * Trainer.global_ray_count(self, rendered.size(0)))
 
     def loss_value(self) -> float:
-        v = self._loss.clone()
+        """Loss of the last step (MSE + weighted regulariser, run.py:252-256), assembled on demand from the device
+        accumulators the step left behind (valid until the next step)."""
+        acc, inv, inv_dev, reg_coef = self._loss_parts
+        v = acc[0] * inv * (inv_dev[0].double() if inv_dev is not None else 1.0)
+        if reg_coef is not None:
+            v = v + (acc[1:1 + reg_coef.numel()] * reg_coef.reshape(-1)).sum() / self.world
+        v = v.float().reshape(1).clone()
         if self.world > 1:
             torch.distributed.all_reduce(v)
         return float(v.item())

@@ -138,10 +138,11 @@ int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32_t *base_of
 int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
                   void *stream);
 /* pass 3: packed[start_r - base + j] = (contracted xyz, ray dir, step) for the j-th set bit
- * (core.py:182-186).  ray_ids (optional) receives the ray index of every packed sample. */
+ * (core.py:182-186).  ray_ids / steps (optional) receive the ray index and the step size (column 6) of every packed
+ * sample as contiguous arrays (what the weights kernels and the per-ray colour-head table index). */
 int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d,
                    int64_t n_rays, const uint64_t *maskbits, const int32_t *info,
-                   const int32_t *base_offset, float *packed, int32_t *ray_ids, int64_t capacity,
+                   const int32_t *base_offset, float *packed, int32_t *ray_ids, float *steps, int64_t capacity,
                    void *stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -329,7 +329,7 @@ class RayProvider:
         packed = torch.empty((n, 7), device=dev)
         ray_ids = torch.empty(n, dtype=torch.int32, device=dev) if return_ray_ids else None
         L.call("tn_sample_pack", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R), L.ptr(maskbits), L.ptr(info),
-               C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), C.c_int64(n))
+               C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), C.c_void_p(None), C.c_int64(n))
         if return_ray_ids:
             return packed, info, ray_ids
         return packed, info

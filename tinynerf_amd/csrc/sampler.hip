@@ -297,7 +297,7 @@ template <int MARCH, int CONTRACT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_pack_kernel(
     SamplerArgs a, const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays,
     const uint64_t *__restrict__ maskbits, const int32_t *__restrict__ info, const int32_t *__restrict__ base_offset,
-    float *__restrict__ packed, int32_t *__restrict__ ray_ids, int64_t capacity)
+    float *__restrict__ packed, int32_t *__restrict__ ray_ids, float *__restrict__ steps, int64_t capacity)
 {
     const int lane = tn::lane_id();
     const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_pack_kernel(
                 p[3] = d[0]; p[4] = d[1]; p[5] = d[2];
                 p[6] = delta;
                 if (ray_ids) ray_ids[row] = (int32_t)ray;
+                if (steps) steps[row] = delta;
             }
         }
         out += __popcll(m);
@@ -511,7 +512,7 @@ extern "C" int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batc
 
 extern "C" int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,
                               const uint64_t *maskbits, const int32_t *info, const int32_t *base_offset, float *packed,
-                              int32_t *ray_ids, int64_t capacity, void *stream)
+                              int32_t *ray_ids, float *steps, int64_t capacity, void *stream)
 {
     SamplerArgs a;
     if (int rc = make_args(desc, a)) return rc;
@@ -519,7 +520,7 @@ extern "C" int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, 
     if (n_rays == 0 || capacity == 0) return TN_OK;
     TN_REQUIRE(rays_o && rays_d && maskbits && info && packed, TN_E_NULL, "tn_sample_pack: null pointer");
     TN_DISPATCH_MC(a, sample_pack_kernel<M, Cn><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(
-                          a, rays_o, rays_d, n_rays, maskbits, info, base_offset, packed, ray_ids, capacity));
+                          a, rays_o, rays_d, n_rays, maskbits, info, base_offset, packed, ray_ids, steps, capacity));
     return tn::check_launch("sample_pack_kernel");
 }
 

@@ -59,25 +59,31 @@ def _workspace(desc: L.MlpDesc, n: int, dev: torch.device, arena: Optional[Arena
     return _alloc(arena, name, (nbytes // 4,), dev), nbytes
 
 
-def _ray_aux(packed: torch.Tensor, info: torch.Tensor, freqs: torch.Tensor, n_freqs: int, arena: Optional[Arena]):
+def _ray_aux(packed: torch.Tensor, info: torch.Tensor, freqs: torch.Tensor, n_freqs: int, arena: Optional[Arena], hint: Optional[dict]):
     """Per-ray inputs of the colour head (models.py:87: cat[PE(d), d]): evaluated once per ray into a table
-    (tn_dir_encode) that the MLP kernels index through the ray id of every sample, instead of 48 sin/cos per sample."""
+    (tn_dir_encode) that the MLP kernels index through the ray id of every sample, instead of 48 sin/cos per sample.
+    Returns (table, ray_ids, stride, steps).  ``hint``: ray ids / steps / ray directions the sampler already wrote out
+    for exactly this batch (run.Trainer.build_batch); otherwise they are rebuilt from (packed, info)."""
     dev = packed.device
     n, R = packed.size(0), info.size(0)
     stride = (6 * n_freqs + 3 + 7) & ~7
     table = _alloc(arena, "aux_table", (R, stride), dev)
-    ray_ids = torch.repeat_interleave(torch.arange(R, dtype=torch.int32, device=dev), info[:, 1].long(), output_size=n)
+    if hint is not None and hint.get("key") == (packed.data_ptr(), n, R):
+        ray_ids, steps, dirs_ray = hint["ray_ids"], hint["steps"], hint["dirs"]
+    else:
+        ray_ids = torch.repeat_interleave(torch.arange(R, dtype=torch.int32, device=dev), info[:, 1].long(), output_size=n)
+        steps = _alloc(arena, "steps", (n,), dev).copy_(packed[:, 6])
+        dirs_ray = packed[info[:, 0].long().clamp_(max=max(n - 1, 0)), 3:6].contiguous() if n > 0 else None   # rays without samples: unused rows
     if n > 0:
-        dirs_ray = packed[info[:, 0].long().clamp_(max=n - 1), 3:6].contiguous()     # rays without samples: unused rows
         L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(freqs), C.c_int(n_freqs), L.ptr(table), C.c_int(stride))
-    return table, ray_ids, stride
+    return table, ray_ids, stride, steps
 
 
 class _RenderKPlanes(Function):
     @staticmethod
     def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
                 freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool, arena: Optional[Arena],
-                train: bool, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                train: bool, hint: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
@@ -87,7 +93,7 @@ class _RenderKPlanes(Function):
         F = kdesc.n_scales * kdesc.channels
         feat = _alloc(arena, "feat", (n, F), dev)
         L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
-        table, ray_ids, stride = _ray_aux(packed, info, freqs, n_freqs, arena)
+        table, ray_ids, stride, steps = _ray_aux(packed, info, freqs, n_freqs, arena, hint)
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
         rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, 0, ray_ids, stride)
         ws_s = ws_r = None
@@ -105,7 +111,6 @@ class _RenderKPlanes(Function):
             L.call("tn_mlp_fwd_stash", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), L.ptr(ws_s), C.c_int64(sb))
         else:
             L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
-        steps = _alloc(arena, "steps", (n,), dev).copy_(packed[:, 6])
         weights = _alloc(arena, "weights", (n,), dev)
         L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                C.c_int64(n), C.c_int64(R))
@@ -189,7 +194,7 @@ class _RenderKPlanes(Function):
                 gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
         L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         grads = [None if in_place else g for (g, in_place) in bufs]
-        return (None, None, None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def supports(renderer) -> bool:
@@ -210,4 +215,4 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
         arena = renderer.__dict__.setdefault("_arena", Arena())
     train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
     return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
-                                len(sig_p), accumulate_into_grad, arena, train, *planes, *sig_p, *rgb_p)
+                                len(sig_p), accumulate_into_grad, arena, train, getattr(renderer, "_batch_aux", None), *planes, *sig_p, *rgb_p)

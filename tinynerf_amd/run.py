@@ -182,8 +182,12 @@ class Trainer:
         total = self._buf("total", (1,), torch.int32)
         L.call("tn_sample_scan", dev, L.ptr(pend["counts"]), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
         packed = self._buf("packed", (n, 7), torch.float32)
+        ray_ids = self._buf("ray_ids", (n,), torch.int32)
+        steps = self._buf("steps", (n,), torch.float32)
         L.call("tn_sample_pack", dev, C.byref(pend["desc"]), L.ptr(pend["o"]), L.ptr(pend["d"]), C.c_int64(R), L.ptr(pend["maskbits"]),
-               L.ptr(info), C.c_void_p(None), L.ptr(packed), C.c_void_p(None), C.c_int64(n))
+               L.ptr(info), C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), L.ptr(steps), C.c_int64(n))
+        # what the fused render node would otherwise rebuild from (packed, info): ray id and step of every sample, ray directions
+        self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R]}
         return packed, info, self.rgbs[pend["idx"][:R]], k
 
     # ------------------------------------------------------------------ one optimizer step

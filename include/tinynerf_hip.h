@@ -317,6 +317,21 @@ typedef struct tn_adam_item {
 int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, int32_t zero_grad, void *stream);
 
+/* tn_adam_multi with the K-Planes regulariser folded in (run.py:254-260 in one pass): items with H > 0 are [H,W,C]
+ * planes whose TV / L1 gradient (coefficients as in tn_plane_reg_multi, times `upstream`) is added to grad before the
+ * update; it is built from the values in `param` while the update goes to `param_out` (a second buffer: the caller swaps
+ * them), and sums[3*sum_slot + {0,1,2}] receive the regulariser's three sums (may be NULL).  Items with H == 0 are plain
+ * Adam (param_out may equal param). */
+typedef struct tn_adam_reg_item {
+    const float *param;
+    float *param_out, *grad, *exp_avg, *exp_avg_sq;
+    int64_t n;
+    int32_t H, W, C, sum_slot;
+    float cy, cx, cl1, reserved;
+} tn_adam_reg_item;
+int tn_adam_reg_multi(const tn_adam_reg_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, int32_t zero_grad, float upstream, double *sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

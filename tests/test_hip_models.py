@@ -534,3 +534,42 @@ def test_mlp_bwd_pair_matches_two_single_head_backwards():
     np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-5, atol=2e-6)
     for a_, b_ in zip(gr1 + gs1, gr0 + gs0):
         np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b_.abs().max())))
+
+
+def test_adam_with_folded_regulariser_matches_two_passes():
+    """FusedAdam.step(plane_reg=...) (tn_adam_reg_multi: TV / L1 gradient built from the current planes inside the update,
+    new values written to a second buffer and swapped in) against regulariser_step() followed by a plain FusedAdam.step()."""
+    from tinynerf_amd.optim import FusedAdam
+    m = models()
+    torch.manual_seed(9)
+
+    def make():
+        torch.manual_seed(9)
+        f = m.KPlanesFeatureField(32)
+        f.planes = torch.nn.ModuleList([torch.nn.ModuleList([m.KPlanesFeaturePlane(32, r) for _ in range(3)]) for r in ((8, 8), (12, 10), (33, 17))])
+        f.to(DEV)
+        lin = torch.nn.Linear(7, 5).to(DEV)
+        params = list(f.parameters()) + list(lin.parameters())
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        return f, params, FusedAdam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
+
+    fa, pa, oa = make()
+    fb, pb, ob = make()
+    for it in range(4):
+        torch.manual_seed(100 + it)
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x) * 1024
+            x.grad.copy_(g); y.grad.copy_(g)
+        sums_a = torch.zeros(9 * 3, dtype=torch.float64, device=DEV)
+        coef = fa.regulariser_step(0.7, 0.3, upstream=1024.0, sums=sums_a)
+        oa.step()
+        spec, coef_b = fb.regulariser_spec(0.7, 0.3)
+        sums_b = torch.zeros(9 * 3, dtype=torch.float64, device=DEV)
+        ob.step(plane_reg={"spec": spec, "upstream": 1024.0, "sums": sums_b})
+        np.testing.assert_allclose(sums_b.cpu().numpy(), sums_a.cpu().numpy(), rtol=1e-6)
+        for x, y in zip(pa, pb):
+            np.testing.assert_allclose(y.detach().cpu().numpy(), x.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+            assert float(y.grad.abs().max()) == 0.0 and y.is_contiguous(memory_format=torch.channels_last) == x.is_contiguous(memory_format=torch.channels_last)
+        for x, y in zip(pa, pb):
+            np.testing.assert_allclose(ob.state[y]["exp_avg_sq"].cpu().numpy(), oa.state[x]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)

@@ -169,6 +169,74 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamItems items, float 
     }
 }
 
+// Adam with the K-Planes regulariser folded in (harness): for plane tensors the total-variation / L1 gradient is built
+// from the CURRENT values while the update is written to a second buffer (the caller swaps the two), so the planes, their
+// gradients and both moments are streamed exactly once per step instead of once for the regulariser and once for Adam.
+struct AdamRegItems { tn_adam_reg_item it[TN_MULTI_MAX / 2]; };
+
+__global__ __launch_bounds__(256) void adam_reg_multi_kernel(AdamRegItems items, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                             float bc2_sqrt, int zero_grad, float up, double *__restrict__ sums)
+{
+    const tn_adam_reg_item &t = items.it[blockIdx.y];
+    const float *__restrict__ p = t.param; float *__restrict__ po = t.param_out;
+    float *__restrict__ g = t.grad; float *__restrict__ m = t.exp_avg; float *__restrict__ v = t.exp_avg_sq;
+    const int64_t n = t.n, n4 = (n + 3) / 4;
+    const bool reg = t.H > 0;
+    const int W = t.W, H = t.H, C4 = t.C >> 2;
+    const float cy2 = 2.0f * t.cy, cx2 = 2.0f * t.cx;
+    float sy = 0.f, sx = 0.f, sl = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (4 * i + 3 < n) {
+            const f4 *q = reinterpret_cast<const f4 *>(p);
+            f4 pv = q[i], gv = reinterpret_cast<f4 *>(g)[i];
+            f4 mv = reinterpret_cast<f4 *>(m)[i], vv = reinterpret_cast<f4 *>(v)[i];
+            if (reg) {
+                const int64_t texel = i / C4;
+                const int x = (int)(texel % W), y = (int)(texel / W);
+                f4 dy = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+                if (y > 0) dy += pv - q[i - (int64_t)W * C4];
+                if (x > 0) dx += pv - q[i - C4];
+                if (y + 1 < H) { const f4 d = q[i + (int64_t)W * C4] - pv; dy -= d; sy += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
+                if (x + 1 < W) { const f4 d = q[i + C4] - pv; dx -= d; sx += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
+                sl += fabsf(pv[0]) + fabsf(pv[1]) + fabsf(pv[2]) + fabsf(pv[3]);
+                f4 r = dy * cy2 + dx * cx2;
+                if (t.cl1 != 0.0f) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] += t.cl1 * (pv[c] > 0.f ? 1.f : (pv[c] < 0.f ? -1.f : 0.f));
+                }
+                gv += r * up;                                   // as plane_reg_multi_kernel: g += r * upstream
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gg = gv[c] + wd * pv[c];
+                mv[c] = mv[c] + (gg - mv[c]) * (1.0f - b1);
+                vv[c] = b2 * vv[c] + (1.0f - b2) * gg * gg;
+                const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+                pv[c] = pv[c] - (lr / bc1) * (mv[c] / denom);
+            }
+            reinterpret_cast<f4 *>(po)[i] = pv; reinterpret_cast<f4 *>(m)[i] = mv; reinterpret_cast<f4 *>(v)[i] = vv;
+            if (zero_grad) reinterpret_cast<f4 *>(g)[i] = f4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int64_t e = 4 * i; e < n; ++e) {               // (tails: tensors without a regulariser only)
+                const float gg = g[e] + wd * p[e];
+                m[e] = m[e] + (gg - m[e]) * (1.0f - b1);
+                v[e] = b2 * v[e] + (1.0f - b2) * gg * gg;
+                po[e] = p[e] - (lr / bc1) * (m[e] / (sqrtf(v[e]) / bc2_sqrt + eps));
+                if (zero_grad) g[e] = 0.0f;
+            }
+        }
+    }
+    if (!reg || sums == nullptr) return;
+    double dsy = sy, dsx = sx, dsl = sl;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dsy += __shfl_xor(dsy, o, 64); dsx += __shfl_xor(dsx, o, 64); dsl += __shfl_xor(dsl, o, 64); }
+    __shared__ double red[3][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dsy; red[1][threadIdx.x >> 6] = dsx; red[2][threadIdx.x >> 6] = dsl; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(&sums[3 * t.sum_slot + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -257,6 +325,41 @@ extern "C" int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float l
         adam_multi_kernel<<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
             pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad);
         if (int rc = tn::check_launch("adam_multi_kernel")) return rc;
+    }
+    return TN_OK;
+}
+
+extern "C" int tn_adam_reg_multi(const tn_adam_reg_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int32_t step, int32_t zero_grad, float upstream, double *sums, void *stream)
+{
+    TN_REQUIRE(n_items >= 0 && step >= 1, TN_E_SIZE, "tn_adam_reg_multi: bad item count / step");
+    TN_REQUIRE(n_items == 0 || items, TN_E_NULL, "tn_adam_reg_multi: null items");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    constexpr int MAXI = TN_MULTI_MAX / 2;
+    for (int base = 0; base < n_items; base += MAXI) {
+        AdamRegItems pack;
+        const int cnt = std::min(MAXI, n_items - base);
+        int64_t largest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const tn_adam_reg_item &t = items[base + i];
+            TN_REQUIRE(t.n >= 0, TN_E_SIZE, "tn_adam_reg_multi: negative size");
+            TN_REQUIRE(t.n == 0 || (t.param && t.param_out && t.grad && t.exp_avg && t.exp_avg_sq), TN_E_NULL, "tn_adam_reg_multi: null pointer");
+            TN_REQUIRE((((uintptr_t)t.param | (uintptr_t)t.param_out | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0,
+                       TN_E_ALIGN, "tn_adam_reg_multi: buffers must be 16-byte aligned");
+            if (t.H > 0) {
+                TN_REQUIRE(t.W > 0 && t.C > 0 && (t.C & 3) == 0 && (int64_t)t.H * t.W * t.C == t.n, TN_E_SIZE,
+                           "tn_adam_reg_multi: plane shape must match n (C a multiple of 4)");
+                TN_REQUIRE(t.param_out != t.param, TN_E_CONFIG, "tn_adam_reg_multi: a regularised plane needs a separate output buffer");
+                TN_REQUIRE(sums == nullptr || t.sum_slot >= 0, TN_E_SIZE, "tn_adam_reg_multi: bad sum slot");
+            }
+            pack.it[i] = t;
+            largest = std::max<int64_t>(largest, (t.n + 3) / 4);
+        }
+        if (largest == 0) continue;
+        adam_reg_multi_kernel<<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
+            pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad, upstream, sums);
+        if (int rc = tn::check_launch("adam_reg_multi_kernel")) return rc;
     }
     return TN_OK;
 }

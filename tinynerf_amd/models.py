@@ -390,39 +390,49 @@ class KPlanesFeatureField(torch.nn.Module):
         ``accumulate_into_grad`` the backward adds straight into ``plane.grad`` (harness option)."""
         return _PlaneRegulariser.apply(float(w_tv), float(w_l1), bool(accumulate_into_grad), *self.plane_tensors())
 
+    def regulariser_spec(self, w_tv: float, w_l1: float):
+        """[(plane, H, W, C, cy, cx, cl1)] and the [n,3] device tensor of the same coefficients: w_tv * loss_tv() + w_l1 *
+        loss_l1() = sum_i cy_i * S_y,i + cx_i * S_x,i + cl1_i * S_1,i over the three per-plane sums of the kernels."""
+        planes = self.plane_tensors()
+        n = len(planes)
+        dev = planes[0].device
+        spec = []
+        coef = torch.empty((n, 3), dtype=torch.float64)
+        for i, p in enumerate(planes):
+            _, Cc, H, W = p.shape
+            cy = w_tv / (n * Cc * max(H - 1, 1) * W)
+            cx = w_tv / (n * Cc * H * max(W - 1, 1))
+            cl = w_l1 / (n * Cc * H * W)
+            spec.append((p, H, W, Cc, cy, cx, cl))
+            coef[i, 0], coef[i, 1], coef[i, 2] = cy, cx, cl
+        key = (float(w_tv), float(w_l1), str(dev), n)
+        if getattr(self, "_reg_coef_key", None) != key:
+            self._reg_coef, self._reg_coef_key = coef.to(dev), key
+        return spec, self._reg_coef
+
     @torch.no_grad()
     def regulariser_step(self, w_tv: float, w_l1: float, upstream: float, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Harness form of ``regulariser``: value AND gradient in one launch over all planes (tn_plane_reg_multi).
         ``upstream`` = d(total loss)/d(regulariser) as a host scalar; ``upstream * d reg / d plane`` is added to every
         ``plane.grad`` (which must exist).  Returns the regulariser value (0-dim fp32 tensor, no graph), or -- with a
         caller-owned accumulator ``sums`` -- the [n,3] coefficients that turn the accumulated sums into the value."""
-        planes = self.plane_tensors()
-        n = len(planes)
-        dev = planes[0].device
-        if not planes[0].is_cuda:
+        spec, coef = self.regulariser_spec(w_tv, w_l1)
+        n = len(spec)
+        dev = spec[0][0].device
+        if not spec[0][0].is_cuda:
             raise RuntimeError("tinynerf_amd: tensor must be a CUDA (HIP) tensor -- there is no CPU path")
         items = (L.PlaneRegItem * n)()
-        coef = torch.empty((n, 3), dtype=torch.float64)
-        for i, p in enumerate(planes):
-            _, Cc, H, W = p.shape
+        for it, (p, H, W, Cc, cy, cx, cl) in zip(items, spec):
             if p.grad is None or p.grad.stride() != p.stride():
                 raise RuntimeError("regulariser_step: every plane needs a .grad buffer with the plane's layout")
-            cy = w_tv / (n * Cc * max(H - 1, 1) * W)
-            cx = w_tv / (n * Cc * H * max(W - 1, 1))
-            cl = w_l1 / (n * Cc * H * W)
-            it = items[i]
             it.plane, it.grad, it.H, it.W, it.C = _hwc(p).data_ptr(), _hwc(p.grad).data_ptr(), H, W, Cc
             it.cy, it.cx, it.cl1 = cy, cx, cl
-            coef[i, 0], coef[i, 1], coef[i, 2] = cy, cx, cl
-        key = (float(w_tv), float(w_l1), str(dev))
-        if getattr(self, "_reg_coef_key", None) != key:
-            self._reg_coef, self._reg_coef_key = coef.to(dev), key
         if sums is not None:        # caller-owned, zeroed fp64 accumulator [>= 3n]: returns the coefficients, value = (sums * coef).sum()
             L.call("tn_plane_reg_multi", dev, items, C.c_int32(n), C.c_float(upstream), L.ptr(sums))
-            return self._reg_coef
+            return coef
         sums = torch.zeros((n, 3), dtype=torch.float64, device=dev)
         L.call("tn_plane_reg_multi", dev, items, C.c_int32(n), C.c_float(upstream), L.ptr(sums))
-        return (sums * self._reg_coef).sum().to(torch.float32)
+        return (sums * coef).sum().to(torch.float32)
 
 
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):

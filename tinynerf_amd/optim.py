@@ -20,8 +20,15 @@ class FusedAdam(torch.optim.Optimizer):
         self.zero_grad_in_step = zero_grad_in_step
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, plane_reg=None):
+        """``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None) folds
+        the K-Planes regulariser's gradient (and its sums) into the update of those planes (tn_adam_reg_multi): the planes are
+        streamed once per step.  Their new values are written to a second buffer which then becomes ``plane.data``."""
         loss = closure() if closure is not None else None
+        reg = {}
+        if plane_reg is not None:
+            for slot, (p, H, W, Cc, cy, cx, cl) in enumerate(plane_reg["spec"]):
+                reg[id(p)] = (slot, H, W, Cc, cy, cx, cl)
         for group in self.param_groups:
             b1, b2 = group["betas"]
             by_step = {}
@@ -43,12 +50,32 @@ class FusedAdam(torch.optim.Optimizer):
                          or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d)))
                 if not (same and dense and p.dtype == torch.float32):
                     raise RuntimeError("tinynerf_amd.FusedAdam: parameter, gradient and state must be dense fp32 with equal strides")
-                by_step.setdefault((st["step"], p.device), []).append((p, g, m, v))
+                by_step.setdefault((st["step"], p.device, id(p) in reg), []).append((p, g, m, v))
             # one launch per (step count, device): every tensor of the harness shares both
-            for (t, dev), tensors in by_step.items():
-                items = (L.AdamItem * len(tensors))()
+            for (t, dev, with_reg), tensors in by_step.items():
+                common = (C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]), C.c_float(group["weight_decay"]),
+                          C.c_int32(t), C.c_int32(1 if self.zero_grad_in_step else 0))
+                if not with_reg:
+                    items = (L.AdamItem * len(tensors))()
+                    for it, (p, g, m, v) in zip(items, tensors):
+                        it.param, it.grad, it.exp_avg, it.exp_avg_sq, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    L.call("tn_adam_multi", dev, items, C.c_int32(len(tensors)), *common)
+                    continue
+                items = (L.AdamRegItem * len(tensors))()
                 for it, (p, g, m, v) in zip(items, tensors):
-                    it.param, it.grad, it.exp_avg, it.exp_avg_sq, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                L.call("tn_adam_multi", dev, items, C.c_int32(len(tensors)), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2),
-                       C.c_float(group["eps"]), C.c_float(group["weight_decay"]), C.c_int32(t), C.c_int32(1 if self.zero_grad_in_step else 0))
+                    st = self.state[p]
+                    if "shadow" not in st:
+                        st["shadow"] = torch.empty_like(p, memory_format=torch.preserve_format)
+                    slot, H, W, Cc, cy, cx, cl = reg[id(p)]
+                    if (Cc, H, W) != tuple(p.shape[1:]) or not p.is_contiguous(memory_format=torch.channels_last):
+                        raise RuntimeError("tinynerf_amd.FusedAdam: plane_reg expects channels_last [1,C,H,W] planes")
+                    it.param, it.param_out, it.grad = p.data_ptr(), st["shadow"].data_ptr(), g.data_ptr()
+                    it.exp_avg, it.exp_avg_sq, it.n = m.data_ptr(), v.data_ptr(), p.numel()
+                    it.H, it.W, it.C, it.sum_slot, it.cy, it.cx, it.cl1 = H, W, Cc, slot, cy, cx, cl
+                sums = plane_reg.get("sums")
+                L.call("tn_adam_reg_multi", dev, items, C.c_int32(len(tensors)), *common, C.c_float(plane_reg["upstream"]), L.ptr(sums))
+                for p, _, _, _ in tensors:                   # the updated values live in the second buffer: swap
+                    st = self.state[p]
+                    new, st["shadow"] = st["shadow"], p.data
+                    p.data = new
         return loss

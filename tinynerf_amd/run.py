@@ -221,14 +221,16 @@ class Trainer:
         L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
         rendered.backward(grad)
-        reg_coef = None
+        reg_coef, plane_reg = None, None
         if cfg.method == "kplanes":                                               # run.py:254-256
-            reg_coef = self.renderer.feature_module.regulariser_step(self.tv_reg_alpha, self.l1_reg_alpha, cfg.grad_scale / self.world,   # type: ignore
-                                                                     sums=acc[1:])
+            # the regulariser's gradient is the same on every rank (same planes): it is folded into the optimizer pass, after
+            # the gradient exchange, with its full weight (grad_scale: the loss is scaled and never unscaled)
+            spec, reg_coef = self.renderer.feature_module.regulariser_spec(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
+            plane_reg = {"spec": spec, "upstream": cfg.grad_scale, "sums": acc[1:]}
         self._loss_parts = (acc, inv, inv_dev, reg_coef)
         if self.world > 1:
             self.all_reduce_grads()
-        self.optimizer.step()
+        self.optimizer.step(plane_reg=plane_reg)
         self.scheduler.step()
         self.train_step += 1
         self.last = {"n_samples": float(packed.size(0)), "n_rays": float(info.size(0)), "k": float(k)}

@@ -184,6 +184,9 @@ typedef struct tn_mlp_desc {
     const int32_t *aux_index;
     int32_t aux_stride;
     int32_t reserved;
+    /* tn_mlp_fwd only: optional per-row gate [n] (the renderer passes the volume-rendering weights, core.py:246-251: the
+     * colour head only matters where w > 0).  A 32-row tile whose gates are all 0 is not evaluated and yields 0. */
+    const float *row_gate;
 } tn_mlp_desc;
 
 /* y [n, dims[n_layers]] = MLP(x [n,in_dim], aux [n,3] (dirs for TN_ENC_DIR_CAT, else NULL)).

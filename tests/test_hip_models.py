@@ -573,3 +573,33 @@ def test_adam_with_folded_regulariser_matches_two_passes():
             assert float(y.grad.abs().max()) == 0.0 and y.is_contiguous(memory_format=torch.channels_last) == x.is_contiguous(memory_format=torch.channels_last)
         for x, y in zip(pa, pb):
             np.testing.assert_allclose(ob.state[y]["exp_avg_sq"].cpu().numpy(), oa.state[x]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+
+def test_mlp_forward_row_gate_skips_dead_tiles_only():
+    """tn_mlp_desc.row_gate (inference colour head, core.py:246-251): 32-row tiles whose gates are all 0 yield 0 without
+    being evaluated; every row with a non-zero gate equals the ungated result bit for bit."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    from tinynerf_amd.models import _mlp_desc
+    m = models()
+    torch.manual_seed(4)
+    n, F = 1000, 96
+    dev = torch.device(DEV)
+    cd = m.VanillaColorDecoder(8, F, 64, 3).to(dev)
+    params = [p.detach().contiguous() for p in cd.net.params()]
+    x = torch.rand(n, F, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+    gate = torch.rand(n, device=dev)
+    gate[64:192] = 0.0            # four dead tiles
+    gate[200:210] = 0.0           # dead rows inside a live tile
+    gate[992:] = 0.0              # ragged last tile, dead
+    d = _mlp_desc(params, F, L.ENC_DIR_CAT, 8, L.ACT_SIGMOID, cd.pe.freqs)
+    y0 = torch.empty(n, 3, device=dev)
+    L.call("tn_mlp_fwd", dev, C.byref(d), L.ptr(x), L.ptr(dirs), C.c_int64(n), L.ptr(y0), C.c_void_p(None))
+    d.row_gate = gate.data_ptr()
+    y1 = torch.full((n, 3), float("nan"), device=dev)
+    L.call("tn_mlp_fwd", dev, C.byref(d), L.ptr(x), L.ptr(dirs), C.c_int64(n), L.ptr(y1), C.c_void_p(None))
+    live = gate != 0
+    assert torch.equal(y1[live], y0[live])
+    assert float(y1[64:192].abs().max()) == 0.0 and float(y1[992:].abs().max()) == 0.0
+    assert torch.equal(y1[200:210], y0[200:210])          # dead rows of a live tile are still evaluated (harmless)

@@ -42,6 +42,7 @@ class MlpDesc(C.Structure):
         ("freqs", C.c_void_p),
         ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
         ("aux_index", C.c_void_p), ("aux_stride", C.c_int32), ("reserved", C.c_int32),
+        ("row_gate", C.c_void_p),
     ]
 
 

@@ -56,6 +56,20 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         asm volatile("" : "+v"(j), "+v"(h));
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
+        if constexpr (!STASH) {
+            if (a.row_gate != nullptr) {                    // inference: nothing downstream sees rows whose gate is 0
+                const float gate = valid ? a.row_gate[row] : 0.0f;
+                if (!__any(gate != 0.0f)) {
+                    if (valid && h == 0) {
+                        for (int o = 0; o < a.out_dim; ++o) {
+                            y[row * a.out_dim + o] = 0.0f;
+                            if (pre_act) pre_act[row * a.out_dim + o] = 0.0f;
+                        }
+                    }
+                    return;
+                }
+            }
+        }
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
         float aux3[3] = {0.f, 0.f, 0.f};
         const float *auxrow = nullptr;

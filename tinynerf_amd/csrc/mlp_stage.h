@@ -20,6 +20,7 @@ struct MlpArgs {
     int accum_gx;          // grad_x += (TN_MLP_ACCUM_GRAD_X)
     const int *aux_index;  // TN_ENC_AUX_CAT: x row -> aux table row (nullptr: identity)
     int aux_stride;
+    const float *row_gate; // forward only: tiles whose gates are all 0 are skipped (output 0)
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
@@ -137,7 +138,7 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     for (int l = 0; l < L; ++l) TN_REQUIRE(d->weights[l] && d->biases[l], TN_E_NULL, "mlp: null weight / bias pointer");
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
     a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
-    a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride;
+    a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride; a.row_gate = d->row_gate;
     TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
     switch (a.enc) {
     case TN_ENC_NONE: TN_REQUIRE(a.K0 == a.in_dim, TN_E_CONFIG, "mlp: dims[0] must equal in_dim"); break;

@@ -118,8 +118,10 @@ class _RenderKPlanes(Function):
             pass
         elif ws_r is not None:
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
-        else:
+        else:              # inference: the colour head is only evaluated where the weight is not 0 (core.py:246-251), tile-wise
+            rdesc.row_gate = weights.data_ptr()
             L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
+            rdesc.row_gate = None
         out = torch.empty((R, 3), device=dev)
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))

@@ -167,6 +167,10 @@ enum { TN_ENC_NONE = 0,
 #define TN_MLP_ACCUM_GRAD_X 1   /* tn_mlp_bwd: grad_x += instead of = (two heads sharing one feature tensor) */
 #define TN_MLP_STASHED 2        /* tn_mlp_bwd: workspace holds the activations written by tn_mlp_fwd_stash
                                  * (same desc, x, aux, n): no forward recomputation */
+#define TN_MLP_CHAIN_ONLY 4     /* tn_mlp_bwd_pair: data gradients only (grad_x and the G rows of the workspace) ...   */
+#define TN_MLP_WGRAD_ONLY 8     /* ... weight / bias gradients only, from a workspace a CHAIN_ONLY call completed.  The split
+                                 * lets a caller start consuming grad_x (e.g. scatter it and launch a gradient all-reduce)
+                                 * while the weight gradients are still being computed. */
 
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */

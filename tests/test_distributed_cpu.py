@@ -17,6 +17,7 @@ class _Stub:
     """the two attributes Trainer.all_reduce_grads / global_mse read"""
     def __init__(self, renderer, world):
         self.renderer, self.world, self.device = renderer, world, torch.device("cpu")
+        self._early = {}
 
 
 def _make_model():
@@ -45,7 +46,10 @@ def _worker(rank, world, port, q):
         p.grad = torch.zeros_like(p)
     loss.backward()
     assert m.plane.grad.is_contiguous(memory_format=torch.channels_last)
-    Trainer.all_reduce_grads(stub)
+    Trainer._planes_ready(stub, [m.plane.grad])          # the fused node starts the plane all-reduces mid-backward
+    assert len(stub._early) == 1
+    Trainer.all_reduce_grads(stub)                        # ... which are awaited here, everything else is reduced now
+    assert not stub._early
     q.put((rank, float(loss.detach()), {k: p.grad.detach().contiguous().numpy().copy() for k, p in m.named_parameters()}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -58,6 +58,8 @@ TN_COBAFA_MAX_LEVELS = 8
 TN_MULTI_MAX = 32
 MLP_ACCUM_GRAD_X = 1
 MLP_STASHED = 2
+MLP_CHAIN_ONLY = 4
+MLP_WGRAD_ONLY = 8
 
 
 class PlaneRegItem(C.Structure):

@@ -1016,7 +1016,11 @@ extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partn
     PairArgs pr;
     pr.b = b; pr.gy = partner_grad_y; pr.stash = (float *)partner_workspace;
     a.accum_gx = 0;
-    if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr, 3)) return rc;
+    const bool chain = !(desc->flags & TN_MLP_WGRAD_ONLY), wgrad = !(desc->flags & TN_MLP_CHAIN_ONLY);
+    TN_REQUIRE(chain || wgrad, TN_E_CONFIG, "tn_mlp_bwd_pair: TN_MLP_CHAIN_ONLY and TN_MLP_WGRAD_ONLY exclude each other");
+    if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr,
+                                 (chain ? 1 : 0) | (wgrad ? 2 : 0))) return rc;
+    if (!wgrad) return TN_OK;
     return launch_v2_h<64>(b, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
                            (float *)partner_workspace, true, s, nullptr, 2);
 }

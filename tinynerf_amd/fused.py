@@ -129,6 +129,7 @@ class _RenderKPlanes(Function):
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb)
         ctx.arena = arena
         ctx.param_refs = params if accumulate else None
+        ctx.planes_ready = hint.get("planes_ready") if (hint is not None and accumulate) else None
         return out
 
     @staticmethod
@@ -169,12 +170,30 @@ class _RenderKPlanes(Function):
         gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])
         gw_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[0::2]])
         gb_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[1::2]])
+        kdesc, keep = _kplanes_desc(planes)
+        gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
+        for s in range(kdesc.n_scales):
+            for p in range(3):
+                gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
+        scattered = False
         if ws_r is not None and ws_s is not None and PAIR_BACKWARD and F % 32 == 0 and ns == 2 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
             # both heads in one data-gradient pass: d/d feat is written once as the sum of the two
             rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED, ray_ids, stride)
             sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_STASHED)
-            L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
-                   C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+            pair_args = (C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
+                         C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+            if ctx.planes_ready is not None:
+                # N > 1: data gradients -> plane scatter -> hand the finished plane gradients to the caller (it starts their
+                # all-reduce) -> weight gradients of the heads, which run while the planes are on the wire
+                rdesc.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
+                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
+                L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
+                scattered = True
+                ctx.planes_ready(g_planes)
+                rdesc.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
+                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
+            else:
+                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
         else:
             stashed = L.MLP_STASHED if ws_r is not None else 0
             rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, stashed, ray_ids, stride)
@@ -188,13 +207,8 @@ class _RenderKPlanes(Function):
                 ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
             L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s,
                    L.ptr(g_feat), L.ptr(ws_s), C.c_int64(sb))
-        # plane scatter
-        kdesc, keep = _kplanes_desc(planes)
-        gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
-        for s in range(kdesc.n_scales):
-            for p in range(3):
-                gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
-        L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
+        if not scattered:      # plane scatter
+            L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         grads = [None if in_place else g for (g, in_place) in bufs]
         return (None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 

@@ -113,6 +113,7 @@ class Trainer:
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
         self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
         self.last: Dict[str, float] = {}
+        self._early: Dict[int, object] = {}              # all-reduces started during the backward pass (N > 1)
         self._pending: Optional[dict] = None             # sampler pass of the next step, already in flight
         self._plan_host: Optional[torch.Tensor] = None
         self.prefetch = True
@@ -187,7 +188,8 @@ class Trainer:
         L.call("tn_sample_pack", dev, C.byref(pend["desc"]), L.ptr(pend["o"]), L.ptr(pend["d"]), C.c_int64(R), L.ptr(pend["maskbits"]),
                L.ptr(info), C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), L.ptr(steps), C.c_int64(n))
         # what the fused render node would otherwise rebuild from (packed, info): ray id and step of every sample, ray directions
-        self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R]}
+        self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R],
+                                    "planes_ready": self._planes_ready if self.world > 1 else None}
         return packed, info, self.rgbs[pend["idx"][:R]], k
 
     # ------------------------------------------------------------------ one optimizer step
@@ -262,12 +264,24 @@ class Trainer:
         return float(v.item())
 
     # ------------------------------------------------------------------ e: gradient exchange
+    def _planes_ready(self, grads) -> None:
+        """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are
+        final: their all-reduces start here and travel while the heads' weight gradients are still being computed."""
+        for g in grads:
+            if g.numel() >= (1 << 18):
+                flat = g.permute(0, 2, 3, 1) if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last) else g
+                self._early[g.data_ptr()] = torch.distributed.all_reduce(flat, async_op=True)
+
     def all_reduce_grads(self) -> None:
         """Sum gradients over ranks with RCCL.  Large plane gradients go as individual in-place all-reduces
-        (each drives all xGMI peers); everything small is packed into one bucket."""
-        small, handles = [], []
+        (each drives all xGMI peers; started early by ``_planes_ready`` when the fused path is in use); everything
+        small is packed into one bucket."""
+        small, handles = [], list(self._early.values())
+        early, self._early = self._early, {}
         for p in self.renderer.parameters():
             if p.grad is None:
+                continue
+            if p.grad.data_ptr() in early:
                 continue
             if p.grad.numel() >= (1 << 18):
                 g = p.grad

@@ -29,7 +29,10 @@ using namespace tn::mlp;
 // weights sit behind the first head's in LDS), so x is read from HBM once for both.
 struct FwdPair { MlpArgs b; const float *aux; float *y; float *stash; };
 
-template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false>
+// FAST: every head takes the plain-column first layer (TN_ENC_NONE with in_dim % 4 == 0, or TN_ENC_AUX_CAT).  Compiled
+// separately because the generic first layer drags the sin / cos range reduction of the fused encodings into the kernel
+// (14 k VALU instructions, ~120 KB of code against a 64 KB instruction cache shared by two CUs).
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
                                                            const float *__restrict__ aux0, int64_t n,
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
         float aux3[3] = {0.f, 0.f, 0.f};
         const float *auxrow = nullptr;
-        if (valid) {
+        if (!FAST && valid) {
             if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
             else if (a.enc == TN_ENC_DIR_CAT) { aux3[0] = aux[3 * row]; aux3[1] = aux[3 * row + 1]; aux3[2] = aux[3 * row + 2]; }
             else if (a.enc == TN_ENC_AUX_CAT) auxrow = aux + (int64_t)(a.aux_index ? a.aux_index[row] : row) * a.aux_stride;
@@ -100,8 +103,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         // ahead.  (A load whose result is merged with a constant -- `valid ? x[..] : 0` -- makes the compiler wait for
         // it at the merge, which turns the prefetch into a blocking load per group.)  Rows past n read row 0, slots past
         // the input width read slot 0: both only ever meet zero weights or discarded outputs.
-        const bool fast_in = WLDS && (a.enc == TN_ENC_AUX_CAT || (a.enc == TN_ENC_NONE && (a.in_dim & 3) == 0));
-        if (fast_in) {
+        if constexpr (FAST) {
             const float *arow = a.enc == TN_ENC_AUX_CAT
                                     ? aux + (int64_t)(a.aux_index ? a.aux_index[valid ? row : 0] : (valid ? row : 0)) * a.aux_stride
                                     : xrow;
@@ -283,19 +285,27 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
     pr.aux = nullptr; pr.y = nullptr; pr.stash = nullptr;
     if (pair) { pr = *pair; lds_bytes += (size_t)pr.b.lds_floats * 4; } else pr.b = a;
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
+    auto plain_cols = [](const MlpArgs &m) { return m.enc == TN_ENC_AUX_CAT || (m.enc == TN_ENC_NONE && (m.in_dim & 3) == 0); };
+    const bool fast = wlds && plain_cols(a) && (!pair || plain_cols(pr.b));
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
     if (wlds && stash) {
         if constexpr (H <= 64) {
-            constexpr int WPS = 12;           // stash variant: 3 waves per SIMD keep it inside the 170-VGPR budget (no spills)
-            auto kern = pair ? mlp_fwd_kernel<H, true, WPS, true, true> : mlp_fwd_kernel<H, true, WPS, true, false>;
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPS * 64)));
-            const int64_t blocks = std::min<int64_t>((n_tiles + WPS - 1) / WPS, 256 * per_cu);
-            kern<<<dim3((unsigned)blocks), dim3(WPS * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
+            // stash variants: 12 waves (170-VGPR budget) for the generic first layer, 16 for the plain-column one (119 VGPRs)
+            auto launch = [&](auto kern, int wps) -> int {
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wps * 64)));
+                const int64_t blocks = std::min<int64_t>((n_tiles + wps - 1) / wps, 256 * per_cu);
+                kern<<<dim3((unsigned)blocks), dim3(wps * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
+                return TN_OK;
+            };
+            int rc;
+            if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
+            else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
+            if (rc) return rc;
         } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: hidden width must be 32 or 64");
     } else if (wlds) {
-        auto kern = mlp_fwd_kernel<H, true, WPB, false>;
+        auto kern = fast ? mlp_fwd_kernel<H, true, WPB, false, false, true> : mlp_fwd_kernel<H, true, WPB, false, false, false>;
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));

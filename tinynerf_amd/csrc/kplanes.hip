@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256, 3) void kplanes_bwd_kernel(KpArgs a, const flo
                     const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
                     const f32x4k *W1 = W0 + 8;
                     float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
-#pragma unroll
+                    // (not unrolled: fully unrolled, the 32-sample walk with its five-way run logic made the kernel 12 k
+                    // instructions = 72 KB, more than the instruction cache two CUs share)
+#pragma clang loop unroll(disable)
                     for (int s4 = 0; s4 < 8; ++s4) {
                         const f32x4k w0 = W0[s4], w1 = W1[s4];
                         float gv[4];                   // four samples at a time: 32 at once cost 12 spilled registers

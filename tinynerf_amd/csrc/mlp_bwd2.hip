@@ -788,6 +788,193 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad3_kernel(WgradArgs a, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad kernel, paired form (hidden width 64 = two 32-row tiles per layer)
+//
+// Same pipeline as mlp_wgrad3_kernel, different ownership: a wave owns the TWO tiles that share one A-side operand --
+// (layer l, tn = 0 and 1, one tk) -- so every H_{l-1} operand is read from the workspace by exactly one wave (the
+// 16-byte-per-lane operand loads are what the texture-address unit handles worst: 64 requests per instruction), and
+// every LDS operand column is read once for both tiles.  The last layer's two tiles (one G = g_pre, two H blocks) go to
+// one more wave, with H_NH staged in LDS next to the G rows (it directly precedes them in the workspace).
+// Waves: Tk0 (first layer) + (NH-1)*2 (hidden) + 1 (last) <= NW.
+// ------------------------------------------------------------------------------------------------
+template <int NH, int NW, int NCH, bool AUX>
+__global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
+                                                             int64_t n, const float *__restrict__ stash)
+{
+    constexpr int H = 64, T = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = tn::lane_id(), i_ = lane & 31, h_ = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int xs = a.in_dim;
+    constexpr int RG = H + NH * H + 4;                    // staged workspace rows: H_NH, G_0 .. G_{NH-1}, g_pre
+    constexpr int R0 = (NH - 1) * H;                      // first staged row of a tile
+    const int Rt = stash_rows(H, NH, 0);
+    constexpr int g_chunks = RG * 8;
+    const int x_chunks = (32 * a.in_dim) / 4;
+    const int aw = AUX ? a.K0_pad - a.in_dim : 0;
+    const int buf_floats = RG * RS + 32 * a.in_dim + 32 * aw;
+    // ownership (wave-uniform): kind 0 = first layer (tk), 1 = hidden layer l (tk), 2 = last layer, -1 = idle
+    int kind = -1, l = 0, tk = 0;
+    if (wave < a.Tk0) { kind = 0; tk = wave; }
+    else if (wave < a.Tk0 + (NH - 1) * T) { const int q = wave - a.Tk0; kind = 1; l = 1 + q / T; tk = q - (l - 1) * T; }
+    else if (wave == a.Tk0 + (NH - 1) * T) { kind = 2; l = NH; }
+    f32x16 acc[2];
+    float dbacc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    f32x4 pre[NCH];
+    f32x4 preA = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hn[4];
+    int aidx = 0;
+    auto prefetch = [&](int64_t tile, int64_t tile_after) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + R0 * 32);
+        const int64_t x0 = tile * 32 * (int64_t)a.in_dim;
+        const int64_t xlast = n * (int64_t)a.in_dim - 4;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            int64_t e = x0 + 4 * (int64_t)(c - g_chunks);
+            e = e < 0 ? 0 : (e > xlast ? xlast : e);
+            const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
+            const f32x4 *pr = src + (c < g_chunks ? c : 0);
+            pre[k] = *(c < g_chunks ? pr : px);
+        }
+        if constexpr (AUX) {
+            const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;
+            preA = *reinterpret_cast<const f32x4 *>(aux + (int64_t)aidx * a.aux_stride + (4 * part < aw ? 4 * part : 0));
+            int64_t r_ = tile_after * 32 + s_;
+            r_ = r_ < n ? r_ : n - 1;
+            aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
+        }
+    };
+    float *dummy = lds + 2 * buf_floats;
+    auto commit = [&](float *buf) {
+        float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = threadIdx.x + k * NW * 64;
+            float *dst = c < g_chunks ? buf + (c >> 3) * RS + (c & 7) * 4 : (c < g_chunks + x_chunks ? ldsX + 4 * (c - g_chunks) : dummy);
+            *reinterpret_cast<f32x4 *>(dst) = pre[k];
+        }
+        if constexpr (AUX) {
+            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
+            float *dst = (threadIdx.x < 512 && 4 * part < aw) ? ldsA + s_ * aw + 4 * part : dummy;
+            *reinterpret_cast<f32x4 *>(dst) = preA;
+        }
+    };
+    // the one H operand of a hidden-layer wave; other waves read one (broadcast) line so that the load stays unconditional
+    const int hoff = kind == 1 ? ((l - 1) * H + 32 * tk + i_) * 32 + 16 * h_ : 0;
+    auto fetch_h = [&](int64_t tile) {
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + hoff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hn[e] = p[e];
+    };
+    const int64_t last = n_tiles - 1;
+    int64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if constexpr (AUX) {
+        int64_t r_ = tile * 32 + ((threadIdx.x >> 4) & 31);
+        r_ = r_ < n ? r_ : n - 1;
+        aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
+    }
+    {
+        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
+        prefetch(tile, t1 < last ? t1 : last);
+        fetch_h(tile);
+        commit(lds);
+        __syncthreads();
+        prefetch(t1 < last ? t1 : last, t2 < last ? t2 : last);
+    }
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        int i = i_, h = h_;
+        asm volatile("" : "+v"(i), "+v"(h));
+        float *buf = lds + cur * buf_floats;
+        float *nbuf = lds + (cur ^ 1) * buf_floats;
+        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x, t3 = t2 + gridDim.x;
+        commit(nbuf);
+        prefetch(t2 < last ? t2 : last, t3 < last ? t3 : last);
+        f32x4 hc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hc[e] = hn[e];
+        fetch_h(t1 < last ? t1 : last);
+        const float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+        if (kind >= 0) {
+            // staged rows: [0, H): H_NH   [H + l*H, ...): G_l   [H + NH*H, +4): g_pre
+            const f32x4 *g0, *g1;          // G-side operands of the two tiles
+            bool gok = true;
+            if (kind == 2) {
+                g0 = g1 = reinterpret_cast<const f32x4 *>(buf + (H + NH * H + (i < 4 ? i : 0)) * RS + 16 * h);
+                gok = i < 4;
+            } else {
+                g0 = reinterpret_cast<const f32x4 *>(buf + (H + l * H + i) * RS + 16 * h);
+                g1 = reinterpret_cast<const f32x4 *>(buf + (H + l * H + 32 + i) * RS + 16 * h);
+            }
+            const float *cp = nullptr;      // first layer: a column of the sample-major x / aux rows
+            int cstride = 0;
+            if (kind == 0) {
+                const int q = 32 * tk + i;
+                if (q < xs) { cp = ldsX + 16 * h * a.in_dim + q; cstride = a.in_dim; }
+                else if (AUX && q < a.K0_pad) { cp = ldsA + 16 * h * aw + (q - xs); cstride = aw; }
+            }
+            const f32x4 *r0 = reinterpret_cast<const f32x4 *>(buf + i * RS + 16 * h);            // last layer: H_NH rows tk = 0
+            const f32x4 *r1 = reinterpret_cast<const f32x4 *>(buf + (32 + i) * RS + 16 * h);     //                       tk = 1
+            float gs0 = 0.f, gs1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 gv0 = g0[e], gv1 = g1[e];
+                if (!gok) { gv0 = f32x4{0.f, 0.f, 0.f, 0.f}; gv1 = gv0; }
+                f32x4 av0 = {0.f, 0.f, 0.f, 0.f}, av1;
+                if (kind == 0) {
+                    if (cp != nullptr) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) av0[u] = cp[(4 * e + u) * cstride];
+                    }
+                    av1 = av0;
+                } else if (kind == 1) { av0 = hc[e]; av1 = av0; }
+                else { av0 = r0[e]; av1 = r1[e]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0] = tn::mfma32(gv0[u], av0[u], acc[0]);
+                    acc[1] = tn::mfma32(gv1[u], av1[u], acc[1]);
+                }
+                gs0 += (gv0[0] + gv0[1]) + (gv0[2] + gv0[3]);
+                gs1 += (gv1[0] + gv1[1]) + (gv1[2] + gv1[3]);
+            }
+            if (kind == 2 || tk == 0) { dbacc[0] += gs0; dbacc[1] += gs1; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- flush ----
+    if (kind < 0) return;
+    const int i = i_, h = h_;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        tn::pin16(acc[m]);
+        const int tn_ = kind == 2 ? 0 : m, tkm = kind == 2 ? m : tk;
+        const int Nl = a.N[l], Kl = a.K[l];
+        const int k = 32 * tkm + i;
+        const bool kok = k < Kl;
+        const int kc = kok ? (l == 0 ? wg_col0(a, k) : k) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = 32 * tn_ + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (kok && nn < Nl) atomicAdd(&a.gW[l][(int64_t)nn * Kl + kc], acc[m][r]);
+        }
+        if (tkm == 0) {                                   // bias gradient: row sums of G (once per row block)
+            float sum = dbacc[m];
+            sum += __shfl_xor(sum, 32, 64);
+            const int nn = 32 * tn_ + i;
+            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 // chunk / LDS budget of the wgrad kernel for a descriptor (host)
@@ -897,6 +1084,18 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
         wk<<<dim3((unsigned)blocks3), dim3(NW_ * 64), lds3, s>>>(w, x, aux, n, stash);                                      \
         return tn::check_launch("mlp_wgrad3_kernel");                                                                       \
     } while (0)
+        if constexpr (H == 64 && NH >= 2) {                // paired ownership: one wave per shared operand
+            constexpr int RG4 = H + NH * H + 4;
+            const size_t lds4 = 2 * ((size_t)RG4 * RS + 32 * (size_t)a.in_dim + 32 * (size_t)wp.aw) * 4 + 32 * 16;
+            const int chunks4 = RG4 * 8 + 8 * a.in_dim;
+            if (lds4 <= (size_t)LDS_LIMIT_BYTES && w.Tk0 + (NH - 1) * 2 + 1 <= 12 && chunks4 <= 5 * 768) {
+                auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad4_kernel<NH, 12, 5, true> : mlp_wgrad4_kernel<NH, 12, 5, false>;
+                hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds4, hipGetErrorString(we)); return (int)we; }
+                wk<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256)), dim3(12 * 64), lds4, s>>>(w, x, aux, n, stash);
+                return tn::check_launch("mlp_wgrad4_kernel");
+            }
+        }
         if (lds3 <= (size_t)LDS_LIMIT_BYTES) {
             if (w.total_tiles <= 8 && chunks3 <= 3 * 512) TN_WGRAD3(1, 8, 3);
             else if (w.total_tiles <= 8 && chunks3 <= 4 * 512) TN_WGRAD3(1, 8, 4);

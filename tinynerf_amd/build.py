@@ -37,7 +37,6 @@ SOURCES = {
     "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
-    "render.hip": FAST + ["-munsafe-fp-atomics"],
 }
 
 

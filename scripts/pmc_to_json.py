@@ -15,7 +15,7 @@ for k in f:
 def total(*subs):
     return sum(v["bytes"] for k, v in per.items() if any(k.startswith(s) for s in subs))
 entry = {
-    "tn_mlp_bwd_pair": total("mlp_chain_kernel<64, 4", "mlp_wgrad3_kernel<64, 4", "mlp_wgrad_kernel<64, 4", "mlp_wgrad_kernel<64, 1"),
+    "tn_mlp_bwd_pair": total("mlp_chain_kernel<64, 4", "mlp_wgrad4_kernel<4", "mlp_wgrad3_kernel<64, 4", "mlp_wgrad_kernel<64, 4", "mlp_wgrad_kernel<64, 1"),
     "tn_mlp_fwd_stash_pair": total("mlp_fwd_kernel<64, true, 16, true, true", "mlp_fwd_kernel<64, true, 12, true, true"),
     "tn_kplanes_bwd": total("kplanes_bwd_kernel"), "tn_kplanes_fwd": total("kplanes_fwd_kernel"),
 }

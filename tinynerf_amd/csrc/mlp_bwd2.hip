@@ -76,7 +76,7 @@ __device__ __forceinline__ void first_dgrad(const float *__restrict__ Wf, int sf
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = (mask[kb] >> (4 * q + u)) & 1u ? acc4[u] : 0.0f;
+            for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = mask_keep(acc4[u], mask[kb], 4 * q + u);
         }
     }
 }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = (mask[NH - 1][kb] >> (4 * q + u)) & 1u ? acc4[u] : 0.0f;
+                for (int u = 0; u < 4; ++u) G[kb][4 * q + u] = mask_keep(acc4[u], mask[NH - 1][kb], 4 * q + u);
             }
         }
 
@@ -286,7 +286,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
             for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
             const float *Wl = lds + a.w_off[l];
-            const int sl = a.stride[l];
+            constexpr int sl = H + 4;                       // stride of every hidden layer (mlp_stage.h plan()): a constant lets the
+                                                            // row offsets below become ds_read immediates instead of VALU adds
             f32x16 Gn[T];
 #pragma unroll
             for (int kt = 0; kt < T; ++kt)
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             for (int kt = 0; kt < T; ++kt) {
                 tn::pin16(Gn[kt]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) G[kt][r] = (mask[l - 1][kt] >> r) & 1u ? Gn[kt][r] : 0.0f;
+                for (int r = 0; r < 16; ++r) G[kt][r] = mask_keep(Gn[kt][r], mask[l - 1][kt], r);
             }
         });
 #pragma unroll

@@ -120,11 +120,21 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
     for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * 32] = t[r];
 }
 
+// Bit r = (t[r] > 0) for ReLU outputs (t >= 0, so "> 0" is "bit pattern != 0"; -0.0 cannot occur after fmaxf(x, 0)
+// ... it can: fmaxf(-0.0, 0) may return either zero, hence the shift that drops the sign bit).  Two VALU operations per
+// element (min, shift-or) instead of compare + select + or: VALU instructions are what the MFMA-heavy kernels run out of.
 __device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (t[r] > 0.0f ? 1u : 0u) << r;
+    for (int r = 0; r < 16; ++r) m |= min(__float_as_uint(t[r]) << 1, 1u) << r;
     return m;
+}
+
+// x where bit r of mask is set, else 0: sign-extend the bit to a full word (v_bfe_i32) and AND it in -- two VALU
+// operations instead of and + compare + select
+__device__ __forceinline__ float mask_keep(float x, unsigned mask, int r) {
+    const int keep = __builtin_amdgcn_sbfe((int)mask, r, 1);
+    return __uint_as_float(__float_as_uint(x) & (unsigned)keep);
 }
 
 inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)

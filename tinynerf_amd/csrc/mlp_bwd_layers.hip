@@ -239,6 +239,72 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// data gradient of a wide hidden layer (H = 128 / 256, K == H) with the weights in LDS.
+// The generic kernel above reads W from L2 once per MFMA group (5.5 ms per 256x256 layer and 2^20 samples where the
+// MFMAs need 0.9).  Here a workgroup stages the 32*NKT columns of W it is responsible for (all of them for H = 128, one
+// half for H = 256: 135 KB) once, and every wave walks its 32-sample tiles with the input gradient in registers and
+// one conflict-free ds_read_b32 per MFMA for the transposed weight operand.  blockIdx.y selects the column group.
+// ------------------------------------------------------------------------------------------------
+template <int H, int NKT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_t n, float *__restrict__ stash)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = H / 32;
+    constexpr int SW = 32 * NKT + 4;                      // LDS row stride (floats)
+    const int kt0 = blockIdx.y * NKT;
+    for (int e = threadIdx.x; e < H * 32 * NKT; e += blockDim.x) {
+        const int nn = e / (32 * NKT), c = e - nn * (32 * NKT);
+        lds[nn * SW + c] = nn < a.N ? a.W[(int64_t)nn * a.K + 32 * kt0 + c] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        float *st = stash + tile * (int64_t)a.rows_total * 32;
+        const float *gin = st + a.off_gin * 32;
+        const float *hm = st + a.off_mask * 32;
+        float *gout = st + a.off_gout * 32;
+        f32x16 G[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * t + frow(r, h);
+                const float v = gin[(nn < a.N ? nn : a.N - 1) * 32 + j];     // unconditional load, zeroed afterwards
+                G[t][r] = nn < a.N ? v : 0.0f;
+            }
+#pragma clang loop unroll(disable)
+        for (int ktl = 0; ktl < NKT; ++ktl) {
+            const int kt = kt0 + ktl;
+            float m[16];                                   // ReLU mask source of this output block: requested before the MFMAs
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = hm[(32 * kt + frow(r, h)) * 32 + j];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float *wl = lds + 4 * h * SW + 32 * ktl + j;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) w[u] = wl[(32 * t + 8 * q + u) * SW];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], G[t][4 * q + u], acc);
+                }
+            }
+            tn::pin16(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gout[(32 * kt + frow(r, h)) * 32 + j] = m[r] > 0.0f ? acc[r] : 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -372,8 +438,26 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {
-            dgrad_layer_kernel<H, false, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, nullptr);
-            if (int rc = tn::check_launch("dgrad_layer_kernel")) return rc;
+            bool done = false;
+            if constexpr (H >= 128) {
+                if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS
+                    constexpr int NKT = 4, WL = 8;
+                    constexpr size_t lds_bytes = (size_t)H * (32 * NKT + 4) * 4;
+                    auto kern = dgrad_lds_kernel<H, NKT, WL>;
+                    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+                    const int groups = (H / 32) / NKT;
+                    const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+                    const int64_t bl = std::min<int64_t>((n_tiles + WL - 1) / WL, (256 * per_cu) / groups);
+                    kern<<<dim3((unsigned)bl, (unsigned)groups), dim3(WL * 64), lds_bytes, s>>>(d, n, stash);
+                    if (int rc = tn::check_launch("dgrad_lds_kernel")) return rc;
+                    done = true;
+                }
+            }
+            if (!done) {
+                dgrad_layer_kernel<H, false, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, nullptr);
+                if (int rc = tn::check_launch("dgrad_layer_kernel")) return rc;
+            }
             std::swap(cur, nxt);
         } else if (gx != nullptr && a.enc != TN_ENC_POSENC) {
             dgrad_layer_kernel<H, true, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, gx);

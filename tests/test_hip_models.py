@@ -334,9 +334,12 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     dict(kind="mlp", K=40, H=64, layers=6, out=3, n=257),      # deeper than the register-resident forms cover
     dict(kind="color", F=4, dim=256, H=128, layers=1, n=300),  # reference tests/test_core.py:58 decoder shape
 ])
-def test_wide_deep_mlp_backward_vs_torch(cfg):
-    """layer-by-layer backward (mlp_bwd_layers.hip) against torch autograd of the same fp32 network on the device."""
+@pytest.mark.parametrize("stash", [True, False])
+def test_wide_deep_mlp_backward_vs_torch(cfg, stash, monkeypatch):
+    """layer-by-layer backward (mlp_bwd_layers.hip) against torch autograd of the same fp32 network on the device, with the
+    activations written by the training forward (tn_mlp_fwd_stash) and recomputed by the backward."""
     m = models()
+    monkeypatch.setattr(m._FusedMLP, "stash_forward", stash)
     torch.manual_seed(11)
     n = cfg["n"]
     if cfg["kind"] == "vanilla":

@@ -365,14 +365,23 @@ extern "C" int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *
 
 extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 
+extern "C" int tn_mlp_fwd_stash_layers(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *workspace,
+                                       void *stream);
+
 extern "C" int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, void *workspace,
                                 int64_t workspace_bytes, void *stream)
 {
     TN_REQUIRE(desc, TN_E_NULL, "tn_mlp_fwd_stash: null descriptor");
     const int H = desc->dims[1];
-    TN_REQUIRE((H == 32 || H == 64) && desc->n_layers >= 2 && desc->n_layers <= 5 && desc->dims[desc->n_layers] <= 4, TN_E_CONFIG,
-               "tn_mlp_fwd_stash: outside the two-pass backward's configurations (hidden 32/64, <= 5 layers, <= 4 outputs)");
     if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_mlp_fwd_stash: negative n");
+    const bool two_pass = (H == 32 || H == 64) && desc->n_layers >= 2 && desc->n_layers <= 5 && desc->dims[desc->n_layers] <= 4;
+    if (!two_pass) {       // wide / deep stacks: the layer-by-layer backward's workspace
+        const int64_t need_l = tn_mlp_bwd_workspace_bytes(desc, n);
+        TN_REQUIRE(need_l > 0, TN_E_CONFIG, "tn_mlp_fwd_stash: this configuration's backward does not use a workspace");
+        TN_REQUIRE(workspace && workspace_bytes >= need_l, TN_E_NULL, "tn_mlp_fwd_stash: workspace missing or too small");
+        TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd_stash: workspace must be 16-byte aligned");
+        return tn_mlp_fwd_stash_layers(desc, x, aux, n, y, (float *)workspace, stream);
+    }
     const int64_t need = tn_mlp_bwd_workspace_bytes(desc, n);
     const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
     TN_REQUIRE(need == ((n + 31) / 32) * (int64_t)stash_rows(H, desc->n_layers - 1, extra) * 128, TN_E_CONFIG,

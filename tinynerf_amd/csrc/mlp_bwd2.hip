@@ -1158,11 +1158,12 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
     const bool stashed = (desc->flags & TN_MLP_STASHED) != 0;
     const bool v2 = v2_supported(desc);
     if (stashed || desc->encoding == TN_ENC_AUX_CAT) {
-        TN_REQUIRE(v2, TN_E_CONFIG, "tn_mlp_bwd: TN_MLP_STASHED / TN_ENC_AUX_CAT need a configuration of the two-pass form");
+        TN_REQUIRE(v2 || (stashed && desc->encoding != TN_ENC_AUX_CAT && need > 0), TN_E_CONFIG,
+                   "tn_mlp_bwd: TN_ENC_AUX_CAT needs a configuration of the two-pass form, TN_MLP_STASHED one with a workspace");
         if (n == 0) return TN_OK;
         TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: TN_MLP_STASHED / TN_ENC_AUX_CAT need the workspace");
     }
-    if (!v2 && !v1_supported(desc)) {                          // wide / deep stack: layer-by-layer form
+    if (!v2 && (!v1_supported(desc) || stashed)) {             // wide / deep stack (or its stash): layer-by-layer form
         if (n == 0) return TN_OK;
         TN_REQUIRE(need > 0, TN_E_CONFIG, "tn_mlp_bwd: unsupported layer configuration");
         TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: this configuration needs the workspace");

@@ -51,9 +51,12 @@ __device__ __forceinline__ int col0(const MlpArgs &a, int q) { return layer0_col
 // ------------------------------------------------------------------------------------------------
 // forward with activation stash + output gradient
 // ------------------------------------------------------------------------------------------------
-template <int H, int WPB>
+// FWD_ONLY (training forward, tn_mlp_fwd_stash on a wide / deep stack): y is written, and buffer A receives the last
+// layer's PRE-ACTIVATION instead of the output gradient; out_grad_kernel turns it into the gradient when the backward runs.
+template <int H, int WPB, bool FWD_ONLY = false>
 __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
-                                                             const float *__restrict__ gy, int64_t n, float *__restrict__ stash)
+                                                             const float *__restrict__ gy, int64_t n, float *__restrict__ stash,
+                                                             float *__restrict__ y = nullptr)
 {
     constexpr int T = H / 32;
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
@@ -121,7 +124,10 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
                 float g = 0.0f;
                 if (o < out) {
                     const float pre = tn::small_out<H>(Wf + o * H, Bf[o], act, h);
-                    g = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
+                    if constexpr (FWD_ONLY) {
+                        g = valid ? pre : 0.0f;
+                        if (valid && h == 0) y[row * out + o] = tn::apply_act(pre, a.out_act);
+                    } else g = valid ? gy[row * out + o] * act_grad(pre, a.out_act) : 0.0f;
                 }
                 if (h == 0) stG[o * 32 + j] = g;
             }
@@ -146,10 +152,27 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = 32 * ob + frow(r, h);
-                    stG[f * 32 + j] = (valid && f < out) ? gy[row * out + f] * act_grad(acc[r], a.out_act) : 0.0f;
+                    if constexpr (FWD_ONLY) {
+                        stG[f * 32 + j] = (valid && f < out) ? acc[r] : 0.0f;
+                        if (valid && f < out) y[row * out + f] = tn::apply_act(acc[r], a.out_act);
+                    } else stG[f * 32 + j] = (valid && f < out) ? gy[row * out + f] * act_grad(acc[r], a.out_act) : 0.0f;
                 }
             }
         }
+    }
+}
+
+// buffer A: pre-activation rows (written by the FWD_ONLY forward) -> output gradient  g = gy * act'(pre)
+__global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__ gy, int64_t n, int out, int out_act, int rows_total,
+                                                       int off_g, float *__restrict__ stash)
+{
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int j = threadIdx.x & 31, sub = threadIdx.x >> 5;                 // 8 row slots per block
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        float *g = stash + (tile * (int64_t)rows_total + off_g) * 32;
+        const int64_t row = tile * 32 + j;
+        for (int f = sub; f < out; f += 8)
+            g[f * 32 + j] = row < n ? gy[row * out + f] * act_grad(g[f * 32 + j], out_act) : 0.0f;
     }
 }
 
@@ -406,14 +429,28 @@ __global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const flo
 }
 
 template <int H>
+int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s)
+{
+    const int64_t n_tiles = (n + 31) / 32;
+    constexpr int WPB = H <= 64 ? 8 : 4;
+    const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
+    fwd_stash_kernel<H, WPB, true><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, nullptr, n, stash, y);
+    return tn::check_launch("fwd_stash_kernel(forward)");
+}
+
+template <int H>
 int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *gy, int64_t n, float *const *gw,
-               float *const *gb, float *gx, float *stash, hipStream_t s)
+               float *const *gb, float *gx, float *stash, hipStream_t s, bool stashed = false)
 {
     const int L = a.n_layers;
     const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim);
     const int64_t n_tiles = (n + 31) / 32;
     constexpr int WPB = H <= 64 ? 8 : 4;
-    {
+    if (stashed) {        // activations and the last pre-activation are in the workspace already (tn_mlp_fwd_stash)
+        out_grad_kernel<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * 8)), dim3(256), 0, s>>>(gy, n, a.out_dim, a.out_act, lay.total,
+                                                                                         lay.rowsH + lay.rowsE, stash);
+        if (int rc = tn::check_launch("out_grad_kernel")) return rc;
+    } else {
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
         fwd_stash_kernel<H, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, gy, n, stash);
         if (int rc = tn::check_launch("fwd_stash_kernel")) return rc;
@@ -495,10 +532,30 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_
     for (int l = 0; l < a.n_layers; ++l)
         TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd(layers): null gradient pointer");
     hipStream_t s = (hipStream_t)stream;
+    const bool stashed = (desc->flags & TN_MLP_STASHED) != 0;
     switch (H) {
-    case 32: return run_layers<32>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
-    case 64: return run_layers<64>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
-    case 128: return run_layers<128>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
-    default: return run_layers<256>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s);
+    case 32: return run_layers<32>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
+    case 64: return run_layers<64>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
+    case 128: return run_layers<128>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
+    default: return run_layers<256>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
+    }
+}
+
+// training forward of a stack the layer-by-layer form covers: y + activations + last pre-activation into the workspace
+extern "C" __attribute__((visibility("hidden"))) int tn_mlp_fwd_stash_layers(const tn_mlp_desc *desc, const float *x, const float *aux,
+                                                                            int64_t n, float *y, float *workspace, void *stream)
+{
+    MlpArgs a;
+    int H = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    TN_REQUIRE(x && y && workspace, TN_E_NULL, "tn_mlp_fwd_stash(layers): null pointer");
+    TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_fwd_stash(layers): dir_cat needs aux");
+    TN_REQUIRE(a.enc != TN_ENC_AUX_CAT, TN_E_CONFIG, "tn_mlp_fwd_stash(layers): aux_cat is only implemented for the two-pass form");
+    hipStream_t s = (hipStream_t)stream;
+    switch (H) {
+    case 32: return run_fwd_only<32>(a, x, aux, n, y, workspace, s);
+    case 64: return run_fwd_only<64>(a, x, aux, n, y, workspace, s);
+    case 128: return run_fwd_only<128>(a, x, aux, n, y, workspace, s);
+    default: return run_fwd_only<256>(a, x, aux, n, y, workspace, s);
     }
 }

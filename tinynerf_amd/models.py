@@ -48,9 +48,11 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
 
 
 class _FusedMLP(Function):
-    """y = act(MLP(enc(x, aux))) in one launch; backward recomputes the hidden activations."""
+    """y = act(MLP(enc(x, aux))) in one launch; in training the forward also writes the activation workspace the backward
+    consumes (tn_mlp_fwd_stash), otherwise the backward recomputes the hidden activations."""
 
     two_pass = True     # give tn_mlp_bwd its workspace (two-pass form); False forces the single-kernel form
+    stash_forward = True   # training forward writes the activation workspace (tn_mlp_fwd_stash); False: backward recomputes
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
@@ -63,20 +65,30 @@ class _FusedMLP(Function):
         n = x2.size(0)
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
         y = torch.empty((n, ps[-1].numel()), device=dev)
-        L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
-        ctx.save_for_backward(x2, aux2, freqs, *ps)
+        # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
+        ws, ws_bytes = None, 0
+        if _FusedMLP.two_pass and _FusedMLP.stash_forward and any(ctx.needs_input_grad) and n > 0:
+            wsfn = L.lib().tn_mlp_bwd_workspace_bytes
+            wsfn.restype = C.c_int64
+            ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, device=dev)
+            L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
+        else:
+            L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
+        ctx.save_for_backward(x2, aux2, freqs, ws, *ps)
         ctx.cfg = (encoding, n_freqs, out_act)
         ctx.x_shape = x.shape
         return y.reshape(*lead, y.size(-1))
 
     @staticmethod
     def backward(ctx: Any, grad_y: torch.Tensor):  # type: ignore
-        x2, aux2, freqs, *ps = ctx.saved_tensors
+        x2, aux2, freqs, ws_fwd, *ps = ctx.saved_tensors
         encoding, n_freqs, out_act = ctx.cfg
         dev = x2.device
         n = x2.size(0)
         gy = grad_y.reshape(n, -1).to(torch.float32).contiguous()
-        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
+        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs, L.MLP_STASHED if ws_fwd is not None else 0)
         grads = [torch.zeros_like(p) for p in ps]
         n_layers = len(ps) // 2
         gw = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[0::2]])
@@ -88,7 +100,7 @@ class _FusedMLP(Function):
         ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
         if not _FusedMLP.two_pass and len(ps) // 2 <= 5 and ps[0].size(0) <= 128:
             ws_bytes = 0                     # test hook: force the single-kernel form where it exists
-        ws = torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None     # caching allocator: no hipMalloc per step
+        ws = ws_fwd if ws_fwd is not None else (torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None)
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None

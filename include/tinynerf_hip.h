@@ -198,7 +198,7 @@ typedef struct tn_mlp_desc {
 int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
                float *pre_act, void *stream);
 /* Training forward: y as tn_mlp_fwd, plus the hidden activations, their ReLU bit masks and the last layer's
- * pre-activation into `workspace` (tn_mlp_bwd_workspace_bytes(desc, n) bytes) in the layout tn_mlp_bwd's two-pass
+ * pre-activation into `workspace` (tn_mlp_bwd_workspace_bytes(desc, n) bytes) in the layout tn_mlp_bwd's
  * backward (two-pass or layer-by-layer form) uses; pass the same workspace to tn_mlp_bwd with TN_MLP_STASHED set.
  * Returns TN_E_CONFIG for configurations whose backward takes no workspace (tn_mlp_bwd_workspace_bytes == 0). */
 int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,

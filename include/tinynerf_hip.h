@@ -303,6 +303,12 @@ int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t n, float *
 int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
                   float *const *grad_basis, void *stream);
 
+/* From (packed [N,7], info [R,2]): ray_ids[i] = ray of sample i, steps[i] = packed[i,6] (contiguous, what tn_weights_*
+ * take), dirs[r] = packed[start_r, 3:6] (the ray direction every sample of ray r carries, core.py:182-186; 0 for empty
+ * rays).  One launch; feeds tn_dir_encode / TN_ENC_AUX_CAT when the sampler's own by-products are not at hand. */
+int tn_ray_aux(const float *packed, const int32_t *info, int64_t n_rays, int32_t *ray_ids, float *steps, float *dirs,
+               void *stream);
+
 /* Loss of the harness (run.py:252,259): grad[i] = scale * (scale_dev ? scale_dev[0] : 1) * (rendered[i] - target[i]) and
  * sumsq[0] += sum (rendered - target)^2 (fp64, caller zeroes) over n = 3 * rays elements, one pass. */
 int tn_mse_grad(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, float *grad,

@@ -203,6 +203,24 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float *__restrict__
     if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
 }
 
+// per-sample ray index, contiguous step sizes and per-ray direction out of (packed, info): what the per-ray colour-head
+// table and the weights kernels index (one launch instead of repeat_interleave + gathers + copies)
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void ray_aux_kernel(const float *__restrict__ packed, const int32_t *__restrict__ info,
+                                                                       int64_t n_rays, int32_t *__restrict__ ray_ids,
+                                                                       float *__restrict__ steps, float *__restrict__ dirs)
+{
+    const int lane = tn::lane_id();
+    const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int2 sc = reinterpret_cast<const int2 *>(info)[ray];
+    if (lane < 3) dirs[3 * ray + lane] = sc.y > 0 ? packed[7 * (int64_t)sc.x + 3 + lane] : 0.0f;
+    for (int k = lane; k < sc.y; k += 64) {
+        const int64_t i = sc.x + k;
+        ray_ids[i] = (int32_t)ray;
+        steps[i] = packed[7 * i + 6];
+    }
+}
+
 inline unsigned ray_blocks(int64_t n_rays) { return (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
 }  // namespace
@@ -263,4 +281,15 @@ extern "C" int tn_mse_grad(const float *rendered, const float *target, int64_t n
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 512);
     mse_grad_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(rendered, target, n, scale, scale_dev, grad, sumsq);
     return tn::check_launch("mse_grad_kernel");
+}
+
+extern "C" int tn_ray_aux(const float *packed, const int32_t *info, int64_t n_rays, int32_t *ray_ids, float *steps, float *dirs,
+                          void *stream)
+{
+    TN_REQUIRE(n_rays >= 0, TN_E_SIZE, "tn_ray_aux: negative size");
+    if (n_rays == 0) return TN_OK;
+    TN_REQUIRE(packed && info && ray_ids && steps && dirs, TN_E_NULL, "tn_ray_aux: null pointer");
+    TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_ray_aux: info must be 8-byte aligned");
+    ray_aux_kernel<<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(packed, info, n_rays, ray_ids, steps, dirs);
+    return tn::check_launch("ray_aux_kernel");
 }

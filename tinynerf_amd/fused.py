@@ -46,8 +46,8 @@ PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
 
 
-def _alloc(arena: Optional[Arena], name: str, shape, dev: torch.device) -> torch.Tensor:
-    return arena.get(name, shape, dev) if arena is not None else torch.empty(tuple(shape), device=dev)
+def _alloc(arena: Optional[Arena], name: str, shape, dev: torch.device, dtype=torch.float32) -> torch.Tensor:
+    return arena.get(name, shape, dev, dtype) if arena is not None else torch.empty(tuple(shape), device=dev, dtype=dtype)
 
 
 def _workspace(desc: L.MlpDesc, n: int, dev: torch.device, arena: Optional[Arena] = None, name: str = "ws"):
@@ -71,9 +71,10 @@ def _ray_aux(packed: torch.Tensor, info: torch.Tensor, freqs: torch.Tensor, n_fr
     if hint is not None and hint.get("key") == (packed.data_ptr(), n, R):
         ray_ids, steps, dirs_ray = hint["ray_ids"], hint["steps"], hint["dirs"]
     else:
-        ray_ids = torch.repeat_interleave(torch.arange(R, dtype=torch.int32, device=dev), info[:, 1].long(), output_size=n)
-        steps = _alloc(arena, "steps", (n,), dev).copy_(packed[:, 6])
-        dirs_ray = packed[info[:, 0].long().clamp_(max=max(n - 1, 0)), 3:6].contiguous() if n > 0 else None   # rays without samples: unused rows
+        ray_ids = _alloc(arena, "ray_ids", (n,), dev, torch.int32)
+        steps = _alloc(arena, "steps", (n,), dev)
+        dirs_ray = _alloc(arena, "dirs_ray", (R, 3), dev)
+        L.call("tn_ray_aux", dev, L.ptr(packed), L.ptr(info), C.c_int64(R), L.ptr(ray_ids), L.ptr(steps), L.ptr(dirs_ray))
     if n > 0:
         L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(freqs), C.c_int(n_freqs), L.ptr(table), C.c_int(stride))
     return table, ray_ids, stride, steps

@@ -81,28 +81,34 @@ class RaysDataset:
         return {"rays_o": self.rays_o[idx], "rays_d": self.rays_d[idx], "rgbs": self.rgbs[idx]}
 
 
-def parse_nerf_synthetic(scene_path: Path, split: str = "train", bg_color: Tuple[int, int, int] = (255, 255, 255)) -> NerfData:
-    """Blender-synthetic scenes (https://www.matthewtancik.com/nerf), data.py:123-158: RGBA composited over
-    `bg_color`, focal = w / (2 tan(camera_angle_x / 2)), principal point at the image centre."""
+def _composite_over(img, bg_color):
+    """PIL image -> float32 [h,w,3] in [0,1]; RGBA is composited over `bg_color` first."""
     from PIL import Image
-    scene_path = Path(scene_path)
-    with open(scene_path / f"transforms_{split}.json") as f:
-        meta = json.load(f)
-    imgs, cameras = [], []
-    intrinsics = None
-    for frame in meta["frames"]:
-        with Image.open((scene_path / frame["file_path"]).with_suffix(".png")) as img:
-            if intrinsics is None:
-                w, h = img.size
-                focal = w / (2. * np.tan(0.5 * meta["camera_angle_x"]))
-                intrinsics = Intrinsics(focal, focal, w / 2., h / 2., w, h)
-            if img.mode == "RGBA":
-                bg = Image.new("RGBA", img.size, bg_color)
-                img = Image.alpha_composite(bg, img).convert("RGB")
-            imgs.append(torch.from_numpy(np.array(img, dtype=np.single)) / 255.)
-        cameras.append(frame["transform_matrix"])
-    assert intrinsics is not None
-    return NerfData(imgs=imgs, cameras=torch.tensor(cameras, dtype=torch.float), intrinsics=intrinsics,
+    if img.mode == "RGBA":
+        img = Image.alpha_composite(Image.new("RGBA", img.size, bg_color), img).convert("RGB")
+    return torch.from_numpy(np.asarray(img, dtype=np.float32) / np.float32(255.))
+
+
+def parse_nerf_synthetic(scene_path: Path, split: str = "train", bg_color: Tuple[int, int, int] = (255, 255, 255)) -> NerfData:
+    """Blender-synthetic scenes (https://www.matthewtancik.com/nerf), data.py:123-158: frames listed in
+    ``transforms_<split>.json``, RGBA composited over `bg_color`, one pinhole camera for the whole split with
+    focal = w / (2 tan(camera_angle_x / 2)) and the principal point at the image centre."""
+    from PIL import Image
+    root = Path(scene_path)
+    meta = json.loads((root / f"transforms_{split}.json").read_text())
+    frames = meta["frames"]
+    if not frames:
+        raise ValueError(f"{root}: no frames in split {split!r}")
+    images = []
+    size = None
+    for frame in frames:
+        with Image.open((root / frame["file_path"]).with_suffix(".png")) as img:
+            size = size or img.size
+            images.append(_composite_over(img, bg_color))
+    width, height = size
+    focal = width / (2. * np.tan(0.5 * meta["camera_angle_x"]))
+    poses = torch.tensor([frame["transform_matrix"] for frame in frames], dtype=torch.float)
+    return NerfData(cameras=poses, intrinsics=Intrinsics(focal, focal, width / 2., height / 2., width, height), imgs=images,
                     bg_color=torch.tensor(bg_color, dtype=torch.float) / 255.)
 
 

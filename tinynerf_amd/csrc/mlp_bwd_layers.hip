@@ -53,7 +53,7 @@ __device__ __forceinline__ int col0(const MlpArgs &a, int q) { return layer0_col
 // ------------------------------------------------------------------------------------------------
 // FWD_ONLY (training forward, tn_mlp_fwd_stash on a wide / deep stack): y is written, and buffer A receives the last
 // layer's PRE-ACTIVATION instead of the output gradient; out_grad_kernel turns it into the gradient when the backward runs.
-template <int H, int WPB, bool FWD_ONLY = false>
+template <int H, int WPB, bool FWD_ONLY = false, bool FIRST_ONLY = false>
 __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ stash,
                                                              float *__restrict__ y = nullptr)
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
             act[ob] = tn::relu16(act[ob]);
             store_rows(st, act[ob], ob, j, h);
         }
+        if constexpr (FIRST_ONLY) continue;        // the remaining layers run as fwd_lds_kernel launches
         for (int l = 1; l + 1 < L; ++l) {
             tn::hidden_layer<H>(a.W[l], a.B[l], H, act, j, h);
 #pragma unroll
@@ -328,6 +329,86 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
+// training forward of one wide layer (H = 128 / 256, K == H) with the weights in LDS -- the forward twin of
+// dgrad_lds_kernel.  The all-layers kernel above re-reads each 256 KB weight matrix from L2 per 32-sample tile (16.7 ms for
+// the 10-layer 256-wide stack and 2^20 samples where the MFMAs need 8.5); here a workgroup stages the 32*NOT weight ROWS
+// (output features) it is responsible for once, every wave walks its tiles with the layer input H_{l-1} in registers (read
+// back from the workspace rows the previous launch wrote, which are already in B-operand layout) and one ds_read_b128 per
+// four MFMAs.  LAST: no ReLU; writes y and the pre-activation rows the backward's out_grad_kernel expects.
+// ------------------------------------------------------------------------------------------------
+struct FwdLayerArgs {
+    const float *W, *B;   // [N][K] torch layout, [N]
+    int N, K;
+    int rows_total, off_in, off_out;
+    int out_act;
+};
+
+template <int H, int NOT, int WPB, bool LAST>
+__global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = H / 32;
+    constexpr int SW = H + 4;                              // LDS row stride (floats): b128 reads of 16 rows hit 64 banks
+    const int ot0 = blockIdx.y * NOT;
+    for (int e = threadIdx.x; e < 32 * NOT * (H / 4); e += blockDim.x) {
+        const int o = e / (H / 4), c = (e - o * (H / 4)) * 4;
+        const int nn = 32 * ot0 + o;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nn < a.N) v = *reinterpret_cast<const f32x4 *>(a.W + (int64_t)nn * a.K + c);
+        *reinterpret_cast<f32x4 *>(lds + o * SW + c) = v;
+    }
+    __syncthreads();
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int n_ot = min(NOT, ((a.N + 31) >> 5) - ot0);
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        float *st = stash + tile * (int64_t)a.rows_total * 32;
+        const float *in = st + a.off_in * 32;
+        float *outp = st + a.off_out * 32;
+        f32x16 A[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) A[t][r] = in[(32 * t + frow(r, h)) * 32 + j];
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+#pragma clang loop unroll(disable)
+        for (int otl = 0; otl < n_ot; ++otl) {
+            const int ot = ot0 + otl;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int f = 32 * ot + frow(r, h); acc[r] = a.B[f < a.N ? f : 0]; }
+            const float *wl = lds + (32 * otl + j) * SW + 4 * h;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wl + 32 * t + 8 * q);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], A[t][4 * q + u], acc);
+                }
+            }
+            tn::pin16(acc);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) outp[(32 * ot + frow(r, h)) * 32 + j] = fmaxf(acc[r], 0.0f);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 32 * ot + frow(r, h);
+                    const bool ok = valid && f < a.N;
+                    outp[f * 32 + j] = ok ? acc[r] : 0.0f;
+                    if (ok) y[row * a.N + f] = tn::apply_act(acc[r], a.out_act);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -428,12 +509,127 @@ __global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const flo
     }
 }
 
+// Hidden layers of the 256-wide stack (N = K = 256, 8 x 8 output tiles): a wave owns a BN x BK block of tiles instead of
+// eight scattered ones, so per 32-sample tile it loads BN + BK operand row blocks instead of 2 * BN * BK (the generic kernel
+// spends its time in the texture path: 64 16-byte loads per wave and tile for 128 MFMAs; here 24).
+template <int BN, int BK>
+__global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
+{
+    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int WK = ((a.K + 31) >> 5) / BK;                 // waves along k
+    const int tn0 = (wave / WK) * BN, tk0 = (wave % WK) * BK;
+    f32x16 acc[BN][BK];
+    float dbacc[BN];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn) {
+        dbacc[bn] = 0.0f;
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bn][bk][r] = 0.0f;
+    }
+    const int64_t goff = (int64_t)(a.off_g + 32 * tn0 + i) * 32 + 16 * h;
+    const int64_t aoff = (int64_t)(a.off_a + 32 * tk0 + i) * 32 + 16 * h;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *st = stash + tile * (int64_t)a.rows_total * 32;
+        f32x4 gv[BN][4];
+#pragma unroll
+        for (int bn = 0; bn < BN; ++bn) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + goff + bn * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[bn][e] = p[e];
+        }
+        f32x4 av[2][4];
+        {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[0][e] = p[e];
+        }
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            if (bk + 1 < BK) {
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff + (bk + 1) * 1024);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[(bk + 1) & 1][e] = p[e];
+            }
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[bn][bk] = tn::mfma32(gv[bn][e][u], av[bk & 1][e][u], acc[bn][bk]);
+        }
+        if (tk0 == 0) {
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += (gv[bn][e][0] + gv[bn][e][1]) + (gv[bn][e][2] + gv[bn][e][3]);
+                dbacc[bn] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn) {
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            tn::pin16(acc[bn][bk]);
+            const int k = 32 * (tk0 + bk) + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * (tn0 + bn) + frow(r, h);
+                atomicAdd(&a.gW[(int64_t)nn * a.K + k], acc[bn][bk][r]);
+            }
+        }
+        if (tk0 == 0) {
+            float s = dbacc[bn];
+            s += __shfl_xor(s, 32, 64);
+            if (h == 0) atomicAdd(&a.gB[32 * (tn0 + bn) + i], s);
+        }
+    }
+}
+
+template <int H, bool LAST>
+int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    constexpr int NOT = 4, WL = 8;
+    constexpr size_t lds_bytes = (size_t)32 * NOT * (H + 4) * 4;
+    auto kern = fwd_lds_kernel<H, NOT, WL, LAST>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int groups = (((f.N + 31) / 32) + NOT - 1) / NOT;
+    const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + WL - 1) / WL, (256 * per_cu) / groups));
+    kern<<<dim3((unsigned)bl, (unsigned)groups), dim3(WL * 64), lds_bytes, s>>>(f, n, stash, y);
+    return tn::check_launch("fwd_lds_kernel");
+}
+
 template <int H>
 int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s)
 {
     const int64_t n_tiles = (n + 31) / 32;
     constexpr int WPB = H <= 64 ? 8 : 4;
     const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
+    if constexpr (H >= 128) {
+        const int L = a.n_layers, out = a.out_dim;
+        if (L >= 3 && out > 4 && out <= H) {      // first layer, then one launch per layer with W in LDS
+            const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
+            fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
+                a, x, aux, nullptr, n, stash, y);
+            if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
+            for (int l = 1; l < L; ++l) {
+                FwdLayerArgs f;
+                f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.rows_total = lay.total;
+                f.off_in = (l - 1) * H; f.off_out = l + 1 < L ? l * H : lay.rowsH + lay.rowsE; f.out_act = a.out_act;
+                const int rc = l + 1 < L ? launch_fwd_lds<H, false>(f, n, stash, y, s) : launch_fwd_lds<H, true>(f, n, stash, y, s);
+                if (rc) return rc;
+            }
+            return TN_OK;
+        }
+    }
     fwd_stash_kernel<H, WPB, true><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, nullptr, n, stash, y);
     return tn::check_launch("fwd_stash_kernel(forward)");
 }
@@ -464,7 +660,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
-        if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
+        if (!w.first && w.N == 256 && w.K == 256) wgrad_block_kernel<2, 4><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, n, stash);
+        else if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else if (tiles <= 64) wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: layer too large for the wgrad tiling");
         if (int rc = tn::check_launch("wgrad_layer_kernel")) return rc;

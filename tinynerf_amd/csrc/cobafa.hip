@@ -20,30 +20,6 @@ struct CbArgs {
     float *gbasis[TN_COBAFA_MAX_LEVELS];
 };
 
-struct Taps3 {
-    int off[8];      // voxel index (z*H + y)*W + x, or -1 when out of bounds
-    float w[8];
-};
-
-// ATen grid_sampler_3d conventions (align_corners=True, zeros padding); p = (x -> W, y -> H, z -> D)
-__device__ __forceinline__ Taps3 taps3(const float p[3], int D, int H, int W) {
-    Taps3 t;
-    const float ix = ((p[0] + 1.0f) * 0.5f) * (float)(W - 1);
-    const float iy = ((p[1] + 1.0f) * 0.5f) * (float)(H - 1);
-    const float iz = ((p[2] + 1.0f) * 0.5f) * (float)(D - 1);
-    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
-    const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
-    const float gx = (x0 + 1.0f) - ix, gy = (y0 + 1.0f) - iy, gz = (z0 + 1.0f) - iz;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float cx = x0 + (float)(k & 1), cy = y0 + (float)((k >> 1) & 1), cz = z0 + (float)(k >> 2);
-        const bool ok = cx >= 0.0f && cx < (float)W && cy >= 0.0f && cy < (float)H && cz >= 0.0f && cz < (float)D;
-        t.off[k] = ok ? ((int)cz * H + (int)cy) * W + (int)cx : -1;
-        t.w[k] = ((k & 1) ? fx : gx) * (((k >> 1) & 1) ? fy : gy) * ((k >> 2) ? fz : gz);
-    }
-    return t;
-}
-
 __device__ __forceinline__ void sawtooth(const float x[3], float f, float y[3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -53,55 +29,7 @@ __device__ __forceinline__ void sawtooth(const float x[3], float f, float y[3]) 
     }
 }
 
-__global__ __launch_bounds__(256) void cobafa_fwd_kernel(CbArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ feat)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
-    float coef[TN_COBAFA_MAX_LEVELS];
-#pragma unroll
-    for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) coef[l] = 0.0f;
-    {
-        const Taps3 t = taps3(p, a.cres[0], a.cres[1], a.cres[2]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (t.off[k] < 0) continue;
-            const float *v = a.coef + (int64_t)t.off[k] * a.n_levels;
-#pragma unroll
-            for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l)
-                if (l < a.n_levels) coef[l] += v[l] * t.w[k];
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) {
-        if (l >= a.n_levels) break;
-        float y[3];
-        sawtooth(p, a.freq[l], y);
-        const Taps3 t = taps3(y, a.res[l][0], a.res[l][1], a.res[l][2]);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int C = a.ch[l];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (t.off[k] < 0) continue;
-            const float *v = a.basis[l] + (int64_t)t.off[k] * C;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < C) acc[c] += v[c] * t.w[k];
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < C) feat[i * a.feat_dim + a.off[l] + c] = acc[c] * coef[l];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward: transposed scatter.  A lane-per-sample scatter issues wave atomics whose 64 lanes hit 64 different lines
-// (~20 G lane-atomics/s on the chip: 17.7 ms for 2^20 samples x 8 taps x 42 channels).  Here a wave does the per-sample
-// arithmetic with lane = sample (phase A: cell, fractions, the forward values the coefficient gradient needs), publishes
-// g * coef through a wave-private LDS tile, and then walks its samples with lane = (tap, channel) (phase B): the per-sample
-// cell / fractions travel as scalars (v_readlane), the two x-adjacent taps' channels are one contiguous 32-64 B run, so an
-// atomic instruction is 4-8 memory requests instead of 64.  Levels with <= 4 channels take two samples per instruction.
-// ------------------------------------------------------------------------------------------------
+// ATen grid_sampler_3d conventions (align_corners=True, zeros padding); p = (x -> W, y -> H, z -> D)
 struct Cell3 {
     int base, mask;                    // voxel index of the (x0,y0,z0) corner; bit k: tap k is inside the grid
     float fx, gx, fy, gy, fz, gz;
@@ -146,6 +74,34 @@ __device__ __forceinline__ void gather8(const Cell3 &t, const float *__restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void cobafa_fwd_kernel(CbArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ feat)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    float coef[8];
+    gather8(cell3(p, a.cres[0], a.cres[1], a.cres[2]), a.coef, a.n_levels, a.cres[1], a.cres[2], coef);
+#pragma unroll
+    for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) {
+        if (l >= a.n_levels) break;
+        float y[3], acc[8];
+        sawtooth(p, a.freq[l], y);
+        const int C = a.ch[l];
+        gather8(cell3(y, a.res[l][0], a.res[l][1], a.res[l][2]), a.basis[l], C, a.res[l][1], a.res[l][2], acc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) feat[i * a.feat_dim + a.off[l] + c] = acc[c] * coef[l];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: transposed scatter.  A lane-per-sample scatter issues wave atomics whose 64 lanes hit 64 different lines
+// (~20 G lane-atomics/s on the chip: 17.7 ms for 2^20 samples x 8 taps x 42 channels).  Here a wave does the per-sample
+// arithmetic with lane = sample (phase A: cell, fractions, the forward values the coefficient gradient needs), publishes
+// g * coef through a wave-private LDS tile, and then walks its samples with lane = (tap, channel) (phase B): the per-sample
+// cell / fractions travel as scalars (v_readlane), the two x-adjacent taps' channels are one contiguous 32-64 B run, so an
+// atomic instruction is 4-8 memory requests instead of 64.  Levels with <= 4 channels take two samples per instruction.
+// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rl(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
 __device__ __forceinline__ float rl(float v, int s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); }
 

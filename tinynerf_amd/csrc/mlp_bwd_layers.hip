@@ -532,24 +532,40 @@ __global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n
     }
     const int64_t goff = (int64_t)(a.off_g + 32 * tn0 + i) * 32 + 16 * h;
     const int64_t aoff = (int64_t)(a.off_a + 32 * tk0 + i) * 32 + 16 * h;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // the next tile's G blocks and first A block are requested before this tile's MFMAs (a tile's loads would otherwise be
+    // a full HBM latency in front of 32 * BN * BK MFMAs); the other A blocks follow one block ahead
+    f32x4 gvn[BN][4], avn[4];
+    auto prefetch = [&](int64_t tile) {
         const float *st = stash + tile * (int64_t)a.rows_total * 32;
-        f32x4 gv[BN][4];
 #pragma unroll
         for (int bn = 0; bn < BN; ++bn) {
             const f32x4 *p = reinterpret_cast<const f32x4 *>(st + goff + bn * 1024);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gv[bn][e] = p[e];
+            for (int e = 0; e < 4; ++e) gvn[bn][e] = p[e];
         }
-        f32x4 av[2][4];
-        {
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff);
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[0][e] = p[e];
+        for (int e = 0; e < 4; ++e) avn[e] = p[e];
+    };
+    if ((int64_t)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *st = stash + tile * (int64_t)a.rows_total * 32;
+        f32x4 gv[BN][4], av[2][4];
+#pragma unroll
+        for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[bn][e] = gvn[bn][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[0][e] = avn[e];
+        if (BK > 1) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff + 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[1][e] = p[e];
         }
+        prefetch(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
 #pragma unroll
         for (int bk = 0; bk < BK; ++bk) {
-            if (bk + 1 < BK) {
+            if (bk >= 1 && bk + 1 < BK) {
                 const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff + (bk + 1) * 1024);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[(bk + 1) & 1][e] = p[e];
@@ -661,6 +677,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
         if (!w.first && w.N == 256 && w.K == 256) wgrad_block_kernel<2, 4><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, n, stash);
+        else if (!w.first && w.N == 128 && w.K == 128) wgrad_block_kernel<2, 1><<<dim3((unsigned)std::min<int64_t>(n_tiles, 256)), dim3(512), 0, s>>>(w, n, stash);
         else if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else if (tiles <= 64) wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: layer too large for the wgrad tiling");

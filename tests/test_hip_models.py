@@ -194,7 +194,7 @@ def test_cobafa_default_config_against_grid_sample():
     torch.manual_seed(3)
     res, ch, freqs = [32, 51, 70, 89, 108, 128], [8, 8, 8, 4, 4, 4], [2., 3.2, 4.4, 5.6, 6.8, 8.]
     cf = m.CobafaFeatureField(basis_res=res, coef_res=64, freqs=freqs, channels=ch, mlp_hidden_dim=128).to(DEV)
-    x = (torch.rand(20000, 3, device=DEV) * 2.4 - 1.2)
+    x = (torch.rand(20001, 3, device=DEV) * 2.4 - 1.2)
     feat = cf.features(x)
     gfeat = torch.randn_like(feat)
     (feat * gfeat).sum().backward()

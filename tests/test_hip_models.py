@@ -539,6 +539,68 @@ def test_mlp_bwd_pair_matches_two_single_head_backwards():
         np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b_.abs().max())))
 
 
+def test_mlp_pair_full_size_properties():
+    """BASELINE config 3's size (2^20 + 13 packed samples, K-Planes heads): (i) rows of the two-head training forward equal a
+    plain torch fp32 evaluation of the same modules on a random subset; (ii) parameter gradients are additive over a split of
+    the batch -- bwd(all) == bwd(first part) + bwd(rest) -- which no per-tile or per-workgroup bookkeeping error survives."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L
+    from tinynerf_amd.models import _mlp_desc
+    m = models()
+    torch.manual_seed(5)
+    n, R, F = (1 << 20) + 13, 22579, 96
+    dev = torch.device(DEV)
+    sig = m.VanillaOpacityDecoder(F).to(dev)
+    cd = m.VanillaColorDecoder(8, F, 64, 3).to(dev)
+    sp = [p.detach().contiguous() for p in sig.net.params()]
+    rp = [p.detach().contiguous() for p in cd.net.params()]
+    x = torch.rand(n, F, device=dev)
+    ray_ids = torch.sort(torch.randint(0, R, (n,), device=dev, dtype=torch.int32)).values.contiguous()
+    dirs_ray = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+    table = torch.empty(R, 56, device=dev)
+    L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(cd.pe.freqs), C.c_int(8), L.ptr(table), C.c_int(56))
+    g_rgb, g_sig = torch.randn(n, 3, device=dev), torch.randn(n, 1, device=dev)
+    fn = L.lib().tn_mlp_bwd_workspace_bytes
+    fn.restype = C.c_int64
+
+    def run(lo, hi):
+        k = hi - lo
+        xs, ids, gr, gs_ = x[lo:hi], ray_ids[lo:hi].contiguous(), g_rgb[lo:hi], g_sig[lo:hi]
+        rd = _mlp_desc(rp, F, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, cd.pe.freqs, 0, ids, 56)
+        sd = _mlp_desc(sp, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, 0, None, 0)
+        nbr, nbs = int(fn(C.byref(rd), C.c_int64(k))), int(fn(C.byref(sd), C.c_int64(k)))
+        wr, wsg = torch.empty(nbr // 4, device=dev), torch.empty(nbs // 4, device=dev)
+        rgb, sigma = torch.empty(k, 3, device=dev), torch.empty(k, 1, device=dev)
+        L.call("tn_mlp_fwd_stash_pair", dev, C.byref(rd), C.byref(sd), L.ptr(xs), L.ptr(table), C.c_int64(k), L.ptr(rgb), L.ptr(sigma),
+               L.ptr(wr), C.c_int64(nbr), L.ptr(wsg), C.c_int64(nbs))
+        rd.flags = sd.flags = L.MLP_STASHED
+        grs, gss = [torch.zeros_like(p) for p in rp], [torch.zeros_like(p) for p in sp]
+        arr = lambda gs, o: (C.c_void_p * (len(gs) // 2))(*[g.data_ptr() for g in gs[o::2]])
+        gx = torch.empty(k, F, device=dev)
+        L.call("tn_mlp_bwd_pair", dev, C.byref(rd), C.byref(sd), L.ptr(xs), L.ptr(table), L.ptr(gr), L.ptr(gs_), C.c_int64(k),
+               arr(grs, 0), arr(grs, 1), arr(gss, 0), arr(gss, 1), L.ptr(gx), L.ptr(wr), C.c_int64(nbr), L.ptr(wsg), C.c_int64(nbs))
+        return rgb, sigma, grs + gss, gx
+
+    rgb, sigma, g_all, gx = run(0, n)
+    pick = torch.randint(0, n, (8192,), device=dev)
+    pick[-1] = n - 1
+    with torch.no_grad():
+        d = dirs_ray[ray_ids[pick].long()]
+        pe = torch.cat([torch.sin(d[..., None] * cd.pe.freqs), torch.cos(d[..., None] * cd.pe.freqs)], -1).flatten(-2)
+        ref_rgb = torch.sigmoid(cd.net.net(torch.cat([pe, d, x[pick]], -1)))
+        ref_sig = torch.exp(sig.net.net(x[pick]) - 1.0)
+    np.testing.assert_allclose(rgb[pick].cpu().numpy(), ref_rgb.cpu().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(sigma[pick].cpu().numpy(), ref_sig.cpu().numpy(), rtol=1e-5, atol=TOL)
+    cut = 400_007                                           # not a multiple of the 32-sample tile
+    _, _, g_a, gx_a = run(0, cut)
+    _, _, g_b, gx_b = run(cut, n)
+    for t, a_, b_ in zip(g_all, g_a, g_b):
+        r = (a_ + b_).cpu().numpy()
+        np.testing.assert_allclose(t.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(r).max())))
+    assert torch.equal(gx[:cut][:cut - cut % 32], gx_a[:cut - cut % 32])          # whole tiles see the same arithmetic
+    np.testing.assert_allclose(gx[cut:].cpu().numpy(), gx_b.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
 def test_adam_with_folded_regulariser_matches_two_passes():
     """FusedAdam.step(plane_reg=...) (tn_adam_reg_multi: TV / L1 gradient built from the current planes inside the update,
     new values written to a second buffer and swapped in) against regulariser_step() followed by a plain FusedAdam.step()."""

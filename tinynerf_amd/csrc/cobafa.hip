@@ -2,7 +2,7 @@
 // the coefficient grid (L channels) and, per level, one trilinear lookup of the sawtooth-warped point into a
 // basis grid; features = basis * coefficient, levels concatenated.  Replaces 7 x grid_sampler_3d + transposes
 // + muls + cat of the reference with one launch each way.  Channel-last grids: a voxel's channels are one
-// 16-32 B run.  Forward: thread = sample (36 outputs); backward: transposed scatter (see below).
+// 16-32 B run.
 #include "tn_common.h"
 #include <algorithm>
 
@@ -59,127 +59,112 @@ __device__ __forceinline__ float tap_weight(const Cell3 &t, int k) {
 }
 __device__ __forceinline__ int tap_delta(int k, int H, int W) { return (k & 1) + ((k >> 1) & 1) * W + (k >> 2) * W * H; }
 
-// lane = sample: sum_k w_k * grid[tap k][c]; taps outside the grid are read from voxel 0 with weight 0
-__device__ __forceinline__ void gather8(const Cell3 &t, const float *__restrict__ grid, int C, int H, int W, float acc[8]) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool ok = (t.mask >> k) & 1;
-        const float *v = grid + (int64_t)(ok ? t.base + tap_delta(k, H, W) : 0) * C;
-        const float w = ok ? tap_weight(t, k) : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < C) acc[c] += v[c] * w;
-    }
-}
-
-__global__ __launch_bounds__(256) void cobafa_fwd_kernel(CbArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ feat)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
-    float coef[8];
-    gather8(cell3(p, a.cres[0], a.cres[1], a.cres[2]), a.coef, a.n_levels, a.cres[1], a.cres[2], coef);
-#pragma unroll
-    for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) {
-        if (l >= a.n_levels) break;
-        float y[3], acc[8];
-        sawtooth(p, a.freq[l], y);
-        const int C = a.ch[l];
-        gather8(cell3(y, a.res[l][0], a.res[l][1], a.res[l][2]), a.basis[l], C, a.res[l][1], a.res[l][2], acc);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < C) feat[i * a.feat_dim + a.off[l] + c] = acc[c] * coef[l];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward: transposed scatter.  A lane-per-sample scatter issues wave atomics whose 64 lanes hit 64 different lines
-// (~20 G lane-atomics/s on the chip: 17.7 ms for 2^20 samples x 8 taps x 42 channels).  Here a wave does the per-sample
-// arithmetic with lane = sample (phase A: cell, fractions, the forward values the coefficient gradient needs), publishes
-// g * coef through a wave-private LDS tile, and then walks its samples with lane = (tap, channel) (phase B): the per-sample
-// cell / fractions travel as scalars (v_readlane), the two x-adjacent taps' channels are one contiguous 32-64 B run, so an
-// atomic instruction is 4-8 memory requests instead of 64.  Levels with <= 4 channels take two samples per instruction.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rl(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
 __device__ __forceinline__ float rl(float v, int s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); }
 
-// phase B of one grid: tile[s * 8 + c] holds the per-sample, per-channel factor; every tap receives factor * w_tap
-__device__ __forceinline__ void scatter_grid(const float *tile, const Cell3 &t, int C, int H, int W, float *__restrict__ grad, int cnt, int lane)
-{
-    if (C > 4) {
-        const int k = lane >> 3, c = lane & 7;
-        const int dk = tap_delta(k, H, W);
-#pragma unroll 4
-        for (int s = 0; s < cnt; ++s) {
-            Cell3 u;
-            u.base = rl(t.base, s); u.mask = rl(t.mask, s);
-            u.fx = rl(t.fx, s); u.gx = rl(t.gx, s); u.fy = rl(t.fy, s); u.gy = rl(t.gy, s); u.fz = rl(t.fz, s); u.gz = rl(t.gz, s);
-            const float v = tile[s * 8 + c] * tap_weight(u, k);
-            if (((u.mask >> k) & 1) && c < C) atomicAdd(grad + (int64_t)(u.base + dk) * C + c, v);
-        }
-    } else {
-        const int half = lane >> 5, k = (lane >> 2) & 7, c = lane & 3;
-        const int dk = tap_delta(k, H, W);
-#pragma unroll 2
-        for (int s = 0; s < cnt; s += 2) {
-            const int s1 = s + 1 < 64 ? s + 1 : 63;
-            Cell3 u;
-            u.base = half ? rl(t.base, s1) : rl(t.base, s); u.mask = half ? rl(t.mask, s1) : rl(t.mask, s);
-            u.fx = half ? rl(t.fx, s1) : rl(t.fx, s); u.gx = half ? rl(t.gx, s1) : rl(t.gx, s);
-            u.fy = half ? rl(t.fy, s1) : rl(t.fy, s); u.gy = half ? rl(t.gy, s1) : rl(t.gy, s);
-            u.fz = half ? rl(t.fz, s1) : rl(t.fz, s); u.gz = half ? rl(t.gz, s1) : rl(t.gz, s);
-            const int ss = s + half;
-            const float v = tile[(ss < 64 ? ss : 63) * 8 + c] * tap_weight(u, k);
-            if (ss < cnt && ((u.mask >> k) & 1) && c < C) atomicAdd(grad + (int64_t)(u.base + dk) * C + c, v);
-        }
-    }
-}
-
 constexpr int CB_WAVES = 4;
 
-__global__ __launch_bounds__(CB_WAVES * 64) void cobafa_bwd_kernel(CbArgs a, const float *__restrict__ x, int64_t n,
-                                                                   const float *__restrict__ gfeat)
+// ------------------------------------------------------------------------------------------------
+// Both directions in transposed form: lane = (tap k = lane >> 3, channel c = lane & 7), a wave walks its 64 samples.
+// A lane-per-sample gather / scatter touches 64 different lines per instruction (the scatter ran at ~20 G lane-atomics/s:
+// 17.7 ms for 2^20 samples x 8 taps x 42 channels; this form: 2.2 ms, forward 1.6 -> 0.8 ms); here a level of a
+// sample is ONE load instruction whose x-adjacent taps form 32-64 B runs (4 requests), the 8 taps are summed with three
+// cross-lane adds, and the backward scatters through the very addresses it gathered from.  Per-sample cells travel as
+// wave scalars (v_readlane).  Forward results go through a wave-private LDS tile and leave as one contiguous block;
+// the backward stages its slice of grad_feat the same way.  NL > 0: compile-time level count (straight-line level loop).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Cell3 bcast(const Cell3 &t, int s) {
+    Cell3 u;
+    u.base = rl(t.base, s); u.mask = rl(t.mask, s);
+    u.fx = rl(t.fx, s); u.gx = rl(t.gx, s); u.fy = rl(t.fy, s); u.gy = rl(t.gy, s); u.fz = rl(t.fz, s); u.gz = rl(t.gz, s);
+    return u;
+}
+__device__ __forceinline__ float sum_taps(float v) {          // over k = lane bits 3..5
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float sum_channels(float v) {      // over c = lane bits 0..2
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+template <bool BWD, int NL>
+__global__ __launch_bounds__(CB_WAVES * 64) void cobafa_t_kernel(CbArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ feat,
+                                                                 const float *__restrict__ gfeat)
 {
-    __shared__ __attribute__((aligned(16))) float lds[CB_WAVES][64 * 8];
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *tile = lds[wave];
+    const int FD = a.feat_dim, n_levels = NL > 0 ? NL : a.n_levels;
+    float *tile = lds_t + wave * 64 * FD;
     const int64_t first = ((int64_t)blockIdx.x * CB_WAVES + wave) * 64;
     if (first >= n) return;                                     // wave-uniform
     const int cnt = (int)(n - first < 64 ? n - first : 64);
     const bool valid = lane < cnt;
     const int64_t i = valid ? first + lane : n - 1;
     const float p[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    // phase 0, lane = sample: the cell of every lookup
     Cell3 tc = cell3(p, a.cres[0], a.cres[1], a.cres[2]);
-    if (!valid) tc.mask = 0;
-    float coef[8], gcoef[TN_COBAFA_MAX_LEVELS];
-    gather8(tc, a.coef, a.n_levels, a.cres[1], a.cres[2], coef);
-#pragma unroll
-    for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) gcoef[l] = 0.0f;
+    Cell3 tl[TN_COBAFA_MAX_LEVELS];
 #pragma unroll
     for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) {
-        if (l >= a.n_levels) break;
+        if (l >= n_levels) break;
         float y[3];
         sawtooth(p, a.freq[l], y);
-        Cell3 t = cell3(y, a.res[l][0], a.res[l][1], a.res[l][2]);
-        if (!valid) t.mask = 0;
-        const int C = a.ch[l], H = a.res[l][1], W = a.res[l][2];
-        float g[8], acc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) g[c] = gfeat[i * a.feat_dim + a.off[l] + (c < C ? c : 0)];
-        gather8(t, a.basis[l], C, H, W, acc);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c >= C) g[c] = 0.0f;
-            gcoef[l] += g[c] * acc[c];                          // d feat / d coef = basis value
-            tile[lane * 8 + c] = g[c] * coef[l];                // d feat / d basis = coef * w
-        }
-        scatter_grid(tile, t, C, H, W, a.gbasis[l], cnt, lane);
+        tl[l] = cell3(y, a.res[l][0], a.res[l][1], a.res[l][2]);
     }
+    if constexpr (BWD) {                                        // this wave's [cnt, FD] block of grad_feat
+        const float *src = gfeat + first * FD;
+        for (int e = lane; e < cnt * FD; e += 64) tile[e] = src[e];
+    }
+    const int k = lane >> 3, c = lane & 7;
+    const int dkc = tap_delta(k, a.cres[1], a.cres[2]);
+    const int cc = c < n_levels ? c : 0;
+    for (int s = 0; s < cnt; ++s) {
+        // coefficient lookup: lane c < n_levels ends up with coef[c] of sample s
+        const Cell3 uc = bcast(tc, s);
+        const bool okc = ((uc.mask >> k) & 1) && c < n_levels;
+        const int64_t ac = (int64_t)(okc ? uc.base + dkc : 0) * n_levels + cc;
+        const float wc = okc ? tap_weight(uc, k) : 0.0f;
+        const float coef = sum_taps(a.coef[ac] * wc);
+        float gcv = 0.0f;                                       // BWD: lane c = level: d loss / d coef[c] of sample s
 #pragma unroll
-    for (int l = 0; l < 8; ++l) tile[lane * 8 + l] = l < TN_COBAFA_MAX_LEVELS ? gcoef[l] : 0.0f;
-    scatter_grid(tile, tc, a.n_levels, a.cres[1], a.cres[2], a.gcoef, cnt, lane);
+        for (int l = 0; l < TN_COBAFA_MAX_LEVELS; ++l) {
+            if (l >= n_levels) break;
+            const int C = a.ch[l];
+            const Cell3 u = bcast(tl[l], s);
+            const bool ok = ((u.mask >> k) & 1) && c < C;
+            const int64_t ad = (int64_t)(ok ? u.base + tap_delta(k, a.res[l][1], a.res[l][2]) : 0) * C + (c < C ? c : 0);
+            const float w = ok ? tap_weight(u, k) : 0.0f;
+            const float val = sum_taps(a.basis[l][ad] * w);      // basis value of channel c (0 for c >= C)
+            const float cl = rl(coef, l);
+            float *slot = tile + s * FD + a.off[l] + (c < C ? c : 0);
+            if constexpr (!BWD) {
+                if (k == 0 && c < C) *slot = val * cl;
+            } else {
+                const float g = c < C ? *slot : 0.0f;
+                const float gc = sum_channels(g * val);           // d feat / d coef = basis value
+                gcv = c == l ? gc : gcv;
+                if (ok) atomicAdd(a.gbasis[l] + ad, g * cl * w);   // d feat / d basis = coef * w
+            }
+        }
+        if constexpr (BWD) {
+            if (okc) atomicAdd(a.gcoef + ac, gcv * wc);
+        }
+    }
+    if constexpr (!BWD) {
+        float *dst = feat + first * FD;
+        for (int e = lane; e < cnt * FD; e += 64) dst[e] = tile[e];
+    }
+}
+
+template <bool BWD>
+int launch_t(const CbArgs &a, const float *x, int64_t n, float *feat, const float *gfeat, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((n + 64 * CB_WAVES - 1) / (64 * CB_WAVES));
+    const size_t lds = (size_t)CB_WAVES * 64 * a.feat_dim * sizeof(float);
+    if (a.n_levels == 6) cobafa_t_kernel<BWD, 6><<<dim3(blocks), dim3(64 * CB_WAVES), lds, s>>>(a, x, n, feat, gfeat);
+    else cobafa_t_kernel<BWD, 0><<<dim3(blocks), dim3(64 * CB_WAVES), lds, s>>>(a, x, n, feat, gfeat);
+    return tn::check_launch(BWD ? "cobafa_t_kernel(backward)" : "cobafa_t_kernel(forward)");
 }
 
 int make_args(const tn_cobafa_desc *d, CbArgs &a)
@@ -211,8 +196,7 @@ extern "C" int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t
     TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_cobafa_fwd: negative n");
     if (n == 0) return TN_OK;
     TN_REQUIRE(x && feat, TN_E_NULL, "tn_cobafa_fwd: null pointer");
-    cobafa_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a, x, n, feat);
-    return tn::check_launch("cobafa_fwd_kernel");
+    return launch_t<false>(a, x, n, feat, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
@@ -228,6 +212,5 @@ extern "C" int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t
         TN_REQUIRE(grad_basis[l], TN_E_NULL, "tn_cobafa_bwd: null basis gradient");
         a.gbasis[l] = grad_basis[l];
     }
-    cobafa_bwd_kernel<<<dim3((unsigned)((n + 64 * CB_WAVES - 1) / (64 * CB_WAVES))), dim3(64 * CB_WAVES), 0, (hipStream_t)stream>>>(a, x, n, grad_feat);
-    return tn::check_launch("cobafa_bwd_kernel");
+    return launch_t<true>(a, x, n, nullptr, grad_feat, (hipStream_t)stream);
 }

@@ -333,6 +333,8 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     dict(kind="mlp", K=36, H=128, layers=5, out=128, n=500),   # Cobafa MLP (run.py:141-147)
     dict(kind="mlp", K=40, H=64, layers=6, out=3, n=257),      # deeper than the register-resident forms cover
     dict(kind="color", F=4, dim=256, H=128, layers=1, n=300),  # reference tests/test_core.py:58 decoder shape
+    dict(kind="vanilla", F=10, H=256, layers=2, n=40037),      # more 32-sample tiles than workgroups / waves: the persistent
+    dict(kind="mlp", K=36, H=128, layers=2, out=128, n=40037), # loops and their next-tile prefetches run several rounds
 ])
 @pytest.mark.parametrize("stash", [True, False])
 def test_wide_deep_mlp_backward_vs_torch(cfg, stash, monkeypatch):

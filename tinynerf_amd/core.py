@@ -459,8 +459,11 @@ class NerfRenderer(torch.nn.Module):
             rgbs = torch.zeros((n_samples, 3), device=device, requires_grad=True)
             weights = torch.zeros(n_samples, device=device, requires_grad=True)
         else:
-            rgb_active = self.rgb_decoder(feats[active], packed_samples[:, 3:6][active])
-            rgbs = torch.zeros((n_samples, 3), device=device).index_copy(0, active, rgb_active)
+            if active.numel() == n_samples:                 # nothing masked: the gather / scatter pair is the identity
+                rgbs = self.rgb_decoder(feats, packed_samples[:, 3:6].contiguous())
+            else:
+                rgb_active = self.rgb_decoder(feats[active], packed_samples[:, 3:6][active])
+                rgbs = torch.zeros((n_samples, 3), device=device).index_copy(0, active, rgb_active)
         if n_rays == 0:
             return torch.zeros((0, 3), device=device)
         return _Composite.apply(rgbs, weights, packing_info.contiguous(), bg)

@@ -167,13 +167,24 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
 __global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__ gy, int64_t n, int out, int out_act, int rows_total,
                                                        int off_g, float *__restrict__ stash)
 {
+    // [32 samples][out] block of gy -> [out][32 samples] rows through LDS: both sides of the transposition are coalesced
+    __shared__ float t[32][257];
     const int64_t n_tiles = (n + 31) >> 5;
     const int j = threadIdx.x & 31, sub = threadIdx.x >> 5;                 // 8 row slots per block
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         float *g = stash + (tile * (int64_t)rows_total + off_g) * 32;
-        const int64_t row = tile * 32 + j;
-        for (int f = sub; f < out; f += 8)
-            g[f * 32 + j] = row < n ? gy[row * out + f] * act_grad(g[f * 32 + j], out_act) : 0.0f;
+        const int64_t e0 = tile * 32 * (int64_t)out, e1 = n * (int64_t)out;
+        for (int e = threadIdx.x; e < 32 * out; e += 256) {
+            const int r = e / out;
+            t[r][e - r * out] = e0 + e < e1 ? gy[e0 + e] : 0.0f;
+        }
+        __syncthreads();
+        for (int f = sub; f < out; f += 8) {
+            float v = t[j][f];
+            if (out_act != TN_ACT_NONE) v *= act_grad(g[f * 32 + j], out_act);       // buffer A holds the pre-activation
+            g[f * 32 + j] = v;
+        }
+        __syncthreads();
     }
 }
 

@@ -347,26 +347,57 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
 // back from the workspace rows the previous launch wrote, which are already in B-operand layout) and one ds_read_b128 per
 // four MFMAs.  LAST: no ReLU; writes y and the pre-activation rows the backward's out_grad_kernel expects.
 // ------------------------------------------------------------------------------------------------
+// positional-encoding inputs of a tile as workspace rows [slot][32 samples] (the E rows of the layout)
+__global__ __launch_bounds__(256) void enc_rows_kernel(MlpArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ stash,
+                                                       int rows_total, int off_e)
+{
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int G0 = a.K0_pad >> 3;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        const float aux3[3] = {xrow[0], xrow[1], xrow[2]};
+        float *stE = stash + (tile * (int64_t)rows_total + off_e) * 32 + j;
+        for (int g = 0; g < G0; ++g) {
+            const f32x4 b = fetch_input(a, xrow, aux3, valid, g, h);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stE[(8 * g + 4 * h + u) * 32] = b[u];
+        }
+    }
+}
+
 struct FwdLayerArgs {
     const float *W, *B;   // [N][K] torch layout, [N]
     int N, K;
+    int Kp;               // input rows present in the workspace (K for hidden layers, K0_pad for the encoded first layer)
     int rows_total, off_in, off_out;
     int out_act;
 };
 
-template <int H, int NOT, int WPB, bool LAST>
+// T = 32-row blocks of the layer input: H / 32 for hidden layers; 2 for the positional-encoding first layer, whose encoded
+// inputs (<= 64 slots) enc_rows_kernel has written as workspace rows (the rows the weight gradient reads anyway)
+template <int H, int T, int NOT, int WPB, bool LAST>
 __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int T = H / 32;
-    constexpr int SW = H + 4;                              // LDS row stride (floats): b128 reads of 16 rows hit 64 banks
+    constexpr int SW = 32 * T + 4;                         // LDS row stride (floats): b128 reads of 16 rows hit 64 banks
     const int ot0 = blockIdx.y * NOT;
-    for (int e = threadIdx.x; e < 32 * NOT * (H / 4); e += blockDim.x) {
-        const int o = e / (H / 4), c = (e - o * (H / 4)) * 4;
-        const int nn = 32 * ot0 + o;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (nn < a.N) v = *reinterpret_cast<const f32x4 *>(a.W + (int64_t)nn * a.K + c);
-        *reinterpret_cast<f32x4 *>(lds + o * SW + c) = v;
+    if (a.K == 32 * T) {
+        for (int e = threadIdx.x; e < 32 * NOT * (8 * T); e += blockDim.x) {
+            const int o = e / (8 * T), c = (e - o * (8 * T)) * 4;
+            const int nn = 32 * ot0 + o;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < a.N) v = *reinterpret_cast<const f32x4 *>(a.W + (int64_t)nn * a.K + c);
+            *reinterpret_cast<f32x4 *>(lds + o * SW + c) = v;
+        }
+    } else {                                               // ragged K (first layer): zero padded
+        for (int e = threadIdx.x; e < 32 * NOT * 32 * T; e += blockDim.x) {
+            const int o = e / (32 * T), c = e - o * (32 * T);
+            const int nn = 32 * ot0 + o;
+            lds[o * SW + c] = (nn < a.N && c < a.K) ? a.W[(int64_t)nn * a.K + c] : 0.0f;
+        }
     }
     __syncthreads();
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
@@ -383,7 +414,14 @@ __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) A[t][r] = in[(32 * t + frow(r, h)) * 32 + j];
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * t + frow(r, h);
+                if constexpr (32 * T == H) A[t][r] = in[k * 32 + j];          // hidden layer: K == H rows, immediate offsets
+                else {
+                    const float v = in[(k < a.Kp ? k : 0) * 32 + j];
+                    A[t][r] = k < a.Kp ? v : 0.0f;                            // rows past Kp belong to another buffer
+                }
+            }
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
 #pragma clang loop unroll(disable)
@@ -618,12 +656,12 @@ __global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n
     }
 }
 
-template <int H, bool LAST>
+template <int H, int T, int NOT, bool LAST>
 int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
 {
-    constexpr int NOT = 4, WL = 8;
-    constexpr size_t lds_bytes = (size_t)32 * NOT * (H + 4) * 4;
-    auto kern = fwd_lds_kernel<H, NOT, WL, LAST>;
+    constexpr int WL = 8;
+    constexpr size_t lds_bytes = (size_t)32 * NOT * (32 * T + 4) * 4;
+    auto kern = fwd_lds_kernel<H, T, NOT, WL, LAST>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
@@ -644,14 +682,24 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
         const int L = a.n_layers, out = a.out_dim;
         if (L >= 3 && out > 4 && out <= H) {      // first layer, then one launch per layer with W in LDS
             const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
-            fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
-                a, x, aux, nullptr, n, stash, y);
-            if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
+            if (a.enc == TN_ENC_POSENC && a.K0_pad <= 64) {      // encoded inputs as rows, then the first layer like any other
+                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, lay.total,
+                                                                                                        lay.rowsH);
+                if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
+                FwdLayerArgs f;
+                f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = lay.total;
+                f.off_in = lay.rowsH; f.off_out = 0; f.out_act = a.out_act;
+                if (int rc = launch_fwd_lds<H, 2, H / 32, false>(f, n, stash, y, s)) return rc;
+            } else {
+                fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
+                    a, x, aux, nullptr, n, stash, y);
+                if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
+            }
             for (int l = 1; l < L; ++l) {
                 FwdLayerArgs f;
-                f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.rows_total = lay.total;
+                f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = lay.total;
                 f.off_in = (l - 1) * H; f.off_out = l + 1 < L ? l * H : lay.rowsH + lay.rowsE; f.out_act = a.out_act;
-                const int rc = l + 1 < L ? launch_fwd_lds<H, false>(f, n, stash, y, s) : launch_fwd_lds<H, true>(f, n, stash, y, s);
+                const int rc = l + 1 < L ? launch_fwd_lds<H, H / 32, 4, false>(f, n, stash, y, s) : launch_fwd_lds<H, H / 32, 4, true>(f, n, stash, y, s);
                 if (rc) return rc;
             }
             return TN_OK;

@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--views", type=int, default=20, help="synthetic 800x800 cameras (640k rays each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rates (profiling runs)")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 17)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 19)
     return ap.parse_args()
 
 
@@ -217,6 +217,31 @@ def main():
         stages = {"sampler_samples_per_s": nb / t_samp, "render_fwd_samples_per_s": nb / t_fwd,
                   "render_fwd_bwd_samples_per_s": nb / t_fb, "batch_samples": nb}
 
+    # the reference's other two model configurations on the same workload (BASELINE configs 2 and 5), N = 1 only: a short
+    # run each, reported beside the headline (never part of `value`)
+    others = None
+    if rank == 0 and world == 1 and not args.no_stages:
+        others = {}
+        for method in ("vanilla", "cobafa"):
+            try:
+                c2 = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
+                t2 = Trainer(c2, o, d, rgbs, torch.ones(3, device=dev), dev)
+                t2.occupancy_grid.grid.copy_(tr.occupancy_grid.grid)
+                t2.occupancy_grid.mean = float(t2.occupancy_grid.grid.mean().item())
+                t2.occupancy_grid_updates = 10 ** 9                      # the refresh schedule is part of the headline run only
+                for _ in range(2):
+                    t2.step()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                n_ = sum(t2.step()["n_samples"] for _ in range(5))
+                torch.cuda.synchronize()
+                t_ = time.perf_counter() - t_
+                others[method] = {"ms_per_step": t_ / 5 * 1e3, "samples_per_s": n_ / t_, "loss": t2.loss_value()}
+                del t2
+                torch.cuda.empty_cache()
+            except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
+                others[method] = {"error": repr(e)}
+
     if rank == 0:
         ks = timer.summary()
         dom = max(ks, key=lambda t: ks[t]["total_ms"]) if ks else None
@@ -252,6 +277,7 @@ def main():
                        "samples_per_step_per_gpu": samples / args.steps / world, "rays_per_step_per_gpu": rays_n / args.steps / world},
             "loss": loss,
             "stages": stages,
+            "other_configs": others,
             "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
             "roofline": roof,
         }

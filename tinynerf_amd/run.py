@@ -244,7 +244,7 @@ class Trainer:
         equal the single-GPU loss; with this normalisation the SUM of rank gradients does."""
         if self.world == 1:
             return float(local_rays)
-        n_rays = torch.tensor([float(local_rays)], device=self.device)
+        n_rays = torch.full((1,), float(local_rays), device=self.device)   # a fill kernel: no pageable H2D copy, no host sync
         torch.distributed.all_reduce(n_rays)
         return n_rays[0]
 

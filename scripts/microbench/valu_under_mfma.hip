@@ -1,15 +1,18 @@
-// VALU issue rate of one wave while another wave on the same SIMD streams fp32 MFMAs
+// VALU issue rate of one wave while another wave on the same SIMD streams fp32 MFMAs, with and without s_setprio.
+// mode 0: VALU waves only; 1: MFMA + VALU waves, default priority; 2: VALU waves at s_setprio 3; 3: MFMA waves at s_setprio 3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(512) void mix(float *out, int iters, int with_mfma, unsigned long long *cycles) {
+__global__ __launch_bounds__(512) void mix(float *out, int iters, int mode, unsigned long long *cycles) {
     const int wave = threadIdx.x >> 6, slot = wave >> 2;
     f32x16 acc; for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float v[8]; for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 1e-3f + k;
     const float y = 1.0001f, z = 0.5f;
+    if (mode == 2 && slot == 1) __builtin_amdgcn_s_setprio(3);
+    if (mode == 3 && slot == 0) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (slot == 0) {
-        if (with_mfma)
+        if (mode != 0)
             for (int i = 0; i < iters; ++i) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y, z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, y, acc, 0, 0, 0);
@@ -30,14 +33,14 @@ __global__ __launch_bounds__(512) void mix(float *out, int iters, int with_mfma,
 int main() {
     float *out; unsigned long long *cyc; hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 64);
     const int iters = 20000;
-    for (int with : {0, 1}) {
-        mix<<<256, 512>>>(out, iters, with, cyc); hipDeviceSynchronize();
+    for (int mode : {0, 1, 2, 3}) {
+        mix<<<256, 512>>>(out, iters, mode, cyc); hipDeviceSynchronize();
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        hipEventRecord(a); mix<<<256, 512>>>(out, iters, with, cyc); hipEventRecord(b); hipEventSynchronize(b);
+        hipEventRecord(a); mix<<<256, 512>>>(out, iters, mode, cyc); hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         unsigned long long c[8]; hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
-        printf("MFMA wave %s: kernel %.3f ms; VALU wave: %.2f ns per fma instruction (32 per iteration); memtime ticks mfma-wave %llu valu-wave %llu\n",
-               with ? "on " : "off", ms, ms * 1e6 / (iters * 32.0), c[0], c[4]);
+        printf("mode %d: kernel %.3f ms (MFMA alone: %.3f ms at 2.4 GHz); memtime ticks mfma-wave %llu valu-wave %llu\n",
+               mode, ms, iters * 2 * 64 / 2.4e6, c[0], c[4]);
     }
     return 0;
 }

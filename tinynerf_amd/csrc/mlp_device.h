@@ -47,9 +47,15 @@ __device__ __forceinline__ void pin16(f32x16 &v) {
     for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));
 }
 
+// one v_max per element: fmaxf() on a value the compiler cannot prove canonical (an MFMA result behind pin16) costs a second,
+// canonicalising v_max (32 extra VALU instructions per 64-wide layer and tile -- VALU time adds to MFMA time on a SIMD)
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+    for (int r = 0; r < 16; ++r) {
+        float y;
+        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(v[r]));
+        v[r] = y;
+    }
     return v;
 }
 

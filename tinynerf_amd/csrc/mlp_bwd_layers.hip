@@ -277,19 +277,19 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 // data gradient of a wide hidden layer (H = 128 / 256, K == H) with the weights in LDS.
 // The generic kernel above reads W from L2 once per MFMA group (5.5 ms per 256x256 layer and 2^20 samples where the
 // MFMAs need 0.9).  Here a workgroup stages the 32*NKT columns of W it is responsible for (all of them for H = 128, one
-// half for H = 256: 135 KB) once, and every wave walks its 32-sample tiles with the input gradient in registers and
-// one conflict-free ds_read_b32 per MFMA for the transposed weight operand.  blockIdx.y selects the column group.
+// half for H = 256: 133 KB) once, TRANSPOSED, and every wave walks its 32-sample tiles with the input gradient in registers
+// and one conflict-free ds_read_b128 per four MFMAs.  blockIdx.y selects the column group.
 // ------------------------------------------------------------------------------------------------
 template <int H, int NKT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_t n, float *__restrict__ stash)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
-    constexpr int SW = 32 * NKT + 4;                      // LDS row stride (floats)
+    constexpr int SW = H + 4;                             // LDS row stride (floats): W^T, one row per input feature k
     const int kt0 = blockIdx.y * NKT;
-    for (int e = threadIdx.x; e < H * 32 * NKT; e += blockDim.x) {
+    for (int e = threadIdx.x; e < H * 32 * NKT; e += blockDim.x) {      // coalesced read of W, transposed into LDS (once)
         const int nn = e / (32 * NKT), c = e - nn * (32 * NKT);
-        lds[nn * SW + c] = nn < a.N ? a.W[(int64_t)nn * a.K + 32 * kt0 + c] : 0.0f;
+        lds[c * SW + nn] = nn < a.N ? a.W[(int64_t)nn * a.K + 32 * kt0 + c] : 0.0f;
     }
     __syncthreads();
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
@@ -320,14 +320,12 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float *wl = lds + 4 * h * SW + 32 * ktl + j;
+            const float *wl = lds + (32 * ktl + j) * SW + 4 * h;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) w[u] = wl[(32 * t + 8 * q + u) * SW];
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wl + 32 * t + 8 * q);     // W[n .. n+3][k]: one ds_read_b128
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], G[t][4 * q + u], acc);
                 }
@@ -752,7 +750,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             if constexpr (H >= 128) {
                 if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS
                     constexpr int NKT = 4, WL = 8;
-                    constexpr size_t lds_bytes = (size_t)H * (32 * NKT + 4) * 4;
+                    constexpr size_t lds_bytes = (size_t)32 * NKT * (H + 4) * 4;
                     auto kern = dgrad_lds_kernel<H, NKT, WL>;
                     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }

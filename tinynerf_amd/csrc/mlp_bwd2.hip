@@ -93,6 +93,19 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     const float *ldsb = lds + a.lds_floats;
     if constexpr (PAIR) stage_weights(pr.b, lds + a.lds_floats);
     __syncthreads();
+    if constexpr (STASHED && NH > 1) {
+        // nothing is recomputed: the hidden layers are only ever read transposed (W_l^T G_l), so transpose them in place once
+        // and let every dgrad operand be one ds_read_b128 (4 consecutive n of one k) instead of four strided ds_read_b32
+        constexpr int sl = H + 4;
+        for (int l = 1; l < NH; ++l) {
+            float *W = lds + a.w_off[l];
+            for (int e = threadIdx.x; e < H * H; e += blockDim.x) {
+                const int r = e / H, c = e - r * H;
+                if (r < c) { const float t = W[r * sl + c]; W[r * sl + c] = W[c * sl + r]; W[c * sl + r] = t; }
+            }
+        }
+        __syncthreads();
+    }
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int64_t n_tiles = (n + 31) >> 5;
@@ -296,29 +309,29 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             // software pipeline over the 4T groups (tn_, q): operands of group g+1 are requested before group g's MFMAs
             {
                 constexpr int NG = 4 * T;
-                float cur[T][4], nxt[T][4];
+                f32x4 cur[T], nxt[T];
+                auto operands = [&](int g, f32x4 (&w)[T]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int kt = 0; kt < T; ++kt) {
+                        if constexpr (STASHED) w[kt] = *reinterpret_cast<const f32x4 *>(Wl + (32 * kt + j) * sl + 8 * g + 4 * h);   // W^T rows
+                        else {
 #pragma unroll
-                    for (int kt = 0; kt < T; ++kt) cur[kt][u] = Wl[(4 * h + u) * sl + 32 * kt + j];
+                            for (int u = 0; u < 4; ++u) w[kt][u] = Wl[(8 * g + 4 * h + u) * sl + 32 * kt + j];
+                        }
+                    }
+                };
+                operands(0, cur);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int tn_ = g >> 2, q = g & 3;
-                    if (g + 1 < NG) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int kt = 0; kt < T; ++kt) nxt[kt][u] = Wl[(8 * (g + 1) + 4 * h + u) * sl + 32 * kt + j];
-                    }
+                    if (g + 1 < NG) operands(g + 1, nxt);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int kt = 0; kt < T; ++kt) Gn[kt] = tn::mfma32(cur[kt][u], G[tn_][4 * q + u], Gn[kt]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int kt = 0; kt < T; ++kt) cur[kt][u] = nxt[kt][u];
+                    for (int kt = 0; kt < T; ++kt) cur[kt] = nxt[kt];
                 }
             }
 #pragma unroll

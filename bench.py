@@ -262,9 +262,9 @@ def main():
                         algorithmic_per_row=unit_work)
             # HBM-side bytes per launch from the committed PMC passes (scripts/pmc.sh); they cannot be collected live
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v9.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v12.json")))
                 roof["traffic"] = pmc["per_entry"].get(dom)
-                roof["traffic_source"] = "profiles/round1_pmc_traffic_v9.json"
+                roof["traffic_source"] = "profiles/round1_pmc_traffic_v12.json"
             except Exception:
                 pass
         line = {

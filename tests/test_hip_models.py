@@ -187,13 +187,16 @@ def test_cobafa_forward():
     assert out.shape == (128, 32)
 
 
-def test_cobafa_default_config_against_grid_sample():
-    """run.py:176-181's Cobafa configuration (6 levels, 36 features): forward and every grid gradient against ATen's
-    CPU grid_sampler_3d (what the reference runs), points partly outside [-1,1] (zeros padding)."""
+@pytest.mark.parametrize("res,ch,freqs,coef_res", [
+    ([32, 51, 70, 89, 108, 128], [8, 8, 8, 4, 4, 4], [2., 3.2, 4.4, 5.6, 6.8, 8.], 64),      # run.py:176-181
+    ([7, 12, 9], [2, 5, 8], [1.5, 2.5, 4.], 6),                                               # run-time level count, odd channel counts
+])
+def test_cobafa_default_config_against_grid_sample(res, ch, freqs, coef_res):
+    """run.py:176-181's Cobafa configuration (6 levels, 36 features) and a small irregular one: forward and every grid gradient
+    against ATen's CPU grid_sampler_3d (what the reference runs), points partly outside [-1,1] (zeros padding)."""
     m = models()
     torch.manual_seed(3)
-    res, ch, freqs = [32, 51, 70, 89, 108, 128], [8, 8, 8, 4, 4, 4], [2., 3.2, 4.4, 5.6, 6.8, 8.]
-    cf = m.CobafaFeatureField(basis_res=res, coef_res=64, freqs=freqs, channels=ch, mlp_hidden_dim=128).to(DEV)
+    cf = m.CobafaFeatureField(basis_res=res, coef_res=coef_res, freqs=freqs, channels=ch, mlp_hidden_dim=128).to(DEV)
     x = (torch.rand(20001, 3, device=DEV) * 2.4 - 1.2)
     feat = cf.features(x)
     gfeat = torch.randn_like(feat)
@@ -216,7 +219,7 @@ def test_cobafa_default_config_against_grid_sample():
     y = cf.coef_grid(x[:64])
     np.testing.assert_allclose(y.detach().cpu().numpy(), lookup(leaves["coef_grid.grid"], xc[:64]).detach().numpy(), rtol=0, atol=TOL)
     # empty input
-    assert cf.features(x[:0]).shape == (0, 36)
+    assert cf.features(x[:0]).shape == (0, sum(ch))
 
 
 def test_cobafa_renderer_trains():

@@ -133,11 +133,48 @@ def cpu_baseline(trainer, n_target: int):
                       f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, {cores} threads (best of 32/64), best of 2 after warm-up"}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as fresh child processes and
+    relay rank 0's JSON line.  The parent never touches the GPU (`torch.cuda.device_count()` does not initialise it
+    on this image), the children are plain `python bench.py` processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set -- the same environment `python -m torch.distributed.run` gives them.  Any failing rank fails the run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    visible = torch.cuda.device_count()
+    shared = os.environ.get("TN_BENCH_BACKEND", "nccl") != "nccl"
+    if visible < n and not shared:
+        sys.stderr.write(f"bench.py --gpus {n}: only {visible} GPU(s) visible (TN_BENCH_BACKEND=gloo shares GPUs between "
+                         f"ranks for debugging; its numbers are not scaling measurements)\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write(f"bench.py --gpus {n}: rank exit codes {codes}\n")
+        sys.stdout.write(out or "")
+        return 1
+    sys.stdout.write(out)
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: tinynerf_amd has no CPU path")
     # one rank per GPU over RCCL.  TN_BENCH_BACKEND=gloo (debug) lets several ranks share one GPU to exercise the N > 1 path
@@ -273,7 +310,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
-                       "parallelism": f"rays sharded over {world} rank(s), RCCL gradient all-reduce" if world > 1 else "single GPU",
+                       "parallelism": (f"dp{world}: rays sharded over {world} ranks (one per GPU), RCCL all-reduce of plane / MLP gradients"
+                                       + ("" if backend == "nccl" else f" [DEBUG backend {backend}: ranks share GPUs, not a scaling number]"))
+                                      if world > 1 else "single GPU",
                        "samples_per_step_per_gpu": samples / args.steps / world, "rays_per_step_per_gpu": rays_n / args.steps / world},
             "loss": loss,
             "stages": stages,

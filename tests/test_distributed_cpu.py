@@ -24,6 +24,7 @@ def _make_model():
     torch.manual_seed(0)
     m = torch.nn.Module()
     m.plane = torch.nn.Parameter(torch.rand(1, 32, 128, 128).contiguous(memory_format=torch.channels_last))   # >= 2^18: own all-reduce
+    m.grid = torch.nn.Parameter(torch.rand(1, 8, 32, 32, 32).contiguous(memory_format=torch.channels_last_3d))  # Cobafa-style 5-D grid, 2^18
     m.lin = torch.nn.Linear(96, 64)                                                                           # small: bucketed
     m.head = torch.nn.Linear(64, 1)
     return m
@@ -40,12 +41,16 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     rendered_in = torch.rand(n, 96, generator=g)
     target = torch.rand(n, 3, generator=g)
-    rendered = m.head(torch.relu(m.lin(rendered_in))).expand(n, 3) * m.plane[0, :3, 0, 0]
+    rendered = m.head(torch.relu(m.lin(rendered_in))).expand(n, 3) * m.plane[0, :3, 0, 0] + m.grid[0, :3, 1, 2, 3] * rendered_in[:, :3]
     loss = Trainer.global_mse(stub, rendered, target)
     for p in m.parameters():
         p.grad = torch.zeros_like(p)
     loss.backward()
     assert m.plane.grad.is_contiguous(memory_format=torch.channels_last)
+    assert m.grid.grad.is_contiguous(memory_format=torch.channels_last_3d) and not m.grid.grad.is_contiguous()
+    for g in (m.plane.grad, m.grid.grad):                 # the exchange works on the parameter's own memory, no copies
+        v = Trainer._dense_view(g)
+        assert v is not None and v.is_contiguous() and v.data_ptr() == g.data_ptr() and v.numel() == g.numel()
     Trainer._planes_ready(stub, [m.plane.grad])          # the fused node starts the plane all-reduces mid-backward
     assert len(stub._early) == 1
     Trainer.all_reduce_grads(stub)                        # ... which are awaited here, everything else is reduced now
@@ -73,7 +78,7 @@ def test_two_rank_gradient_exchange_equals_single_process():
         g = torch.Generator().manual_seed(100 + rank)
         ins.append(torch.rand(n, 96, generator=g)); tgts.append(torch.rand(n, 3, generator=g))
     x, t = torch.cat(ins), torch.cat(tgts)
-    rendered = m.head(torch.relu(m.lin(x))).expand(x.size(0), 3) * m.plane[0, :3, 0, 0]
+    rendered = m.head(torch.relu(m.lin(x))).expand(x.size(0), 3) * m.plane[0, :3, 0, 0] + m.grid[0, :3, 1, 2, 3] * x[:, :3]
     loss = torch.nn.functional.mse_loss(rendered, t)
     loss.backward()
     assert abs(res[0][1] + res[1][1] - float(loss)) < 1e-6          # local losses sum to the global mean

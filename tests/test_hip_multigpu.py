@@ -1,0 +1,196 @@
+"""N > 1 on the GPU (the reference is single-device, run.py:98, so the oracle here is the 1-rank path):
+
+* the split backward the N > 1 step uses -- data gradients (TN_MLP_CHAIN_ONLY) -> plane scatter -> weight gradients
+  (TN_MLP_WGRAD_ONLY) -- against the one-shot tn_mlp_bwd_pair;
+* two ranks sharing one GPU (gloo rendezvous on 127.0.0.1, CUDA tensors) run the real ``Trainer.step()`` on disjoint
+  halves of a ray set; loss, every reduced ``param.grad`` before Adam and the occupancy grids equal one rank that
+  processes the union of the two ranks' batches.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_split_backward_equals_one_shot():
+    from tinynerf_amd import _lib as L
+    from tinynerf_amd import models as m
+    from tinynerf_amd.models import _hwc, _kplanes_desc, _mlp_desc
+    torch.manual_seed(33)
+    n, R, F = 6007, 83, 96
+    dev = torch.device(DEV)
+    sp = [p.detach().contiguous() for p in m.VanillaOpacityDecoder(F).to(dev).net.params()]
+    cd = m.VanillaColorDecoder(8, F, 64, 3).to(dev)
+    rp = [p.detach().contiguous() for p in cd.net.params()]
+    field = m.KPlanesFeatureField(32, (16, 32, 64)).to(dev)
+    planes = field.plane_tensors()
+    coords = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
+    kdesc, keep = _kplanes_desc(planes)
+    x = torch.empty(n, F, device=dev)
+    L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(coords), C.c_int64(3), C.c_int64(n), L.ptr(x))
+    ray_ids = torch.sort(torch.randint(0, R, (n,), device=dev, dtype=torch.int32)).values.contiguous()
+    dirs_ray = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+    table = torch.empty(R, 56, device=dev)
+    L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(cd.pe.freqs), C.c_int(8), L.ptr(table), C.c_int(56))
+    g_rgb, g_sig = torch.randn(n, 3, device=dev), torch.randn(n, 1, device=dev)
+    fn = L.lib().tn_mlp_bwd_workspace_bytes
+    fn.restype = C.c_int64
+    rd = _mlp_desc(rp, F, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, cd.pe.freqs, 0, ray_ids, 56)
+    sd = _mlp_desc(sp, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, 0, None, 0)
+    nbr, nbs = int(fn(C.byref(rd), C.c_int64(n))), int(fn(C.byref(sd), C.c_int64(n)))
+    wr0, ws0 = torch.empty(nbr // 4, device=dev), torch.empty(nbs // 4, device=dev)
+    rgb, sigma = torch.empty(n, 3, device=dev), torch.empty(n, 1, device=dev)
+    L.call("tn_mlp_fwd_stash_pair", dev, C.byref(rd), C.byref(sd), L.ptr(x), L.ptr(table), C.c_int64(n), L.ptr(rgb), L.ptr(sigma),
+           L.ptr(wr0), C.c_int64(nbr), L.ptr(ws0), C.c_int64(nbs))
+    sd.flags = L.MLP_STASHED
+
+    def run(split: bool):
+        wr, ws = wr0.clone(), ws0.clone()
+        grs, gss = [torch.zeros_like(p) for p in rp], [torch.zeros_like(p) for p in sp]
+        gpl = [torch.zeros_like(p) for p in planes]
+        arr = lambda gs, o: (C.c_void_p * (len(gs) // 2))(*[g.data_ptr() for g in gs[o::2]])
+        gp = ((C.c_void_p * 3) * L.TN_KPLANES_MAX_SCALES)()
+        for s in range(3):
+            for p in range(3):
+                gp[s][p] = _hwc(gpl[3 * s + p]).data_ptr()
+        gx = torch.full((n, F), float("nan"), device=dev)
+        args = (C.byref(sd), L.ptr(x), L.ptr(table), L.ptr(g_rgb), L.ptr(g_sig), C.c_int64(n), arr(grs, 0), arr(grs, 1), arr(gss, 0),
+                arr(gss, 1), L.ptr(gx), L.ptr(wr), C.c_int64(nbr), L.ptr(ws), C.c_int64(nbs))
+        if split:
+            rd.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
+            L.call("tn_mlp_bwd_pair", dev, C.byref(rd), *args)
+            assert all(float(g.abs().max()) == 0.0 for g in grs + gss)       # no weight gradient yet
+            L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(coords), C.c_int64(3), C.c_int64(n), L.ptr(gx), gp)
+            rd.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
+            L.call("tn_mlp_bwd_pair", dev, C.byref(rd), *args)
+        else:
+            rd.flags = L.MLP_STASHED
+            L.call("tn_mlp_bwd_pair", dev, C.byref(rd), *args)
+            L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(coords), C.c_int64(3), C.c_int64(n), L.ptr(gx), gp)
+        return gx, grs + gss, gpl
+
+    gx0, g0, p0 = run(False)
+    gx1, g1, p1 = run(True)
+    assert torch.equal(gx0, gx1)                                             # same kernel, same arithmetic: bit-equal
+    for a_, b_ in zip(g1, g0):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(b_.abs().max())))
+    for a_, b_ in zip(p1, p0):                                               # atomics: order differs, values agree
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(b_.abs().max())))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _scene():
+    from tinynerf_amd import rays
+    o, d, rgb, K, cams = rays.synthetic_scene(n_views=4, res=64, seed=7, device="cpu")
+    return o.contiguous(), d.contiguous(), rgb.contiguous()
+
+
+def _cfg(method):
+    from tinynerf_amd.run import TrainConfig
+    return TrainConfig(method=method, scene_type="aabb", batch_size=256, n_samples=48, seed=4, occupancy_res=32, deterministic=True,
+                       kplanes_resolutions=(32, 64, 128))        # 128^2 x 32 >= 2^18 elements: its own early all-reduce
+
+
+N_STEPS = 3
+
+
+def _no_dropout(tr):
+    """Cobafa's Dropout(0.01) (models.py:250) draws from the process RNG: switched off so that 2 ranks and 1 rank see the same function"""
+    drop = getattr(tr.renderer.feature_module, "dropout", None)
+    if drop is not None:
+        drop.p = 0.0
+
+
+def _grads(t):
+    """every reduced gradient on step 0; later steps skip the multi-million-element grids (queue traffic), keep all the rest"""
+    return {k: p.grad.detach().cpu().clone() for k, p in t.renderer.named_parameters() if t.train_step == 0 or p.numel() < (1 << 20)}
+
+
+def _rank_main(rank, world, port, method, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from tinynerf_amd.run import Trainer
+    dev = torch.device(DEV, 0)
+    torch.cuda.set_device(dev)
+    o, d, rgb = _scene()
+    half = slice(rank, None, world)                                 # disjoint halves of the ray set
+    tr = Trainer(_cfg(method), o[half].to(dev), d[half].to(dev), rgb[half].to(dev), torch.ones(3, device=dev), dev, rank=rank,
+                 world_size=world)
+    _no_dropout(tr)
+    cap = {}
+    tr.grad_hook = lambda t: cap.__setitem__("g", _grads(t))
+    early_calls = [0]
+    planes_ready = tr._planes_ready
+
+    def counted(grads):
+        early_calls[0] += 1
+        planes_ready(grads)
+    tr._planes_ready = counted
+    out = []
+    for _ in range(N_STEPS):
+        cursor = tr._cursor
+        st = tr.step()
+        out.append(dict(cursor=cursor, n_rays=int(st["n_rays"]), n_samples=int(st["n_samples"]), loss=tr.loss_value(), grads=cap["g"],
+                        grid=tr.occupancy_grid.grid.cpu().clone(), pending=len(tr._early), early_calls=early_calls[0]))
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("method", ["kplanes", "cobafa"])
+def test_two_ranks_equal_one_rank_on_the_union(method):
+    from tinynerf_amd.run import Trainer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, method, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+
+    dev = torch.device(DEV, 0)
+    o, d, rgb = _scene()
+    tr = Trainer(_cfg(method), o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev)
+    _no_dropout(tr)
+    cap = {}
+    tr.grad_hook = lambda t: cap.__setitem__("g", _grads(t))
+    for step in range(N_STEPS):
+        os_, ds_, ts_ = [], [], []
+        for rank in range(2):                                       # the rays each rank consumed in this step
+            r = res[rank][step]
+            oh, dh, th = o[rank::2], d[rank::2], rgb[rank::2]
+            idx = (r["cursor"] + torch.arange(r["n_rays"])) % oh.size(0)
+            os_.append(oh[idx]); ds_.append(dh[idx]); ts_.append(th[idx])
+        ou, du, tu = torch.cat(os_).to(dev), torch.cat(ds_).to(dev), torch.cat(ts_).to(dev)
+        packed, info = tr.ray_provider(ou, du, training=False)
+        assert packed.size(0) == res[0][step]["n_samples"] + res[1][step]["n_samples"]
+        tr.step_on_batch(packed, info, tu, prefetch=False)
+        loss = tr.loss_value()
+        tol = 2e-5 if step == 0 else 2e-3                          # later steps: Adam (eps 1e-15) amplifies summation-order noise
+        for rank in range(2):
+            r = res[rank][step]
+            assert abs(r["loss"] - loss) <= tol * abs(loss), (step, rank, r["loss"], loss)
+            for k, g in cap["g"].items():
+                ref = g.numpy()
+                np.testing.assert_allclose(r["grads"][k].numpy(), ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
+            if step == 0:
+                assert torch.equal(r["grid"], tr.occupancy_grid.grid.cpu())        # identical grids without communication
+        assert torch.equal(res[0][step]["grid"], res[1][step]["grid"])
+    assert not any(r["pending"] for rank in range(2) for r in res[rank])           # every early all-reduce was awaited
+    if method == "kplanes":      # the fused node handed its plane gradients over mid-backward (CHAIN_ONLY -> scatter -> WGRAD_ONLY) every step
+        assert all(res[rank][-1]["early_calls"] == N_STEPS for rank in range(2))

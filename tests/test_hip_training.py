@@ -122,6 +122,9 @@ def test_train_entry_point_on_a_scene_on_disk(tmp_path):
     tr, tm, em, testm = train(cfg, train_rays, None, test_set, out, max_steps=150, log_every=50)
     assert (out / "model.pt").exists() and (out / "metrics_train.json").exists() and (out / "metrics_test.json").exists()
     assert (out / "test_full_0000.png").exists()
+    logged = json.load(open(out / "metrics_train.json"))
+    assert len(logged) == 151 and set(logged[0]) == {"loss", "occupancy"}          # one {loss, occupancy} per step (run.py:262-266)
+    assert logged[-1]["loss"] < logged[0]["loss"] and 0.0 < logged[-1]["occupancy"] <= 1.0
     assert testm[0]["psnr"] > 18.0, testm                      # the synthetic ball is learnt in 150 steps
     sd = torch.load(out / "model.pt")
     assert "feature_module.planes.0.0.plane" in sd and "rgb_decoder.net.net.5.weight" in sd

@@ -34,7 +34,6 @@ SOURCES = {
     "kplanes.hip": FAST + ["-munsafe-fp-atomics"],
     "cobafa.hip": STRICT + ["-munsafe-fp-atomics"],   # sawtooth warp x (res-1): an fma in f*x - floor moves taps
     "mlp.hip": FAST,
-    "mlp_bwd.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
 }

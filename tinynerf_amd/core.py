@@ -223,12 +223,16 @@ class OccupancyGrid(torch.nn.Module):
             self._coarse_key = key
         return self._coarse
 
-    def _stats(self) -> Tuple[float, float]:
+    def _stats_device(self) -> torch.Tensor:
+        """[sum of cells, cells above the threshold] as a device tensor (no host sync)"""
         dev = L.require_cuda(self.grid)
         stats = torch.empty(2, dtype=torch.float64, device=dev)
         L.call("tn_occupancy_stats", dev, L.ptr(self.grid), C.c_int64(self.grid.numel()),
                C.c_float(self.threshold), L.ptr(stats))
-        s, c = stats.tolist()
+        return stats
+
+    def _stats(self) -> Tuple[float, float]:
+        s, c = self._stats_device().tolist()
         return s, c
 
     @torch.no_grad()
@@ -238,11 +242,11 @@ class OccupancyGrid(torch.nn.Module):
 
     @torch.no_grad()
     def update(self, sigma_fn: Callable[[torch.Tensor], torch.Tensor], jitters: Optional[torch.Tensor] = None,
-               slices_per_call: Optional[int] = None):
+               slices_per_call: Optional[int] = None, seed: Optional[int] = None):
         """Decay/refresh sweep of core.py:133-145.
 
         Voxel centres are jittered on the device by a counter-based RNG seeded from torch's
-        generator (``jitters`` [D,H,W,3] overrides it for parity runs).  The threshold is constant
+        generator, or from ``seed`` when given (``jitters`` [D,H,W,3] overrides it for parity runs).  The threshold is constant
         during a sweep, so slices are independent: ``slices_per_call`` of them are evaluated by one
         ``sigma_fn`` call (default: as many as give <= 2^21 points) instead of one call per slice.
         """
@@ -250,7 +254,7 @@ class OccupancyGrid(torch.nn.Module):
         dev = L.require_cuda(self.grid)
         thr = float(self.threshold)
         step = float(self.step_size)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         per = slices_per_call or max(1, min(D, (1 << 21) // (H * W)))
         coords = torch.empty((per * H * W, 3), device=dev)
         for i0 in range(0, D, per):
@@ -355,10 +359,7 @@ class NerfWeights(torch.autograd.Function):
             raise RuntimeError("sigmas and steps must be 1-D")
         _check_info(info)
         dev = L.require_cuda(sigmas, steps, info)
-        weights = torch.empty_like(sigmas)
-        covered = int(info.size(0)) > 0
-        if not covered:
-            weights.zero_()
+        weights = torch.zeros_like(sigmas)       # cuda.cu:84: samples no (start, count) covers keep weight 0
         L.call("tn_weights_fwd", dev, L.ptr(sigmas), L.ptr(steps), L.ptr(info), C.c_float(threshold), L.ptr(weights),
                C.c_int64(sigmas.numel()), C.c_int64(info.size(0)))
         ctx.save_for_backward(sigmas, steps, info, weights)

@@ -289,7 +289,7 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
     const bool fast = wlds && plain_cols(a) && (!pair || plain_cols(pr.b));
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
     if (wlds && stash) {
-        if constexpr (H <= 64) {
+        if constexpr (H == 64) {
             // stash variants: 12 waves (170-VGPR budget) for the generic first layer, 16 for the plain-column one (119 VGPRs)
             auto launch = [&](auto kern, int wps) -> int {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -303,7 +303,7 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
             if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
             else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
             if (rc) return rc;
-        } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: hidden width must be 32 or 64");
+        } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: the register-resident training forward is built for width 64");
     } else if (wlds) {
         auto kern = fast ? mlp_fwd_kernel<H, true, WPB, false, false, true> : mlp_fwd_kernel<H, true, WPB, false, false, false>;
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -374,8 +374,7 @@ extern "C" int tn_mlp_fwd_stash(const tn_mlp_desc *desc, const float *x, const f
     TN_REQUIRE(desc, TN_E_NULL, "tn_mlp_fwd_stash: null descriptor");
     const int H = desc->dims[1];
     if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_mlp_fwd_stash: negative n");
-    const bool two_pass = (H == 32 || H == 64) && desc->n_layers >= 2 && desc->n_layers <= 5 && desc->dims[desc->n_layers] <= 4;
-    if (!two_pass) {       // wide / deep stacks: the layer-by-layer backward's workspace
+    if (!two_pass_supported(desc)) {       // wide / deep stacks: the layer-by-layer backward's workspace
         const int64_t need_l = tn_mlp_bwd_workspace_bytes(desc, n);
         TN_REQUIRE(need_l > 0, TN_E_CONFIG, "tn_mlp_fwd_stash: this configuration's backward does not use a workspace");
         TN_REQUIRE(workspace && workspace_bytes >= need_l, TN_E_NULL, "tn_mlp_fwd_stash: workspace missing or too small");

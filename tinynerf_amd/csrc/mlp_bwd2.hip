@@ -1,7 +1,7 @@
-// Backward of the fused MLP heads, two-pass form (the fast path of tn_mlp_bwd).
+// Backward of the fused MLP heads, two-pass form (the width-64 decoders; wide / deep stacks: mlp_bwd_layers.hip).
 //
-// The single-kernel backward (mlp_bwd.hip) keeps every hidden activation AND the gradient image on chip,
-// which leaves one wave per SIMD and weights in L2: ~8 % of the fp32 MFMA peak.  Splitting along the
+// A single kernel that keeps every hidden activation AND the gradient image on chip is left with one wave per
+// SIMD and weights in L2 (round 1 measured ~8 % of the fp32 MFMA peak; that form is gone).  Splitting along the
 // one place where the data layout has to change anyway -- the weight gradient reduces over SAMPLES,
 // everything else over FEATURES -- gives two clean kernels:
 //
@@ -21,8 +21,6 @@
 #include <algorithm>
 #include <type_traits>
 
-extern "C" int tn_mlp_bwd_fused1(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
-                                 float *const *grad_weights, float *const *grad_biases, float *grad_x, void *stream);
 extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
@@ -619,192 +617,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad kernel, double-buffered form (encodings without E rows: TN_ENC_NONE, TN_ENC_AUX_CAT)
+// wgrad kernel, paired form (hidden width 64 = two 32-row tiles per layer)
 //
 // The single-buffer kernel above spends every iteration as  commit | barrier | MFMA phase | barrier , with the next
 // tile's loads in flight during the MFMA phase only; the tile needs longer from HBM (~25 MB chip-wide per iteration)
-// than the MFMAs take, so the difference is exposed on every iteration.  Here only the rows every wave shares (G_l,
-// g_pre, x, aux: 56 KB) are staged, in TWO LDS buffers, and each wave reads the H_{l-1} rows of its own tiles straight
+// than the MFMAs take, so the difference is exposed on every iteration.  Here only the rows every wave shares (H_NH,
+// G_l, g_pre, x, aux) are staged, in TWO LDS buffers, and each wave reads the H_{l-1} rows of its own tiles straight
 // from the workspace in MFMA operand layout (64 contiguous bytes per lane).  Iteration t: write tile t+1 into the other
-// buffer, request tile t+2 (staging registers), multiply tile t (requesting each slot's H operands of tile t+1 right
-// after that slot's operands have been copied out), ONE barrier.  Every
-// load has a full iteration to arrive.  All loads are unconditional (clamped tile indices) so that the compiler keeps
-// exact vmcnt counts instead of draining the queue at control-flow joins.
-// ------------------------------------------------------------------------------------------------
-template <int H, int NH, int MAXS, int NW, int NCH, bool AUX>
-__global__ __launch_bounds__(NW * 64) void mlp_wgrad3_kernel(WgradArgs a, const float *__restrict__ x, const float *__restrict__ aux,
-                                                             int64_t n, const float *__restrict__ stash)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = tn::lane_id(), i_ = lane & 31, h_ = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t n_tiles = (n + 31) >> 5;
-    const int xs = a.in_dim;
-    constexpr int RG = NH * H + 4;                        // staged workspace rows: G_0 .. G_{NH-1}, g_pre
-    const int Rt = stash_rows(H, NH, 0);
-    constexpr int g_chunks = RG * 8;
-    const int x_chunks = (32 * a.in_dim) / 4;
-    const int aw = AUX ? a.K0_pad - a.in_dim : 0;
-    const int buf_floats = RG * RS + 32 * a.in_dim + 32 * aw;
-    f32x16 acc[MAXS];
-    float dbacc[MAXS];
-    int tl[MAXS], ttn[MAXS], ttk[MAXS];
-#pragma unroll
-    for (int m = 0; m < MAXS; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-        dbacc[m] = 0.0f;
-        tl[m] = -1; ttn[m] = 0; ttk[m] = 0;
-        const int id = wave + NW * m;
-        if (id < a.total_tiles) decode_tile<H, NH>(a, id, tl[m], ttn[m], ttk[m]);
-    }
-    f32x4 pre[NCH];
-    f32x4 preA = {0.f, 0.f, 0.f, 0.f};
-    f32x4 hn[MAXS][4];
-    int aidx = 0;                                          // aux-table row of sample (threadIdx.x >> 4) & 31 of the tile fetched next
-    auto prefetch = [&](int64_t tile, int64_t tile_after) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + NH * H * 32);
-        const int64_t x0 = tile * 32 * (int64_t)a.in_dim;
-        const int64_t xlast = n * (int64_t)a.in_dim - 4;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int c = threadIdx.x + k * NW * 64;
-            int64_t e = x0 + 4 * (int64_t)(c - g_chunks);
-            e = e < 0 ? 0 : (e > xlast ? xlast : e);
-            const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
-            const f32x4 *pr = src + (c < g_chunks ? c : 0);
-            pre[k] = *(c < g_chunks ? pr : px);
-        }
-        if constexpr (AUX) {
-            // the table row of this thread's sample was looked up one call earlier (aidx): a dependent index load here
-            // would have to drain every load issued above before the row address is known
-            const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;
-            preA = *reinterpret_cast<const f32x4 *>(aux + (int64_t)aidx * a.aux_stride + (4 * part < aw ? 4 * part : 0));
-            int64_t r_ = tile_after * 32 + s_;
-            r_ = r_ < n ? r_ : n - 1;
-            aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
-        }
-    };
-    // branch-free: idle slots write a scratch line behind the buffers (divergent branches around the ds_writes make the
-    // compiler's vmcnt bookkeeping conservative: it then waits for loads issued AFTER the ones being committed)
-    float *dummy = lds + 2 * buf_floats;       // one shared slot (wave-uniform address: no per-lane register)
-    auto commit = [&](float *buf) {
-        float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int c = threadIdx.x + k * NW * 64;
-            float *dst = c < g_chunks ? buf + (c >> 3) * RS + (c & 7) * 4 : (c < g_chunks + x_chunks ? ldsX + 4 * (c - g_chunks) : dummy);
-            *reinterpret_cast<f32x4 *>(dst) = pre[k];
-        }
-        if constexpr (AUX) {
-            const int s_ = threadIdx.x >> 4, part = threadIdx.x & 15;
-            float *dst = (threadIdx.x < 512 && 4 * part < aw) ? ldsA + s_ * aw + 4 * part : dummy;
-            *reinterpret_cast<f32x4 *>(dst) = preA;
-        }
-    };
-    auto fetch_h1 = [&](int64_t tile, int m) {             // H_{l-1} rows of tile slot m, operand layout, sample tile `tile`
-        const int l = tl[m];
-        const int hrow = (l >= 1 ? (l - 1) * H + 32 * ttk[m] : 0) + i_;
-        const f32x4 *p = reinterpret_cast<const f32x4 *>(stash + tile * (int64_t)Rt * 32 + hrow * 32 + 16 * h_);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hn[m][e] = p[e];
-    };
-    const int64_t last = n_tiles - 1;
-    int64_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;                           // (grid <= n_tiles: never taken; keeps the clamps below valid)
-    if constexpr (AUX) {
-        int64_t r_ = tile * 32 + ((threadIdx.x >> 4) & 31);
-        r_ = r_ < n ? r_ : n - 1;
-        aidx = a.aux_index ? a.aux_index[r_] : (int)r_;
-    }
-    {
-        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
-        prefetch(tile, t1 < last ? t1 : last);
-#pragma unroll
-        for (int m = 0; m < MAXS; ++m) fetch_h1(tile, m);
-        commit(lds);
-        __syncthreads();
-        prefetch(t1 < last ? t1 : last, t2 < last ? t2 : last);
-    }
-    int cur = 0;
-    for (; tile < n_tiles; tile += gridDim.x) {
-        int i = i_, h = h_;
-        asm volatile("" : "+v"(i), "+v"(h));
-        float *buf = lds + cur * buf_floats;
-        float *nbuf = lds + (cur ^ 1) * buf_floats;
-        const int64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x, t3 = t2 + gridDim.x;
-        commit(nbuf);                                      // tile t+1 (a duplicate of the last tile past the end: never read)
-        prefetch(t2 < last ? t2 : last, t3 < last ? t3 : last);
-        const int64_t t1c = t1 < last ? t1 : last;
-        const float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
-#pragma unroll
-        for (int m = 0; m < MAXS; ++m) {
-            const int l = tl[m];
-            if (l < 0) continue;
-            const int grow = l < NH ? l * H + 32 * ttn[m] + i : NH * H + (i < 4 ? i : 0);
-            const f32x4 *gp = reinterpret_cast<const f32x4 *>(buf + grow * RS + 16 * h);
-            f32x4 hc[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hc[e] = hn[m][e];
-            fetch_h1(t1c, m);                              // this slot's operands of the next sample tile: a full iteration to arrive
-            const bool gok = l < NH || i < 4;
-            const float *cp = nullptr;
-            int cstride = 0;
-            if (l == 0) {
-                const int q = 32 * ttk[m] + i;
-                if (q < xs) { cp = ldsX + 16 * h * a.in_dim + q; cstride = a.in_dim; }
-                else if (AUX && q < a.K0_pad) { cp = ldsA + 16 * h * aw + (q - xs); cstride = aw; }
-            }
-            float gsum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f32x4 gv = gp[e];
-                if (!gok) gv = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 av = {0.f, 0.f, 0.f, 0.f};
-                if (l == 0) {
-                    if (cp != nullptr) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) av[u] = cp[(4 * e + u) * cstride];
-                    }
-                } else av = hc[e];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[m] = tn::mfma32(gv[u], av[u], acc[m]);
-                gsum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
-            }
-            if (ttk[m] == 0) dbacc[m] += gsum;
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
-    const int i = i_, h = h_;
-#pragma unroll
-    for (int m = 0; m < MAXS; ++m) {
-        const int l = tl[m];
-        if (l < 0) continue;
-        tn::pin16(acc[m]);
-        const int Nl = a.N[l], Kl = a.K[l];
-        const int k = 32 * ttk[m] + i;
-        const bool kok = k < Kl;
-        const int kc = kok ? (l == 0 ? wg_col0(a, k) : k) : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nn = 32 * ttn[m] + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (kok && nn < Nl) atomicAdd(&a.gW[l][(int64_t)nn * Kl + kc], acc[m][r]);
-        }
-        if (ttk[m] == 0) {
-            float sum = dbacc[m];
-            sum += __shfl_xor(sum, 32, 64);
-            const int nn = 32 * ttn[m] + i;
-            if (h == 0 && nn < Nl) atomicAdd(&a.gB[l][nn], sum);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// wgrad kernel, paired form (hidden width 64 = two 32-row tiles per layer)
-//
-// Same pipeline as mlp_wgrad3_kernel, different ownership: a wave owns the TWO tiles that share one A-side operand --
+// buffer, request tile t+2 (staging registers), multiply tile t, ONE barrier: every load has a full iteration to arrive.
+// All loads are unconditional (clamped tile indices) so that the compiler keeps exact vmcnt counts instead of draining
+// the queue at control-flow joins.  Ownership: a wave owns the TWO tiles that share one A-side operand --
 // (layer l, tn = 0 and 1, one tk) -- so every H_{l-1} operand is read from the workspace by exactly one wave (the
 // 16-byte-per-lane operand loads are what the texture-address unit handles worst: 64 requests per instruction), and
 // every LDS operand column is read once for both tiles.  The last layer's two tiles (one G = g_pre, two H blocks) go to
@@ -1004,37 +826,7 @@ WgradPlan wgrad_plan(int enc, int in_dim, int K0_pad, int H, int NH) {
     return p;
 }
 
-bool v2_supported(const tn_mlp_desc *d) {
-    if (!d) return false;
-    const int L = d->n_layers, H = d->dims[1];
-    if (L < 2 || L > 5) return false;
-    if (H != 32 && H != 64) return false;
-    for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
-    if (d->dims[L] > 4) return false;
-    const int K0_pad = (d->dims[0] + 7) & ~7;
-    const int T = H / 32, Tk0 = (K0_pad + 31) / 32;
-    const int tiles = T * Tk0 + (L - 2) * T * T + T;
-    if (tiles > 48) return false;                                 // 16 waves x 3 accumulator tiles
-    const WgradPlan p = wgrad_plan(d->encoding, d->in_dim, K0_pad, H, L - 1);
-    if (p.xs > 0 && (d->in_dim & 3)) return false;
-    if (p.chunks > 10 * 1024) return false;                       // prefetch registers of the wgrad kernel
-    if (p.lds > 160 * 1024 || p.aw > 64) return false;
-    return true;
-}
-
-// the single-kernel form (mlp_bwd.hip) covers narrow, shallow heads only
-bool v1_supported(const tn_mlp_desc *d) {
-    if (!d) return false;
-    const int L = d->n_layers, H = d->dims[1];
-    if (L < 2 || L > 5) return false;
-    if (H != 32 && H != 64 && H != 128) return false;
-    if ((L - 1) * H > 256) return false;
-    for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
-    if (d->dims[L] < 1 || d->dims[L] > H) return false;
-    int acc = 0;                                       // its LDS gradient image + 8 wave scratches must fit 160 KiB
-    for (int l = 0; l < L; ++l) acc += ((d->dims[l + 1] * d->dims[l] + 3) & ~3) + ((d->dims[l + 1] + 3) & ~3);
-    return acc + 8 * 2 * 32 * 34 <= 160 * 1024 / 4;
-}
+bool v2_supported(const tn_mlp_desc *d) { return two_pass_supported(d); }
 
 // phase bit 0: data-gradient chain, bit 1: weight gradient.  pair != nullptr: the chain also runs head `pair->b`.
 template <int H, int NH>
@@ -1056,7 +848,8 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     pr.gy = nullptr; pr.stash = nullptr;
     if (pair) {
         pr = *pair;
-        kern = mlp_chain_kernel<H, NH, WPP, true, false, true>;
+        if constexpr (NH == 4) kern = mlp_chain_kernel<H, NH, WPP, true, false, true>;
+        else return tn::fail(TN_E_CONFIG, "mlp_bwd: the paired chain is built for the 5-layer colour head");
         wpb = WPP;
         lds_bytes += (size_t)pr.b.lds_floats * 4;
     } else pr.b = a;
@@ -1085,19 +878,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     const int chunks = wp.chunks;
     const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * (wlds * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
     const int extra_rows_ = extra_rows(a.enc, a.in_dim, a.K0_pad);
-    if (extra_rows_ == 0 && wp.xs > 0 && NH >= 2) {        // double-buffered form (measured slower for the 2-layer sigma head)
-        constexpr int RG = NH * H + 4;
-        const size_t lds3 = 2 * ((size_t)RG * RS + 32 * (size_t)a.in_dim + 32 * (size_t)wp.aw) * 4 + 32 * 16;
-        const int chunks3 = RG * 8 + 8 * a.in_dim;
-        const int64_t blocks3 = std::min<int64_t>(n_tiles, 256 * (lds3 * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
-#define TN_WGRAD3(MAXS_, NW_, NCH_)                                                                                        \
-    do {                                                                                                                    \
-        auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad3_kernel<H, NH, MAXS_, NW_, NCH_, true> : mlp_wgrad3_kernel<H, NH, MAXS_, NW_, NCH_, false>; \
-        hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);      \
-        if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds3, hipGetErrorString(we)); return (int)we; } \
-        wk<<<dim3((unsigned)blocks3), dim3(NW_ * 64), lds3, s>>>(w, x, aux, n, stash);                                      \
-        return tn::check_launch("mlp_wgrad3_kernel");                                                                       \
-    } while (0)
+    if (extra_rows_ == 0 && wp.xs > 0 && NH >= 2) {        // double-buffered, paired form (measured slower for the 2-layer sigma head)
         if constexpr (H == 64 && NH >= 2) {                // paired ownership: one wave per shared operand
             constexpr int RG4 = H + NH * H + 4;
             const size_t lds4 = 2 * ((size_t)RG4 * RS + 32 * (size_t)a.in_dim + 32 * (size_t)wp.aw) * 4 + 32 * 16;
@@ -1110,24 +891,18 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
                 return tn::check_launch("mlp_wgrad4_kernel");
             }
         }
-        if (lds3 <= (size_t)LDS_LIMIT_BYTES) {
-            if (w.total_tiles <= 8 && chunks3 <= 3 * 512) TN_WGRAD3(1, 8, 3);
-            else if (w.total_tiles <= 8 && chunks3 <= 4 * 512) TN_WGRAD3(1, 8, 4);
-            else if (w.total_tiles <= 24 && chunks3 <= 4 * 768) TN_WGRAD3(2, 12, 4);
-        }
-#undef TN_WGRAD3
     }
 #define TN_WGRAD(MAXS_, NW_, NCH_)                                                                                         \
     do {                                                                                                                    \
-        auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, true> : mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, false>; \
+        auto wk = mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, false>;                                                        \
         hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);      \
         if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", wlds, hipGetErrorString(we)); return (int)we; } \
         wk<<<dim3((unsigned)wblocks), dim3(NW_ * 64), wlds, s>>>(w, x, aux, n, stash);                                      \
     } while (0)
+    if (a.enc == TN_ENC_AUX_CAT) return tn::fail(TN_E_CONFIG, "mlp_bwd: TN_ENC_AUX_CAT outside the paired weight-gradient tiling");
     if (w.total_tiles <= 8 && chunks <= 4 * 512) TN_WGRAD(1, 8, 4);
     else if (w.total_tiles <= 16 && chunks <= 4 * 1024) TN_WGRAD(1, 16, 4);
     else if (w.total_tiles <= 24 && chunks <= 7 * 768) TN_WGRAD(2, 12, 7);     // 12 waves x 2 tiles: 170-VGPR budget, no spills
-    else if (w.total_tiles <= 32 && chunks <= 5 * 1024) TN_WGRAD(2, 16, 5);
     else if (w.total_tiles <= 32 && chunks <= 6 * 1024) TN_WGRAD(2, 16, 6);
     else if (w.total_tiles <= 48 && chunks <= 10 * 1024) TN_WGRAD(3, 16, 10);
     else return tn::fail(TN_E_CONFIG, "mlp_bwd: configuration outside the wgrad tiling");
@@ -1140,12 +915,9 @@ int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const fl
                 float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s,
                 const PairArgs *pair = nullptr, int phase = 3)
 {
-    switch (a.n_layers - 1) {
-    case 1: return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
-    case 2: return launch_v2<H, 2>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
-    case 3: return launch_v2<H, 3>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
-    default: return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
-    }
+    // the reference's two decoder shapes (two_pass_supported): one hidden layer (sigma) or four (colour)
+    if (a.n_layers == 2) return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
+    return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
 }
 
 }  // namespace
@@ -1155,7 +927,7 @@ extern "C" int64_t tn_mlp_bwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n
     if (n <= 0 || !desc) return 0;
     if (!v2_supported(desc)) {
         if (desc->encoding == TN_ENC_AUX_CAT) return 0;
-        return v1_supported(desc) ? 0 : tn_mlp_bwd_layers_workspace_bytes(desc, n);
+        return tn_mlp_bwd_layers_workspace_bytes(desc, n);
     }
     const int H = desc->dims[1], NH = desc->n_layers - 1;
     const int extra = extra_rows(desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7);
@@ -1176,15 +948,15 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
         if (n == 0) return TN_OK;
         TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: TN_MLP_STASHED / TN_ENC_AUX_CAT need the workspace");
     }
-    if (!v2 && (!v1_supported(desc) || stashed)) {             // wide / deep stack (or its stash): layer-by-layer form
+    if (!v2) {                                                 // wide / deep / odd-shaped stack (or its stash): layer-by-layer form
         if (n == 0) return TN_OK;
         TN_REQUIRE(need > 0, TN_E_CONFIG, "tn_mlp_bwd: unsupported layer configuration");
         TN_REQUIRE(workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: this configuration needs the workspace");
         TN_REQUIRE(((uintptr_t)workspace & 15) == 0, TN_E_ALIGN, "tn_mlp_bwd: workspace must be 16-byte aligned");
         return tn_mlp_bwd_layers(desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stream);
     }
-    if (need == 0 || workspace == nullptr || workspace_bytes < need)
-        return tn_mlp_bwd_fused1(desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, stream);
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(workspace != nullptr && workspace_bytes >= need, TN_E_NULL, "tn_mlp_bwd: workspace missing or too small (tn_mlp_bwd_workspace_bytes)");
     MlpArgs a;
     int H = 0;
     if (int rc = plan(desc, a, H)) return rc;
@@ -1195,7 +967,6 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
     for (int l = 0; l < a.n_layers; ++l)
         TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd: null gradient pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (H == 32) return launch_v2_h<32>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
     return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
 }
 
@@ -1209,9 +980,9 @@ extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partn
     TN_REQUIRE((desc->flags & TN_MLP_STASHED) && (partner->flags & TN_MLP_STASHED), TN_E_CONFIG,
                "tn_mlp_bwd_pair: both heads need TN_MLP_STASHED workspaces (tn_mlp_fwd_stash)");
     TN_REQUIRE(v2_supported(desc) && v2_supported(partner), TN_E_CONFIG, "tn_mlp_bwd_pair: outside the two-pass form's configurations");
-    TN_REQUIRE(partner->n_layers == 2 && partner->encoding == TN_ENC_NONE && partner->in_dim == desc->in_dim &&
+    TN_REQUIRE(desc->n_layers == 5 && partner->n_layers == 2 && partner->encoding == TN_ENC_NONE && partner->in_dim == desc->in_dim &&
                    partner->dims[1] == desc->dims[1] && desc->dims[1] == 64 && (desc->in_dim & 31) == 0 && desc->encoding != TN_ENC_POSENC,
-               TN_E_CONFIG, "tn_mlp_bwd_pair: partner must be a 2-layer head on the same x (width 64, in_dim % 32 == 0)");
+               TN_E_CONFIG, "tn_mlp_bwd_pair: a 5-layer head and a 2-layer partner on the same x (width 64, in_dim % 32 == 0)");
     if (n == 0) return TN_OK;
     const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
     TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b, TN_E_NULL,

@@ -1,5 +1,5 @@
 // Backward of WIDE / DEEP fused MLPs (Vanilla feature stack 60->256x9->256, Cobafa 36->128x6), layer by
-// layer.  The register-resident forms (mlp_bwd.hip, mlp_bwd2.hip) need every hidden activation of a tile on
+// layer.  The register-resident form (mlp_bwd2.hip) needs every hidden activation of a tile on
 // chip; a 9 x 256 stack does not fit.  This path keeps the same transposed MFMA building blocks but runs
 //
 //   1 launch   forward that streams every hidden activation H_l to the workspace ([feature][32 samples]

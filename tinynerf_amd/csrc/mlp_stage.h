@@ -1,5 +1,5 @@
 // Kernel arguments, LDS weight staging and first-layer input fetch shared by the fused MLP forward
-// (mlp.hip) and backward (mlp_bwd.hip) kernels.
+// (mlp.hip) and backward (mlp_bwd2.hip, mlp_bwd_layers.hip) kernels.
 #pragma once
 #include "mlp_device.h"
 
@@ -135,6 +135,29 @@ __device__ __forceinline__ unsigned relu_bits(const f32x16 &t) {
 __device__ __forceinline__ float mask_keep(float x, unsigned mask, int r) {
     const int keep = __builtin_amdgcn_sbfe((int)mask, r, 1);
     return __uint_as_float(__float_as_uint(x) & (unsigned)keep);
+}
+
+// Configurations of the two-pass backward (chain + weight-gradient kernels, mlp_bwd2.hip) and of the register-resident
+// training forward that writes its workspace (mlp.hip): width-64 heads with one or four hidden layers and <= 4 outputs -- the
+// reference's sigma / colour decoders.  Everything else (Vanilla 256 x 9, Cobafa 128 x 6, odd shapes) takes the
+// layer-by-layer form (mlp_bwd_layers.hip).
+inline bool two_pass_supported(const tn_mlp_desc *d) {
+    if (!d) return false;
+    const int L = d->n_layers, H = d->dims[1];
+    if ((L != 2 && L != 5) || H != 64) return false;
+    for (int l = 1; l < L; ++l) if (d->dims[l] != H) return false;
+    if (d->dims[L] < 1 || d->dims[L] > 4) return false;
+    const int K0_pad = (d->dims[0] + 7) & ~7;
+    const int T = H / 32, Tk0 = (K0_pad + 31) / 32;
+    if (T * Tk0 + (L - 2) * T * T + T > 48) return false;       // 16 waves x 3 accumulator tiles
+    const int extra = extra_rows(d->encoding, d->in_dim, K0_pad);
+    const int xs = x_slots(d->encoding, d->in_dim);
+    if (xs > 0 && (d->in_dim & 3)) return false;
+    const int R = stash_rows_w(H, L - 1, extra);
+    const int aw = d->encoding == TN_ENC_AUX_CAT ? K0_pad - d->in_dim : 0;
+    if (R * 8 + (xs > 0 ? 8 * d->in_dim : 0) > 10 * 1024) return false;      // prefetch registers of the wgrad kernel
+    if (((size_t)R * 36 + (xs > 0 ? 32 * (size_t)d->in_dim : 0) + 32 * (size_t)aw) * 4 > 160 * 1024 || aw > 64) return false;
+    return true;
 }
 
 inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)

@@ -113,6 +113,9 @@ class _RenderKPlanes(Function):
         else:
             L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
         weights = _alloc(arena, "weights", (n,), dev)
+        covered = hint is not None and hint.get("key") == (packed.data_ptr(), n, R)     # the trainer's sampler covers every sample
+        if not covered:
+            weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
         L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                C.c_int64(n), C.c_int64(R))
         if pair:
@@ -127,7 +130,7 @@ class _RenderKPlanes(Function):
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
-        ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb)
+        ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
         ctx.param_refs = params if accumulate else None
         ctx.planes_ready = hint.get("planes_ready") if (hint is not None and accumulate) else None
@@ -136,7 +139,7 @@ class _RenderKPlanes(Function):
     @staticmethod
     def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
         packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params = ctx.saved_tensors
-        n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb = ctx.cfg
+        n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered = ctx.cfg
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
@@ -159,6 +162,8 @@ class _RenderKPlanes(Function):
         arena = ctx.arena
         g_rgbs = _alloc(arena, "g_rgbs", (n, 3), dev)
         g_w = _alloc(arena, "g_w", (n,), dev)
+        if not covered:              # samples no ray owns: zero gradient, not whatever the arena held
+            g_rgbs.zero_(); g_w.zero_()
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
                L.ptr(g_w), C.c_int64(n), C.c_int64(R))
         # weights -> sigma (needs only the composite's gradient, not the colour head's)

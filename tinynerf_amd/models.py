@@ -51,7 +51,6 @@ class _FusedMLP(Function):
     """y = act(MLP(enc(x, aux))) in one launch; in training the forward also writes the activation workspace the backward
     consumes (tn_mlp_fwd_stash), otherwise the backward recomputes the hidden activations."""
 
-    two_pass = True     # give tn_mlp_bwd its workspace (two-pass form); False forces the single-kernel form
     stash_forward = True   # training forward writes the activation workspace (tn_mlp_fwd_stash); False: backward recomputes
 
     @staticmethod
@@ -67,7 +66,7 @@ class _FusedMLP(Function):
         y = torch.empty((n, ps[-1].numel()), device=dev)
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
-        if _FusedMLP.two_pass and _FusedMLP.stash_forward and any(ctx.needs_input_grad) and n > 0:
+        if _FusedMLP.stash_forward and any(ctx.needs_input_grad) and n > 0:
             wsfn = L.lib().tn_mlp_bwd_workspace_bytes
             wsfn.restype = C.c_int64
             ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
@@ -98,8 +97,6 @@ class _FusedMLP(Function):
         wsfn = L.lib().tn_mlp_bwd_workspace_bytes
         wsfn.restype = C.c_int64
         ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
-        if not _FusedMLP.two_pass and len(ps) // 2 <= 5 and ps[0].size(0) <= 128:
-            ws_bytes = 0                     # test hook: force the single-kernel form where it exists
         ws = ws_fwd if ws_fwd is not None else (torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None)
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))

@@ -87,8 +87,9 @@ class Trainer:
                  bg_color: Optional[torch.Tensor], device: torch.device, rank: int = 0, world_size: int = 1):
         self.cfg, self.device, self.rank, self.world = cfg, device, rank, world_size
         self.rays_o, self.rays_d, self.rgbs = rays_o, rays_d, rgbs
-        torch.manual_seed(cfg.seed)                    # identical parameters on every rank
-        self.renderer, self.occupancy_grid, self.ray_provider = build_renderer(cfg, bg_color, device)
+        with torch.random.fork_rng(devices=[]):         # identical parameters on every rank, the caller's RNG stream untouched
+            torch.manual_seed(cfg.seed)
+            self.renderer, self.occupancy_grid, self.ray_provider = build_renderer(cfg, bg_color, device)
         bs_ratio = 4096 / cfg.batch_size
         self.steps = int(2048 * bs_ratio)
         self.occupancy_grid_updates = int(16 * bs_ratio)
@@ -113,6 +114,7 @@ class Trainer:
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
         self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
         self.last: Dict[str, float] = {}
+        self.grad_hook: Optional[Callable[["Trainer"], None]] = None   # called with the final (reduced) gradients, before Adam
         self._early: Dict[int, object] = {}              # all-reduces started during the backward pass (N > 1)
         self._pending: Optional[dict] = None             # sampler pass of the next step, already in flight
         self._plan_host: Optional[torch.Tensor] = None
@@ -197,18 +199,23 @@ class Trainer:
         return self.renderer.sigma_decoder(self.renderer.feature_module(t))
 
     def step(self) -> Dict[str, float]:
-        cfg = self.cfg
         packed, info, target, k = self.build_batch()
+        return self.step_on_batch(packed, info, target, k)
+
+    def step_on_batch(self, packed: torch.Tensor, info: torch.Tensor, target: torch.Tensor, k: int = 0,
+                      prefetch: Optional[bool] = None) -> Dict[str, float]:
+        """Everything of one optimizer step behind the dynamic batch (run.py:246-261) on an explicit batch."""
+        cfg = self.cfg
         self.renderer.train()
         if self.train_step % self.occupancy_grid_updates == 0:                    # run.py:248-249
-            torch.manual_seed(cfg.seed + 7919 * (self.train_step + 1))            # same jitter on every rank
             jit = None
             if cfg.deterministic:
                 r = cfg.occupancy_res
                 jit = torch.full((r, r, r, 3), 0.5, device=self.device)
-            self.occupancy_grid.update(self.sigma_fn, jitters=jit)
+            # same jitter on every rank (identical grids without communication); a dedicated seed, not the global RNG
+            self.occupancy_grid.update(self.sigma_fn, jitters=jit, seed=(cfg.seed * 7919 + 104729 * (self.train_step + 1)) % (2 ** 62))
         rendered = self.renderer(packed, info)                                    # run.py:251
-        if self.prefetch:
+        if self.prefetch if prefetch is None else prefetch:
             self._launch_plan()            # next step's sampler pass runs between this forward and backward
         # loss * grad_scale, scaled and never unscaled (run.py:259-260 quirk).  The MSE and its gradient are written out
         # by hand (4 small kernels instead of ~12 through autograd); the regulariser's value and gradient are one launch.
@@ -232,6 +239,8 @@ class Trainer:
         self._loss_parts = (acc, inv, inv_dev, reg_coef)
         if self.world > 1:
             self.all_reduce_grads()
+        if self.grad_hook is not None:
+            self.grad_hook(self)
         self.optimizer.step(plane_reg=plane_reg)
         self.scheduler.step()
         self.train_step += 1
@@ -251,9 +260,9 @@ class Trainer:
     def global_mse(self, rendered: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return ((rendered - target) ** 2).sum() / (3.0 * Trainer.global_ray_count(self, rendered.size(0)))
 
-    def loss_value(self) -> float:
-        """Loss of the last step (MSE + weighted regulariser, run.py:252-256), assembled on demand from the device
-        accumulators the step left behind (valid until the next step)."""
+    def loss_device(self) -> torch.Tensor:
+        """Loss of the last step (MSE + weighted regulariser, run.py:252-256) as a 1-element device tensor, assembled
+        from the accumulators the step left behind (valid until the next step); no host sync."""
         acc, inv, inv_dev, reg_coef = self._loss_parts
         v = acc[0] * inv * (inv_dev[0].double() if inv_dev is not None else 1.0)
         if reg_coef is not None:
@@ -261,15 +270,29 @@ class Trainer:
         v = v.float().reshape(1).clone()
         if self.world > 1:
             torch.distributed.all_reduce(v)
-        return float(v.item())
+        return v
+
+    def loss_value(self) -> float:
+        return float(self.loss_device().item())
 
     # ------------------------------------------------------------------ e: gradient exchange
+    @staticmethod
+    def _dense_view(g: torch.Tensor) -> Optional[torch.Tensor]:
+        """`g`'s memory as a contiguous tensor WITHOUT a copy, for in-place collectives: K-Planes gradients are
+        channels_last [1,C,H,W], Cobafa grids channels_last_3d [1,C,D,H,W] (neither is `is_contiguous()`); None when the
+        tensor is not one dense block in some dimension order."""
+        if g.is_contiguous():
+            return g
+        order = sorted(range(g.dim()), key=lambda d: (-g.stride(d), -g.size(d)))
+        v = g.permute(order)
+        return v if v.is_contiguous() else None
+
     def _planes_ready(self, grads) -> None:
         """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are
         final: their all-reduces start here and travel while the heads' weight gradients are still being computed."""
         for g in grads:
-            if g.numel() >= (1 << 18):
-                flat = g.permute(0, 2, 3, 1) if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last) else g
+            flat = Trainer._dense_view(g) if g.numel() >= (1 << 18) else None
+            if flat is not None:
                 self._early[g.data_ptr()] = torch.distributed.all_reduce(flat, async_op=True)
 
     def all_reduce_grads(self) -> None:
@@ -283,10 +306,8 @@ class Trainer:
                 continue
             if p.grad.data_ptr() in early:
                 continue
-            if p.grad.numel() >= (1 << 18):
-                g = p.grad
-                flat = g.permute(0, 2, 3, 1) if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last) else g
-                assert flat.is_contiguous()
+            flat = Trainer._dense_view(p.grad) if p.grad.numel() >= (1 << 18) else None
+            if flat is not None:                 # large and dense in memory: its own in-place all-reduce
                 handles.append(torch.distributed.all_reduce(flat, async_op=True))
             else:
                 small.append(p.grad)
@@ -356,13 +377,16 @@ def train(cfg: TrainConfig, train_rays, eval_set=None, test_set=None, output=Non
     tr = Trainer(cfg, train_rays.rays_o, train_rays.rays_d, train_rays.rgbs,
                  None if train_rays.bg_color is None else train_rays.bg_color.to(device), device)
     n_steps = tr.steps if max_steps is None else min(tr.steps, max_steps)
-    train_metrics, eval_metrics, eval_step = [], [], 0
+    eval_metrics, eval_step = [], 0
+    # {loss, occupancy} of EVERY step like the reference (run.py:262-266), kept on the device and read back in one copy
+    log = torch.zeros((n_steps + 1, 2), dtype=torch.float64, device=device)
     for step in range(n_steps + 1):                       # the reference runs steps+1 iterations (run.py:290)
         tr.step()
+        log[step, 0] = tr.loss_device()[0]
+        log[step, 1] = tr.occupancy_grid._stats_device()[1] / tr.occupancy_grid.grid.numel()
         if step % log_every == 0 or step == n_steps:
-            train_metrics.append({"step": step, "loss": tr.loss_value(), "occupancy": tr.occupancy_grid.occupancy()})
-            print(f"step {step}/{n_steps} loss {train_metrics[-1]['loss']:.5f} occupancy {train_metrics[-1]['occupancy']:.3f} "
-                  f"samples {int(tr.last['n_samples'])}")
+            lv, ov = log[step].tolist()
+            print(f"step {step}/{n_steps} loss {lv:.5f} occupancy {ov:.3f} samples {int(tr.last['n_samples'])}")
         if eval_every and eval_set is not None and step % eval_every == 0 and step > 0:
             idx = list(range(eval_step, min(eval_step + eval_n, len(eval_set))))
             eval_metrics.extend(asdict(m) for m in evaluate(eval_set, infer(tr, eval_set, idx, output, f"test_{step}"), idx))
@@ -373,6 +397,7 @@ def train(cfg: TrainConfig, train_rays, eval_set=None, test_set=None, output=Non
         rendered = infer(tr, test_set, idx, output, "test_full")
         if test_set.rgbs:
             test_metrics = [asdict(m) for m in evaluate(test_set, rendered, idx)]
+    train_metrics = [{"loss": lv, "occupancy": ov} for lv, ov in log.tolist()]
     if output is not None:
         torch.save(tr.renderer.state_dict(), output / "model.pt")            # run.py:308
         json.dump(train_metrics, open(output / "metrics_train.json", "w"))

@@ -303,6 +303,17 @@ int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t n, float *
 int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
                   float *const *grad_basis, void *stream);
 
+/* Product stage of the explicit K-Planes decoders (models.py:183-205, exercised by the reference's tests/test_models.py:35-69;
+ * train() itself uses the Vanilla decoders, run.py:135-139):
+ *   out[n,k] = act(sum_c f[n,c] * basis[n,k,c]),   f [n,C], basis [n,K,C] row-major, 1 <= K <= 4.
+ * Opacity decoder: basis = Linear(f) (K = 1), act = TN_ACT_EXP_M1 (exp(v - 1) with the truncated exponential's backward clamp,
+ * models.py:42-55); colour decoder: basis = MLP([PE(d), d, f]).view(n, 3, C), act = TN_ACT_SIGMOID.
+ * Backward: grad_basis [n,K,C] (may be NULL) is written, grad_f [n,C] is written or (accumulate_f) added to. */
+int tn_basis_dot_fwd(const float *f, const float *basis, int64_t n, int32_t channels, int32_t n_out, int32_t activation,
+                     float *out, void *stream);
+int tn_basis_dot_bwd(const float *f, const float *basis, const float *grad_out, int64_t n, int32_t channels, int32_t n_out,
+                     int32_t activation, float *grad_f, float *grad_basis, int32_t accumulate_f, void *stream);
+
 /* From (packed [N,7], info [R,2]): ray_ids[i] = ray of sample i, steps[i] = packed[i,6] (contiguous, what tn_weights_*
  * take), dirs[r] = packed[start_r, 3:6] (the ray direction every sample of ray r carries, core.py:182-186; 0 for empty
  * rays).  One launch; feeds tn_dir_encode / TN_ENC_AUX_CAT when the sampler's own by-products are not at hand. */
@@ -329,6 +340,14 @@ typedef struct tn_adam_item {
 } tn_adam_item;
 int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, int32_t zero_grad, void *stream);
+
+/* tn_adam_multi for parameters that receive NO gradient in an "Empty iteration" (core.py:251-254: every sample masked ->
+ * rgbs / weights become fresh leaves, param.grad stays None and torch.optim.Adam skips the parameter, run.py:258-260,
+ * including its per-parameter step count).  `gate` is a device scalar (e.g. max_i w_i of the step): gate > 0 -> `step_dev[0]`
+ * (device int32 counter of the updates these tensors have received) is incremented and the update of tn_adam_multi runs with
+ * that count; gate <= 0 -> parameters, moments and counter are left untouched (gradients are still zeroed if asked). */
+int tn_adam_multi_gated(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int32_t *step_dev, const float *gate, int32_t zero_grad, void *stream);
 
 /* tn_adam_multi with the K-Planes regulariser folded in (run.py:254-260 in one pass): items with H > 0 are [H,W,C]
  * planes whose TV / L1 gradient (coefficients as in tn_plane_reg_multi, times `upstream`) is added to grad before the

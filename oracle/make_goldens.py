@@ -285,6 +285,74 @@ def main():
          rays_o_0=ro[0][::25, ::25], rays_d_0=rd[0][::25, ::25], rays_d_1=rd[1][::25, ::25], scene_scale=nd.scene_scale(),
          img0_sub=nd.imgs[0][::25, ::25], bg=nd.bg_color)
 
+
+    # ---- G13: explicit K-Planes decoders (models.py:183-205; exercised by tests/test_models.py:35-69) -------------
+    torch.manual_seed(13)
+    featin = torch.rand(200, 96, requires_grad=True)
+    eo = models.KPlanesExplicitOpacityDecoder(96); ec = models.KPlanesExplicitColorDecoder(96, 8, 128)
+    d3 = torch.nn.functional.normalize(torch.randn(200, 3), dim=-1)
+    with torch.no_grad():
+        eo.net.weight.mul_(0.1)                      # x = <f, W f + b> stays inside exp's comfortable range
+    s3 = eo(featin); c3 = ec(featin, d3)
+    gs3, gc3 = torch.randn_like(s3), torch.randn_like(c3)
+    ((s3 * gs3).sum() + (c3 * gc3).sum()).backward()
+    save("G13_explicit_decoders", feat=featin, dirs=d3, sigma=s3, rgb=c3, grad_sigma=gs3, grad_rgb=gc3, grad_feat=featin.grad,
+         **{"eo." + k: v for k, v in sd_np(eo).items()}, **{"ec." + k: v for k, v in sd_np(ec).items()},
+         **{"geo." + n: p.grad for n, p in eo.named_parameters()}, **{"gec." + n: p.grad for n, p in ec.named_parameters()})
+
+    # ---- G14: NerfRenderer over the Vanilla stack of run.py:131-134 (VanillaFeatureMLP(10, 256, 8)) -------------------
+    torch.manual_seed(14)
+    fm = models.VanillaFeatureMLP(10, 256, 8)
+    od = models.VanillaOpacityDecoder(256); cd = models.VanillaColorDecoder(8, 256, 64, 3)
+    with torch.no_grad():
+        od.net.net[2].bias.add_(4.5)      # dense enough that some rays terminate early (w == 0 tails -> the boolean gather)
+    rendv = core.NerfRenderer(fm, od, cd, bg)
+    R, S = 40, 48
+    o = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1) * 4.0311
+    d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(R, 3), dim=-1)
+    g = core.OccupancyGrid(32, 1 / 1024.)
+    g.grid[:, :, 22:] = 0.
+    g.mean = g.grid.mean().item()
+    rp = core.RayProvider(g, core.ContractionAABB(aabb), core.RayMarcherAABB(aabb, S, 0.1))
+    packed, info = rp(o, d, training=False)
+    sig = od(fm(packed[:, :3])).ravel()
+    w = core.NerfWeights.apply(sig, packed[:, 6], info, 1e-4)
+    out = rendv(packed, info)
+    target = torch.rand(R, 3)
+    loss = torch.nn.functional.mse_loss(out, target)
+    loss.backward()
+    save("G14_renderer_vanilla", packed=packed, info=info, bg=bg, weights=w, rendered=out, target=target, loss=loss,
+         n_masked=int((w == 0).sum()), **{"sd." + k: v for k, v in sd_np(rendv).items()},
+         **{"grad." + n: p.grad for n, p in rendv.named_parameters()})
+
+    # ---- G15: BASELINE config 5 composed: Cobafa field + RayMarcherUnbounded + ContractionMip360(inf) + renderer --------
+    # (run.py:141-147,154-156; small grids, eval-mode dropout so that the forward is a function)
+    torch.manual_seed(15)
+    freqs15 = [2.0, 3.5, 8.0]
+    cf = models.CobafaFeatureField(basis_res=[8, 10, 12], coef_res=8, freqs=freqs15, channels=[8, 8, 4], mlp_hidden_dim=128)
+    od = models.VanillaOpacityDecoder(128); cd = models.VanillaColorDecoder(8, 128, 64, 3)
+    with torch.no_grad():
+        od.net.net[2].bias.add_(3.0)
+    rendc = core.NerfRenderer(cf, od, cd, None)
+    rendc.eval()
+    R, S = 48, 40
+    o = torch.rand(R, 3) * 0.6 - 0.3                                   # cameras inside the scene (unbounded capture)
+    d = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+    g = core.OccupancyGrid(24, 1.3 / S)
+    kk = torch.randint(0, 30, (24, 24, 24))
+    g.grid.copy_(torch.tensor(decay) ** kk.float())
+    g.mean = g.grid.mean().item()
+    mu = core.RayMarcherUnbounded(S, 0.1, 1e5, 1.3)
+    rpu = core.RayProvider(g, core.ContractionMip360(float("inf")), mu)
+    packed, info = rpu(o, d, training=False)
+    out = rendc(packed, info)
+    target = torch.rand(R, 3)
+    loss = torch.nn.functional.mse_loss(out, target)
+    loss.backward()
+    save("G15_config5_cobafa_unbounded", rays_o=o, rays_d=d, n_samples=S, near=0.1, uniform_range=1.3, grid=g.grid, threshold=g.threshold,
+         packed=packed, info=info, rendered=out, target=target, loss=loss, freqs=freqs15,
+         **{"sd." + k: v for k, v in sd_np(rendc).items()}, **{"grad." + n: p.grad for n, p in rendc.named_parameters()})
+
     with open(os.path.join(out_dir, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by oracle/make_goldens.py from the reference imported at %s\n" % args.ref)
         f.write("torch %s, numpy %s, 1 CPU thread, _cuda replaced by oracle/weights_ref.c\n" % (torch.__version__, np.__version__))

@@ -42,6 +42,26 @@ def kplanes_features(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix: str =
     return torch.cat(feats, -1)
 
 
+def _grid_lookup(grid: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
+    """models.py:226-232 (CobafaGrid.forward): trilinear, zeros padding, align_corners=True -> [N,C]."""
+    out = torch.nn.functional.grid_sample(grid, pts.reshape(1, -1, 1, 1, 3), align_corners=True)
+    return out.view(grid.size(1), -1).t()
+
+
+def cobafa_features(sd: Dict[str, torch.Tensor], x: torch.Tensor, freqs, prefix: str = "feature_module.", dropout_p: float = 0.0) -> torch.Tensor:
+    """models.py:252-266: coefficient grid x sawtooth-warped basis grids -> concat -> (dropout) -> MLP.  ``freqs`` are the
+    SawtoothEncoding constants (plain Python attributes in the reference, not in the state_dict)."""
+    coefs = _grid_lookup(sd[prefix + "coef_grid.grid"], x)
+    feats = []
+    for i, f in enumerate(freqs):
+        warped = 2. * ((f * x) % 1.) - 1.                                      # models.py:213-215
+        feats.append(_grid_lookup(sd[prefix + f"basis_grids.{i}.grid"], warped) * coefs[:, [i]])
+    feat = torch.cat(feats, -1)
+    if dropout_p > 0:
+        feat = torch.nn.functional.dropout(feat, dropout_p, True)
+    return mlp(sd, prefix + "mlp.net.", feat)
+
+
 def _layers(sd: Dict[str, torch.Tensor], prefix: str):
     keys = sorted({k[len(prefix):].rsplit(".", 1)[0] for k in sd if k.startswith(prefix) and k.endswith(".weight")},
                   key=lambda s: int(s.split(".")[0]))
@@ -93,15 +113,22 @@ class _Weights(torch.autograd.Function):
         return torch.from_numpy(gs), None, None, None
 
 
+def features(sd: Dict[str, torch.Tensor], x: torch.Tensor, vanilla_freqs: int = 0, cobafa_freqs=None) -> torch.Tensor:
+    """the three feature modules of run.py:130-147 behind one call"""
+    if cobafa_freqs is not None:
+        return cobafa_features(sd, x, cobafa_freqs)
+    if vanilla_freqs:
+        return mlp(sd, "feature_module.net.net.", posenc(x, sd["feature_module.encoding.freqs"]))
+    return kplanes_features(sd, x)
+
+
 def render(sd: Dict[str, torch.Tensor], packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor],
-           thr: float = 1e-4, vanilla_freqs: int = 0) -> torch.Tensor:
-    """core.py:225-267 for a K-Planes (or Vanilla, vanilla_freqs > 0) field with the Vanilla decoders."""
+           thr: float = 1e-4, vanilla_freqs: int = 0, cobafa_freqs=None) -> torch.Tensor:
+    """core.py:225-267 for a K-Planes (or Vanilla: vanilla_freqs > 0, or Cobafa: cobafa_freqs) field with the Vanilla
+    decoders."""
     n, R = packed.size(0), info.size(0)
     x = packed[:, :3]
-    if vanilla_freqs:
-        feat = mlp(sd, "feature_module.net.net.", posenc(x, sd["feature_module.encoding.freqs"]))
-    else:
-        feat = kplanes_features(sd, x)
+    feat = features(sd, x, vanilla_freqs, cobafa_freqs)
     sig = _TruncExp.apply(mlp(sd, "sigma_decoder.net.net.", feat) - 1.).ravel()
     w = _Weights.apply(sig, packed[:, 6].contiguous(), info, thr)
     mask = w > 0
@@ -110,7 +137,10 @@ def render(sd: Dict[str, torch.Tensor], packed: torch.Tensor, info: torch.Tensor
         d = packed[:, 3:6][mask]
         inp = torch.cat([posenc(d, sd["rgb_decoder.pe.freqs"]), d, feat[mask]], -1)
         rgbs = rgbs.index_put((torch.nonzero(mask).squeeze(1),), torch.sigmoid(mlp(sd, "rgb_decoder.net.net.", inp)))
-    rgbs = rgbs * w[:, None]
+        rgbs = rgbs * w[:, None]
+    else:                                      # core.py:251-254 "Empty iteration": fresh leaves, no parameter is reached
+        rgbs = torch.zeros((n, 3), requires_grad=True)
+        w = torch.zeros(n, requires_grad=True)
     idx = torch.repeat_interleave(torch.arange(R), info[:, 1].long())
     out = torch.zeros((R, 3)).index_add(0, idx, rgbs)
     if bg is not None:
@@ -146,7 +176,8 @@ def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
 
 def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d: np.ndarray, rgbs: np.ndarray, *,
                        method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
-                       bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10):
+                       bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10, scene_type: str = "aabb",
+                       scene_scale: float = 1.0, cobafa_freqs=None):
     """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
     shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
     including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts)."""
@@ -159,12 +190,14 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
     opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[steps // 2, steps * 3 // 4, steps * 5 // 6, steps * 9 // 10], gamma=0.33)
     aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
-    step_size = float(orc.aabb_step_size(aabb, n_samples))
+    # run.py:154-162: aabb scenes march the box, unbounded ones the Mip-NeRF-360 table with the inf-norm contraction
+    step_size = float(orc.aabb_step_size(aabb, n_samples)) if scene_type == "aabb" else scene_scale / n_samples
     decay = 0.01 ** (1 / 16)
     grid = np.ones((occupancy_res,) * 3, np.float32)
     mean = 1.0
-    bg_t = torch.tensor(bg, dtype=torch.float32)
+    bg_t = None if bg is None else torch.tensor(bg, dtype=torch.float32)
     vf = vanilla_freqs if method == "vanilla" else 0
+    cf = tuple(cobafa_freqs) if method == "cobafa" else None
     cursor, M = 0, rays_o.shape[0]
     target_size = batch_size * n_samples
     losses, counts = [], []
@@ -172,7 +205,7 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
     def sigma_np(pts: np.ndarray) -> np.ndarray:
         with torch.no_grad():
             x = torch.from_numpy(np.ascontiguousarray(pts))
-            feat = mlp(sd, "feature_module.net.net.", posenc(x, sd["feature_module.encoding.freqs"])) if vf else kplanes_features(sd, x)
+            feat = features(sd, x, vf, cf)
             return torch.exp(mlp(sd, "sigma_decoder.net.net.", feat) - 1.).numpy()
 
     for step in range(n_steps):
@@ -184,14 +217,18 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
                 idx = (c + np.arange(batch_size)) % M
                 yield rays_o[idx], rays_d[idx], rgbs[idx]
                 c += batch_size
-        prov = lambda o, d: orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
-                                             n_samples=n_samples, near=0.1, aabb=aabb)
+        if scene_type == "aabb":
+            prov = lambda o, d: orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
+                                                 n_samples=n_samples, near=0.1, aabb=aabb)
+        else:
+            prov = lambda o, d: orc.ray_provider(o, d, marcher="unbounded", contraction="mip360", grid=grid, threshold=thr,
+                                                 n_samples=n_samples, near=0.1, far=1e5, uniform_range=scene_scale, order=float("inf"))
         packed, info, target, k = orc.dynamic_batch(batches(), prov, target_size)
         cursor = (cursor + k * batch_size) % M
         if step % occ_updates == 0:
             jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
             grid, mean = orc.occupancy_update(grid, sigma_np, step_size, 0.01, decay, mean, jit)
-        out = render(sd, torch.from_numpy(packed), torch.from_numpy(info), bg_t, vanilla_freqs=vf)
+        out = render(sd, torch.from_numpy(packed), torch.from_numpy(info), bg_t, vanilla_freqs=vf, cobafa_freqs=cf)
         loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
         if method == "kplanes":
             loss = loss + 1e-4 * loss_tv(sd)

@@ -212,6 +212,67 @@ int make_args(const tn_kplanes_desc *d, KpArgs &a, float *const (*grads)[3])
     return TN_OK;
 }
 
+// ---- explicit K-Planes decoders (models.py:183-205): out[n,k] = act(sum_c f[n,c] * basis[n,k,c]) --------------------------
+// A wave walks samples; lanes stride over the C channels (coalesced 256-B runs of f and of every basis row), the K dot
+// products are reduced across the wave.  HBM-bound: (1 + K) * C * 4 B per sample forward, twice that backward.
+template <int ACT>
+__device__ __forceinline__ float bd_act(float v)
+{
+    if (ACT == TN_ACT_EXP_M1) return expf(v - 1.0f);
+    if (ACT == TN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void basis_dot_fwd_kernel(const float *__restrict__ f, const float *__restrict__ basis, int64_t n, int C,
+                                                            int K, float *__restrict__ out)
+{
+    const int lane = tn::lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += n_waves) {
+        const float *fi = f + i * C, *bi = basis + i * (int64_t)K * C;
+        for (int k = 0; k < K; ++k) {
+            float acc = 0.0f;
+            for (int c = lane; c < C; c += 64) acc += fi[c] * bi[k * C + c];
+            acc = tn::wave_sum(acc);
+            if (lane == 0) out[i * K + k] = bd_act<ACT>(acc);
+        }
+    }
+}
+
+// g_basis[n,k,c] = gv[n,k] f[n,c];  g_f[n,c] (+)= sum_k gv[n,k] basis[n,k,c];  gv = g * act'(v), with the truncated
+// exponential's clamp (models.py:50-53: exp(clamp(x, -15, 15)), x = v - 1) and sigmoid' = y (1 - y)
+template <int ACT>
+__global__ __launch_bounds__(256) void basis_dot_bwd_kernel(const float *__restrict__ f, const float *__restrict__ basis,
+                                                            const float *__restrict__ g_out, int64_t n, int C, int K,
+                                                            float *__restrict__ g_f, float *__restrict__ g_basis, int accumulate_f)
+{
+    const int lane = tn::lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += n_waves) {
+        const float *fi = f + i * C, *bi = basis + i * (int64_t)K * C;
+        float gv[4];
+        for (int k = 0; k < K; ++k) {
+            float acc = 0.0f;
+            for (int c = lane; c < C; c += 64) acc += fi[c] * bi[k * C + c];
+            acc = tn::wave_sum(acc);
+            const float g = g_out[i * K + k];
+            if (ACT == TN_ACT_EXP_M1) gv[k] = g * expf(fminf(fmaxf(acc - 1.0f, -15.0f), 15.0f));
+            else if (ACT == TN_ACT_SIGMOID) { const float y = 1.0f / (1.0f + expf(-acc)); gv[k] = g * y * (1.0f - y); }
+            else gv[k] = g;
+        }
+        for (int c = lane; c < C; c += 64) {
+            const float fc = fi[c];
+            float a = accumulate_f ? g_f[i * C + c] : 0.0f;
+            for (int k = 0; k < K; ++k) {
+                a += gv[k] * bi[k * C + c];
+                if (g_basis) g_basis[(i * K + k) * C + c] = gv[k] * fc;
+            }
+            g_f[i * C + c] = a;
+        }
+    }
+}
+
 inline unsigned tile_blocks(int64_t n) { return (unsigned)std::min<int64_t>(((n + 31) / 32 + 3) / 4, 256 * 8); }
 
 }  // namespace
@@ -253,4 +314,38 @@ extern "C" int tn_kplanes_bwd(const tn_kplanes_desc *desc, const float *x, int64
     default: kplanes_bwd_kernel<4><<<grid, block, 0, s>>>(a, x, x_stride, n, grad_feat); break;
     }
     return tn::check_launch("kplanes_bwd_kernel");
+}
+
+extern "C" int tn_basis_dot_fwd(const float *f, const float *basis, int64_t n, int32_t channels, int32_t n_out, int32_t activation,
+                                float *out, void *stream)
+{
+    TN_REQUIRE(n >= 0 && channels > 0 && n_out >= 1 && n_out <= 4, TN_E_SIZE, "tn_basis_dot_fwd: bad size (1 <= n_out <= 4)");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(f && basis && out, TN_E_NULL, "tn_basis_dot_fwd: null pointer");
+    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 256 * 8)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (activation) {
+    case TN_ACT_EXP_M1: basis_dot_fwd_kernel<TN_ACT_EXP_M1><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
+    case TN_ACT_SIGMOID: basis_dot_fwd_kernel<TN_ACT_SIGMOID><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
+    case TN_ACT_NONE: basis_dot_fwd_kernel<TN_ACT_NONE><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
+    default: return tn::fail(TN_E_CONFIG, "tn_basis_dot_fwd: unknown activation");
+    }
+    return tn::check_launch("basis_dot_fwd_kernel");
+}
+
+extern "C" int tn_basis_dot_bwd(const float *f, const float *basis, const float *grad_out, int64_t n, int32_t channels, int32_t n_out,
+                                int32_t activation, float *grad_f, float *grad_basis, int32_t accumulate_f, void *stream)
+{
+    TN_REQUIRE(n >= 0 && channels > 0 && n_out >= 1 && n_out <= 4, TN_E_SIZE, "tn_basis_dot_bwd: bad size (1 <= n_out <= 4)");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(f && basis && grad_out && grad_f, TN_E_NULL, "tn_basis_dot_bwd: null pointer");
+    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 256 * 8)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (activation) {
+    case TN_ACT_EXP_M1: basis_dot_bwd_kernel<TN_ACT_EXP_M1><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
+    case TN_ACT_SIGMOID: basis_dot_bwd_kernel<TN_ACT_SIGMOID><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
+    case TN_ACT_NONE: basis_dot_bwd_kernel<TN_ACT_NONE><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
+    default: return tn::fail(TN_E_CONFIG, "tn_basis_dot_bwd: unknown activation");
+    }
+    return tn::check_launch("basis_dot_bwd_kernel");
 }

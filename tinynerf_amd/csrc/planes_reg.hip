@@ -137,12 +137,30 @@ __global__ __launch_bounds__(256) void plane_reg_multi_kernel(RegItems items, fl
         atomicAdd(&sums[3 * blockIdx.y + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+__global__ void adam_gate_kernel(int32_t *__restrict__ step, const float *__restrict__ gate)
+{
+    if (gate[0] > 0.0f) step[0] += 1;
+}
+
+// GATED: bias corrections from a device-side step count, nothing but the optional gradient zeroing when the gate is closed
+template <bool GATED>
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamItems items, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                         float bc2_sqrt, int zero_grad)
+                                                         float bc2_sqrt, int zero_grad, const int32_t *__restrict__ step_dev,
+                                                         const float *__restrict__ gate)
 {
     const tn_adam_item &t = items.it[blockIdx.y];
     float *__restrict__ p = t.param; float *__restrict__ g = t.grad; float *__restrict__ m = t.exp_avg; float *__restrict__ v = t.exp_avg_sq;
     const int64_t n = t.n, n4 = (n + 3) / 4;
+    if constexpr (GATED) {
+        if (!(gate[0] > 0.0f)) {
+            if (zero_grad)
+                for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) g[e] = 0.0f;
+            return;
+        }
+        const double st = (double)step_dev[0];
+        bc1 = (float)(1.0 - pow((double)b1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         if (4 * i + 3 < n) {
             f4 pv = reinterpret_cast<f4 *>(p)[i], gv = reinterpret_cast<f4 *>(g)[i];
@@ -322,9 +340,37 @@ extern "C" int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float l
             largest = std::max<int64_t>(largest, (t.n + 3) / 4);
         }
         if (largest == 0) continue;
-        adam_multi_kernel<<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
-            pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad);
+        adam_multi_kernel<false><<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
+            pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad, nullptr, nullptr);
         if (int rc = tn::check_launch("adam_multi_kernel")) return rc;
+    }
+    return TN_OK;
+}
+
+extern "C" int tn_adam_multi_gated(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int32_t *step_dev, const float *gate, int32_t zero_grad, void *stream)
+{
+    TN_REQUIRE(n_items >= 0, TN_E_SIZE, "tn_adam_multi_gated: bad item count");
+    TN_REQUIRE((n_items == 0 || items) && step_dev && gate, TN_E_NULL, "tn_adam_multi_gated: null items / step counter / gate");
+    adam_gate_kernel<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>(step_dev, gate);
+    if (int rc = tn::check_launch("adam_gate_kernel")) return rc;
+    for (int base = 0; base < n_items; base += TN_MULTI_MAX) {
+        AdamItems pack;
+        const int cnt = std::min(TN_MULTI_MAX, n_items - base);
+        int64_t largest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const tn_adam_item &t = items[base + i];
+            TN_REQUIRE(t.n >= 0, TN_E_SIZE, "tn_adam_multi_gated: negative size");
+            TN_REQUIRE(t.n == 0 || (t.param && t.grad && t.exp_avg && t.exp_avg_sq), TN_E_NULL, "tn_adam_multi_gated: null pointer");
+            TN_REQUIRE((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0, TN_E_ALIGN,
+                       "tn_adam_multi_gated: buffers must be 16-byte aligned");
+            pack.it[i] = t;
+            largest = std::max<int64_t>(largest, (t.n + 3) / 4);
+        }
+        if (largest == 0) continue;
+        adam_multi_kernel<true><<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
+            pack, lr, beta1, beta2, eps, weight_decay, 1.0f, 1.0f, zero_grad, step_dev, gate);
+        if (int rc = tn::check_launch("adam_multi_kernel<gated>")) return rc;
     }
     return TN_OK;
 }

@@ -84,7 +84,7 @@ class _RenderKPlanes(Function):
     @staticmethod
     def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
                 freqs: torch.Tensor, n_freqs: int, n_planes: int, n_sigma: int, accumulate: bool, arena: Optional[Arena],
-                train: bool, hint: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                train: bool, hint: Optional[dict], stats: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         planes = list(params[:n_planes])
         sig_p = [p.contiguous() for p in params[n_planes:n_planes + n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_planes + n_sigma:]]
@@ -129,6 +129,13 @@ class _RenderKPlanes(Function):
         out = torch.empty((R, 3), device=dev)
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))
+        # core.py:246-254: when EVERY sample is masked (w == 0 everywhere) the reference renders the background from constants
+        # that carry no graph, i.e. no parameter receives a gradient from the image loss; here the upstream gradient is gated
+        # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer replaces it by the maximum over all ranks -- the
+        # single-GPU step on the union of the ranks' rays is only "empty" when every rank's is -- before the backward runs)
+        ctx.gate = weights.amax().reshape(1) if train else None
+        if stats is not None:
+            stats["gate"] = ctx.gate
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
@@ -147,6 +154,8 @@ class _RenderKPlanes(Function):
         n, R = packed.size(0), info.size(0)
         F = feat.size(1)
         g_out = grad_out.contiguous()
+        if ctx.gate is not None:
+            g_out = g_out * (ctx.gate > 0).to(g_out.dtype)       # "Empty iteration": zero gradients, as on the module-by-module path
 
         def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
             if accumulate and ref is not None and ref.grad is not None and ref.grad.stride() == p.stride():
@@ -216,7 +225,7 @@ class _RenderKPlanes(Function):
         if not scattered:      # plane scatter
             L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         grads = [None if in_place else g for (g, in_place) in bufs]
-        return (None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def supports(renderer) -> bool:
@@ -237,4 +246,5 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
         arena = renderer.__dict__.setdefault("_arena", Arena())
     train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
     return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
-                                len(sig_p), accumulate_into_grad, arena, train, getattr(renderer, "_batch_aux", None), *planes, *sig_p, *rgb_p)
+                                len(sig_p), accumulate_into_grad, arena, train, getattr(renderer, "_batch_aux", None),
+                                renderer.__dict__.setdefault("_stats", {}), *planes, *sig_p, *rgb_p)

@@ -167,19 +167,62 @@ class PositionalEncoding(torch.nn.Module):
         return out.reshape(*x.shape[:-1], out.size(-1))
 
 
+class _BasisDot(Function):
+    """out[n,k] = act(sum_c f[n,c] * basis[n,k,c]) -- the product stage of the explicit K-Planes decoders (models.py:183-205)
+    and, with C = K = 1 and f = 1, a plain element-wise activation (tn_basis_dot_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx: Any, f: torch.Tensor, basis: torch.Tensor, n_out: int, act: int) -> torch.Tensor:  # type: ignore
+        f2 = f.reshape(-1, f.size(-1)).to(torch.float32).contiguous()
+        b2 = basis.reshape(f2.size(0), -1).to(torch.float32).contiguous()
+        dev = L.require_cuda(f2, b2)
+        n, Cc = f2.shape
+        if b2.size(1) != n_out * Cc:
+            raise RuntimeError(f"basis must hold {n_out} x {Cc} values per sample")
+        out = torch.empty((n, n_out), device=dev)
+        L.call("tn_basis_dot_fwd", dev, L.ptr(f2), L.ptr(b2), C.c_int64(n), C.c_int32(Cc), C.c_int32(n_out), C.c_int32(act), L.ptr(out))
+        ctx.save_for_backward(f2, b2)
+        ctx.cfg = (n_out, act, f.shape, basis.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, g: torch.Tensor):  # type: ignore
+        f2, b2 = ctx.saved_tensors
+        n_out, act, f_shape, b_shape = ctx.cfg
+        n, Cc = f2.shape
+        g = g.reshape(n, n_out).to(torch.float32).contiguous()
+        g_f = torch.empty_like(f2)
+        g_b = torch.empty_like(b2) if ctx.needs_input_grad[1] else None
+        L.call("tn_basis_dot_bwd", f2.device, L.ptr(f2), L.ptr(b2), L.ptr(g), C.c_int64(n), C.c_int32(Cc), C.c_int32(n_out), C.c_int32(act),
+               L.ptr(g_f), L.ptr(g_b), C.c_int32(0))
+        return g_f.reshape(f_shape) if ctx.needs_input_grad[0] else None, None if g_b is None else g_b.reshape(b_shape), None, None
+
+
 class TruncatedExponential(Function):  # pylint: disable=abstract-method
-    """exp with a clamped backward (models.py:42-53); inside the heads it is fused into the MLP kernel."""
+    """exp with a clamped backward (models.py:42-53): forward exp(x), backward g * exp(clamp(x, -15, 15)).  Inside the heads it
+    is fused into the MLP kernel (TN_ACT_EXP_M1); on its own it is the element-wise case of tn_basis_dot_* (act(v) = exp(v - 1)
+    evaluated at v = x + 1)."""
 
     @staticmethod
     def forward(ctx, x):  # pylint: disable=arguments-differ
-        x = x.float()
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+        x = x.float().contiguous()
+        dev = L.require_cuda(x)
+        v = (x + 1.0).reshape(-1, 1)
+        one = torch.ones_like(v)
+        out = torch.empty_like(v)
+        L.call("tn_basis_dot_fwd", dev, L.ptr(one), L.ptr(v), C.c_int64(v.size(0)), C.c_int32(1), C.c_int32(1), C.c_int32(L.ACT_EXP_M1), L.ptr(out))
+        ctx.save_for_backward(one, v)
+        ctx.x_shape = x.shape
+        return out.reshape(x.shape)
 
     @staticmethod
     def backward(ctx, g):  # pylint: disable=arguments-differ
-        x = ctx.saved_tensors[0]
-        return g * torch.exp(torch.clamp(x, min=-15, max=15))
+        one, v = ctx.saved_tensors
+        g = g.float().contiguous().reshape(-1, 1)
+        g_one, g_v = torch.empty_like(one), torch.empty_like(v)
+        L.call("tn_basis_dot_bwd", v.device, L.ptr(one), L.ptr(v), L.ptr(g), C.c_int64(v.size(0)), C.c_int32(1), C.c_int32(1),
+               C.c_int32(L.ACT_EXP_M1), L.ptr(g_one), L.ptr(g_v), C.c_int32(0))
+        return g_v.reshape(ctx.x_shape)
 
 
 truncated_exp: Callable = TruncatedExponential.apply
@@ -445,17 +488,22 @@ class KPlanesFeatureField(torch.nn.Module):
 
 
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):
+    """sigma = exp(<f, W f + b> - 1) (models.py:183-191).  The Linear is a plain library GEMM (rocBLAS through torch); the
+    per-sample dot product and the truncated exponential are one HIP launch (tn_basis_dot_fwd, backward with the clamp)."""
+
     def __init__(self, feature_dim):
         super().__init__()
         self.net = torch.nn.Linear(feature_dim, feature_dim)
         self.activation = lambda x: truncated_exp(x - 1.)
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        x = torch.sum(features * self.net(features), -1, keepdim=True)
-        return self.activation(x)
+        return _BasisDot.apply(features, self.net(features), 1, L.ACT_EXP_M1)
 
 
 class KPlanesExplicitColorDecoder(torch.nn.Module):
+    """rgb_k = sigmoid(<f, B_k([PE(d), d, f])>) (models.py:193-205): the basis MLP is one fused MFMA launch, the three dot
+    products and the sigmoid another."""
+
     def __init__(self, feature_dim, n_freqs=8, hidden_dim=128):
         super().__init__()
         self.pe = PositionalEncoding(n_freqs)
@@ -465,10 +513,8 @@ class KPlanesExplicitColorDecoder(torch.nn.Module):
         self.net = MLP(in_dim, hidden_dim, 3, 3 * feature_dim)
 
     def forward(self, features: torch.Tensor, rays_d: torch.Tensor) -> torch.Tensor:
-        x = self.net.fused(features, rays_d, L.ENC_DIR_CAT, self.n_freqs, L.ACT_NONE, self.pe.freqs)
-        x = x.view(-1, 3, self.feature_dim)
-        output = torch.sum(features.unsqueeze(-2) * x, -1)
-        return torch.sigmoid(output)
+        basis = self.net.fused(features, rays_d, L.ENC_DIR_CAT, self.n_freqs, L.ACT_NONE, self.pe.freqs)
+        return _BasisDot.apply(features, basis, 3, L.ACT_SIGMOID)
 
 
 # --------------------------------------------------------------------------------------------

@@ -18,10 +18,15 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.zero_grad_in_step = zero_grad_in_step
+        self._gated_count = {}
 
     @torch.no_grad()
-    def step(self, closure=None, plane_reg=None):
-        """``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None) folds
+    def step(self, closure=None, plane_reg=None, gate=None):
+        """``gate`` (harness): device float scalar; tensors outside ``plane_reg`` are only updated -- and their step count only
+        advances -- when it is > 0 (tn_adam_multi_gated).  This is what torch.optim.Adam does with the ``grad is None`` parameters
+        of the reference's "Empty iteration" (core.py:251-254), decided on the device instead of by a host read-back.
+
+        ``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None) folds
         the K-Planes regulariser's gradient (and its sums) into the update of those planes (tn_adam_reg_multi): the planes are
         streamed once per step.  Their new values are written to a second buffer which then becomes ``plane.data``."""
         loss = closure() if closure is not None else None
@@ -50,7 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
                          or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d)))
                 if not (same and dense and p.dtype == torch.float32):
                     raise RuntimeError("tinynerf_amd.FusedAdam: parameter, gradient and state must be dense fp32 with equal strides")
-                by_step.setdefault((st["step"], p.device, id(p) in reg), []).append((p, g, m, v))
+                # gated tensors share ONE device-side count (they are all skipped or all updated together)
+                by_step.setdefault((st["step"] if (gate is None or id(p) in reg) else -1, p.device, id(p) in reg), []).append((p, g, m, v))
             # one launch per (step count, device): every tensor of the harness shares both
             for (t, dev, with_reg), tensors in by_step.items():
                 common = (C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]), C.c_float(group["weight_decay"]),
@@ -59,7 +65,14 @@ class FusedAdam(torch.optim.Optimizer):
                     items = (L.AdamItem * len(tensors))()
                     for it, (p, g, m, v) in zip(items, tensors):
                         it.param, it.grad, it.exp_avg, it.exp_avg_sq, it.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                    L.call("tn_adam_multi", dev, items, C.c_int32(len(tensors)), *common)
+                    if gate is None:
+                        L.call("tn_adam_multi", dev, items, C.c_int32(len(tensors)), *common)
+                    else:
+                        if self._gated_count.get(dev) is None:      # device-side count of the updates that were not gated away
+                            first = min(self.state[p]["step"] for p, _, _, _ in tensors) - 1
+                            self._gated_count[dev] = torch.full((1,), first, dtype=torch.int32, device=dev)
+                        L.call("tn_adam_multi_gated", dev, items, C.c_int32(len(tensors)), *common[:5], L.ptr(self._gated_count[dev]),
+                               L.ptr(gate), common[6])
                     continue
                 items = (L.AdamRegItem * len(tensors))()
                 for it, (p, g, m, v) in zip(items, tensors):

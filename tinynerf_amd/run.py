@@ -223,10 +223,14 @@ class Trainer:
         R = rendered.size(0)
         acc = self._buf("loss_acc", (1 + 32 * 3,), torch.float64).zero_()          # [0]: sum of squares, [1:]: regulariser sums
         grad = self._buf("grad_rendered", (R, 3), torch.float32)
+        # "Empty iteration" (core.py:251-254): no sample of the step has w > 0 -> no parameter is reached by the image loss, and
+        # torch.optim.Adam skips the grad-is-None parameters (run.py:258-260); decided on the device through this scalar
+        gate = getattr(self.renderer, "_stats", {}).get("gate")
         if self.world == 1:
             inv, inv_dev = 1.0 / (3.0 * R), None
         else:                                                                     # MSE over ALL ranks' rays (see global_ray_count)
-            inv, inv_dev = 1.0, (1.0 / (3.0 * self.global_ray_count(R))).reshape(1).float()
+            tot = self.global_ray_count(R, gate)
+            inv, inv_dev = 1.0, (1.0 / (3.0 * tot)).reshape(1).float()
         L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
         rendered.backward(grad)
@@ -241,21 +245,27 @@ class Trainer:
             self.all_reduce_grads()
         if self.grad_hook is not None:
             self.grad_hook(self)
-        self.optimizer.step(plane_reg=plane_reg)
+        self.optimizer.step(plane_reg=plane_reg, gate=gate)
         self.scheduler.step()
         self.train_step += 1
         self.last = {"n_samples": float(packed.size(0)), "n_rays": float(info.size(0)), "k": float(k)}
         return self.last
 
-    def global_ray_count(self, local_rays: int):
+    def global_ray_count(self, local_rays: int, gate: Optional[torch.Tensor] = None):
         """MSE over ALL ranks' rays: sum of local squared errors / (3 * global ray count).  Dynamic batches
         give every rank a different ray count, so a per-rank mean followed by gradient averaging would not
-        equal the single-GPU loss; with this normalisation the SUM of rank gradients does."""
+        equal the single-GPU loss; with this normalisation the SUM of rank gradients does.
+        ``gate`` (the step's max weight, in place): replaced by the sum over ranks in the same exchange -- the step on the
+        union of all ranks' rays is an "Empty iteration" only when every rank's is."""
         if self.world == 1:
             return float(local_rays)
-        n_rays = torch.full((1,), float(local_rays), device=self.device)   # a fill kernel: no pageable H2D copy, no host sync
-        torch.distributed.all_reduce(n_rays)
-        return n_rays[0]
+        both = torch.full((2,), float(local_rays), device=self.device)     # a fill kernel: no pageable H2D copy, no host sync
+        if gate is not None:
+            both[1:2] = (gate > 0).float()
+        torch.distributed.all_reduce(both)
+        if gate is not None:
+            gate.copy_(both[1:2])
+        return both[0]
 
     def global_mse(self, rendered: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return ((rendered - target) ** 2).sum() / (3.0 * Trainer.global_ray_count(self, rendered.size(0)))

@@ -446,6 +446,24 @@ def weights_bwd_py(sigmas, steps, info, weights, grad_w) -> np.ndarray:
     return out
 
 
+def weights_bwd_fp64(sigmas, steps, info, weights, grad_w) -> np.ndarray:
+    """The formula of cuda.cu:49-56 evaluated exactly (fp64, suffix sums formed directly instead of `-total + prefix`).
+    The reference's fp32 version cancels catastrophically behind a terminated ray (acc = -sum + prefix is rounding noise
+    of size eps * |sum| where the true suffix sum is ~0) and multiplies that noise by the step size, which is up to
+    ~10 in unbounded scenes: its result can be percent-level away from this one.  Tests use the difference between the
+    two as the conditioning of a fixture, i.e. as the tolerance any other fp32 evaluation order is entitled to."""
+    s = np.asarray(sigmas, np.float64); dl = np.asarray(steps, np.float64)
+    w = np.asarray(weights, np.float64); g = np.asarray(grad_w, np.float64)
+    out = np.zeros_like(s)
+    for start, cnt in np.asarray(info):
+        sl = slice(int(start), int(start) + int(cnt))
+        wg = w[sl] * g[sl]
+        suffix = np.concatenate([np.cumsum(wg[::-1])[::-1][1:], [0.0]])
+        T = np.cumprod(np.exp(-s[sl] * dl[sl]))
+        out[sl] = dl[sl] * (T * g[sl] - suffix)
+    return out.astype(f32)
+
+
 def weights_fwd_vectorised(sigmas, steps, info, threshold: float) -> np.ndarray:
     """Independent formulation used to cross-check the loop restatement:
     alpha=1-exp(-sigma*delta); T=exclusive cumprod per ray; w=T*alpha where T>thr."""

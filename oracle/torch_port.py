@@ -68,13 +68,48 @@ def _layers(sd: Dict[str, torch.Tensor], prefix: str):
     return [(sd[prefix + k + ".weight"], sd[prefix + k + ".bias"]) for k in keys]
 
 
+class ReluControl:
+    """Bookkeeping for hidden units whose pre-activation is an fp32 tie: |pre| <= eps * (|x| . |w| + |b|), i.e. the sign of
+    the sum depends on the summation order (ATen's blocked sgemm vs the MFMA K-order of the HIP kernels).  Such a unit's ReLU
+    may legitimately be on in one implementation and off in the other; its whole backward contribution then differs although
+    both are correct fp32 evaluations.  While an instance is installed (``with ctrl:``) every ``mlp`` call records the ties it
+    meets in ``found`` as (prefix, layer, row, column) (and in ``state`` the ReLU state this evaluation took plus |pre| / magnitude) and applies the states listed in ``force`` {(prefix, layer, row, column):
+    bool}.  Used by tests/_ties.py to compare gradients "up to the state of the tie units" for ANY seed."""
+
+    current: Optional["ReluControl"] = None
+
+    def __init__(self, eps: float = 4e-6, force: Optional[dict] = None):
+        self.eps, self.force, self.found, self.state = eps, dict(force or {}), [], {}
+
+    def __enter__(self):
+        self._prev, ReluControl.current = ReluControl.current, self
+        return self
+
+    def __exit__(self, *exc):
+        ReluControl.current = self._prev
+
+    def relu(self, prefix: str, li: int, pre: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            mag = torch.nn.functional.linear(x.abs(), w.abs(), b.abs())
+            near = torch.nonzero(pre.abs() <= self.eps * mag)
+            mask = pre > 0
+            for r, c in near.tolist():
+                self.found.append((prefix, li, r, c))
+                self.state[(prefix, li, r, c)] = (bool(mask[r, c]), float(pre[r, c].abs() / mag[r, c]))
+                if (prefix, li, r, c) in self.force:
+                    mask[r, c] = self.force[(prefix, li, r, c)]
+        return pre * mask
+
+
 def mlp(sd, prefix: str, x: torch.Tensor) -> torch.Tensor:
     """models.py:7-28."""
     layers = _layers(sd, prefix)
+    ctrl = ReluControl.current
     for li, (w, b) in enumerate(layers):
-        x = torch.nn.functional.linear(x, w, b)
-        if li + 1 < len(layers):
-            x = torch.relu(x)
+        pre = torch.nn.functional.linear(x, w, b)
+        if li + 1 == len(layers):
+            return pre
+        x = torch.relu(pre) if ctrl is None else ctrl.relu(prefix, li, pre, x, w, b)
     return x
 
 
@@ -97,8 +132,23 @@ class _TruncExp(torch.autograd.Function):
         return g * torch.exp(torch.clamp(ctx.saved_tensors[0], min=-15, max=15))
 
 
+def explicit_sigma(sd: Dict[str, torch.Tensor], feat: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """models.py:183-191 (KPlanesExplicitOpacityDecoder): exp(<f, W f + b> - 1) with the truncated exponential."""
+    basis = torch.nn.functional.linear(feat, sd[prefix + "net.weight"], sd[prefix + "net.bias"])
+    return _TruncExp.apply(torch.sum(feat * basis, -1, keepdim=True) - 1.)
+
+
+def explicit_rgb(sd: Dict[str, torch.Tensor], feat: torch.Tensor, dirs: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """models.py:193-205 (KPlanesExplicitColorDecoder): sigmoid(<f, B_k>) with B = MLP([PE(d), d, f]).view(n, 3, C)."""
+    inp = torch.cat([posenc(dirs, sd[prefix + "pe.freqs"]), dirs, feat], -1)
+    basis = mlp(sd, prefix + "net.net.", inp).view(-1, 3, feat.size(-1))
+    return torch.sigmoid(torch.sum(feat.unsqueeze(-2) * basis, -1))
+
+
 class _Weights(torch.autograd.Function):
-    """core.py:192-207 over the C restatement of cuda.cu."""
+    """core.py:192-207 over the C restatement of cuda.cu.  ``exact_backward`` (tests only): the same formula in fp64 without the
+    cancellation (orc.weights_bwd_fp64) -- the distance between the two results is the conditioning of a fixture."""
+    exact_backward = False
 
     @staticmethod
     def forward(ctx, sigmas, steps, info, thr):
@@ -109,7 +159,8 @@ class _Weights(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         s, d, info, w = ctx.saved_tensors
-        gs = orc.weights_bwd(s.detach().numpy(), d.detach().numpy(), info.numpy(), w.numpy(), g.contiguous().numpy())
+        fn = orc.weights_bwd_fp64 if _Weights.exact_backward else orc.weights_bwd
+        gs = fn(s.detach().numpy(), d.detach().numpy(), info.numpy(), w.numpy(), g.contiguous().numpy())
         return torch.from_numpy(gs), None, None, None
 
 
@@ -163,6 +214,17 @@ def training_loss(sd, packed, info, target, bg, tv_alpha: float = 1e-4) -> torch
     """run.py:251-256 for method == kplanes."""
     out = render(sd, packed, info, bg)
     return torch.nn.functional.mse_loss(out, target) + tv_alpha * loss_tv(sd)
+
+
+def weights_conditioning(compute_grads) -> Dict[str, float]:
+    """max |grads(reference fp32 weights backward) - grads(exact evaluation of the same formula)| / max |grads| per tensor."""
+    base = compute_grads()
+    _Weights.exact_backward = True
+    try:
+        alt = compute_grads()
+    finally:
+        _Weights.exact_backward = False
+    return {k: float(np.abs(alt[k] - base[k]).max() / max(float(np.abs(base[k]).max()), 1e-30)) for k in base}
 
 
 def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:

@@ -1,0 +1,70 @@
+"""Gradient comparison "up to the state of fp32-tie ReLU units" (see oracle/torch_port.ReluControl).
+
+A hidden unit whose pre-activation is a rounding-level tie can be on in ATen's summation order and off in the MFMA K-order
+(or vice versa).  Both are correct fp32 evaluations of the reference network, but the unit's backward contribution differs,
+which moves that sample's gradient by O(1 %) -- far above any fp32 tolerance.  Instead of picking seeds without such units,
+the comparison lets every recorded tie unit take either state: the reference is re-evaluated with one tie unit flipped at a
+time (closest ties first; flips of different units are additive to first order because they sit in different samples or
+layers), a flip is accepted when the projection of (got - current) on its direction says so, and the result must match
+within the stated tolerance.  With no ties, or when nothing flipped (the common cases), this is a plain comparison."""
+from typing import Callable, Dict
+
+import numpy as np
+
+from oracle import torch_port as tp
+
+
+def _flat(d: Dict[str, np.ndarray], keys) -> np.ndarray:
+    return np.concatenate([np.asarray(d[k], np.float64).ravel() for k in keys])
+
+
+def _check(got, ref, keys, rel, what):
+    for k in keys:
+        r = np.asarray(ref[k], np.float64)
+        rk = rel[k] if isinstance(rel, dict) else rel
+        np.testing.assert_allclose(np.asarray(got[k], np.float64), r, rtol=0, atol=rk * max(float(np.abs(r).max()), 1e-30),
+                                   err_msg=f"{k} ({what}; tolerance {rk:.1e} of the largest element)")
+
+
+def _matches(got, ref, keys, rel) -> bool:
+    try:
+        _check(got, ref, keys, rel, "")
+        return True
+    except AssertionError:
+        return False
+
+
+def assert_grads_match_up_to_relu_ties(got: Dict[str, np.ndarray], compute_ref: Callable[[], Dict[str, np.ndarray]], rel: float,
+                                       eps: float = 2e-6, max_flips: int = 48) -> int:
+    """``compute_ref()`` evaluates the reference gradients through oracle/torch_port.mlp (on any device) and returns
+    {name: array}.  |got - ref| <= rel * max|ref| per tensor (``rel``: one number or {name: number}) for some assignment of the tie units (|pre| <= eps * sum |terms|;
+    the rounding error of an fp32 dot product of K <= 307 terms is ~sqrt(K) * 6e-8 = 1e-6 of that sum).  Returns the number of
+    tie units that had to be flipped."""
+    with tp.ReluControl(eps) as ctrl:
+        base = compute_ref()
+    keys = sorted(base)
+    if _matches(got, base, keys, rel):
+        return 0
+    ties = sorted(dict.fromkeys(ctrl.found), key=lambda t: ctrl.state[t][1])[:max_flips]
+    if not ties:
+        _check(got, base, keys, rel, "no tie unit in the reference")
+    cur = {k: np.asarray(v, np.float64).copy() for k, v in base.items()}
+    b, g = _flat(base, keys), _flat(got, keys)
+    flips = {}
+    for t in ties:
+        with tp.ReluControl(eps, force={t: not ctrl.state[t][0]}):
+            alt = compute_ref()
+        d = _flat(alt, keys) - b
+        if not np.any(d):
+            continue
+        if float(np.dot(g - _flat(cur, keys), d) / np.dot(d, d)) > 0.5:
+            flips[t] = not ctrl.state[t][0]
+            for k in keys:
+                cur[k] += np.asarray(alt[k], np.float64) - np.asarray(base[k], np.float64)
+            if _matches(got, cur, keys, rel):
+                break
+    if len(flips) > 1:                      # several flips: evaluate them together (exact, not the first-order sum)
+        with tp.ReluControl(eps, force=flips):
+            cur = compute_ref()
+    _check(got, cur, keys, rel, f"{len(flips)} of {len(ties)} tie units flipped: {sorted(flips)}")
+    return len(flips)

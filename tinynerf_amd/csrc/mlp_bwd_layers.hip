@@ -173,18 +173,21 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__
     const int j = threadIdx.x & 31, sub = threadIdx.x >> 5;                 // 8 row slots per block
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         float *g = stash + (tile * (int64_t)rows_total + off_g) * 32;
-        const int64_t e0 = tile * 32 * (int64_t)out, e1 = n * (int64_t)out;
-        for (int e = threadIdx.x; e < 32 * out; e += 256) {
-            const int r = e / out;
-            t[r][e - r * out] = e0 + e < e1 ? gy[e0 + e] : 0.0f;
+        const int64_t r0 = tile * 32;
+        for (int c0 = 0; c0 < out; c0 += 256) {                   // 256 output columns per pass through the LDS tile
+            const int cw = min(out - c0, 256);
+            for (int e = threadIdx.x; e < 32 * cw; e += 256) {
+                const int r = e / cw, c = e - r * cw;
+                t[r][c] = r0 + r < n ? gy[(r0 + r) * out + c0 + c] : 0.0f;
+            }
+            __syncthreads();
+            for (int f = sub; f < cw; f += 8) {
+                float v = t[j][f];
+                if (out_act != TN_ACT_NONE) v *= act_grad(g[(c0 + f) * 32 + j], out_act);       // buffer A holds the pre-activation
+                g[(c0 + f) * 32 + j] = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int f = sub; f < out; f += 8) {
-            float v = t[j][f];
-            if (out_act != TN_ACT_NONE) v *= act_grad(g[f * 32 + j], out_act);       // buffer A holds the pre-activation
-            g[f * 32 + j] = v;
-        }
-        __syncthreads();
     }
 }
 
@@ -207,19 +210,23 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const int64_t n_tiles = (n + 31) >> 5;
-    const int TN = (a.N + 31) >> 5, ng = (a.N + 7) >> 3;
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
         asm volatile("" : "+v"(j), "+v"(h));
         float *st = stash + tile * (int64_t)a.rows_total * 32;
-        const float *gin = st + a.off_gin * 32;
+        // an output layer wider than H (N > 32 T, e.g. the 3 x 96 basis of KPlanesExplicitColorDecoder on a 128-wide stack) is
+        // consumed in chunks of H rows; the chunks' contributions to the input gradient add up
+        for (int n0 = 0; n0 < a.N; n0 += H) {
+        const float *gin = st + (a.off_gin + n0) * 32;
+        const int Nc = min(a.N - n0, H);
+        const int TN = (Nc + 31) >> 5, ng = (Nc + 7) >> 3;
         f32x16 G[T];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = 32 * t + frow(r, h);
-                G[t][r] = (t < TN && nn < a.N) ? gin[nn * 32 + j] : 0.0f;
+                G[t][r] = (t < TN && nn < Nc) ? gin[nn * 32 + j] : 0.0f;
             }
         const int n_kt = FIRST ? (a.in_dim + 31) >> 5 : T;
 #pragma clang loop unroll(disable)
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int nn = 32 * t + 8 * q + 4 * h + u;
-                            w[u] = (nn < a.N && kok) ? a.W[(int64_t)nn * a.K + kc] : 0.0f;
+                            w[u] = (nn < Nc && kok) ? a.W[(int64_t)(n0 + nn) * a.K + kc] : 0.0f;
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], G[t][4 * q + u], acc);
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * kt + frow(r, h);
-                        if (f < a.in_dim) gx[row * a.in_dim + f] = a.accum_gx ? gx[row * a.in_dim + f] + acc[r] : acc[r];
+                        if (f < a.in_dim) gx[row * a.in_dim + f] = (a.accum_gx || n0 > 0) ? gx[row * a.in_dim + f] + acc[r] : acc[r];
                     }
                 }
             } else {
@@ -266,9 +273,11 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = 32 * kt + frow(r, h);
-                    gout[f * 32 + j] = hm[f * 32 + j] > 0.0f ? acc[r] : 0.0f;
+                    const float v = hm[f * 32 + j] > 0.0f ? acc[r] : 0.0f;
+                    gout[f * 32 + j] = n0 > 0 ? gout[f * 32 + j] + v : v;
                 }
             }
+        }
         }
     }
 }
@@ -785,7 +794,7 @@ extern "C" __attribute__((visibility("hidden"))) int64_t tn_mlp_bwd_layers_works
     if (L < 2 || L > TN_MLP_MAX_LAYERS) return 0;
     if (H != 32 && H != 64 && H != 128 && H != 256) return 0;
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
-    if (desc->dims[L] > H && desc->dims[L] > 256) return 0;
+    if (((desc->dims[L] + 31) / 32) * (H / 32) > 64) return 0;          // weight-gradient tiling of the output layer (run_layers)
     const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L]);
     return ((n + 31) / 32) * (int64_t)lay.total * 32 * (int64_t)sizeof(float);
 }

@@ -183,7 +183,7 @@ class _BasisDot(Function):
         L.call("tn_basis_dot_fwd", dev, L.ptr(f2), L.ptr(b2), C.c_int64(n), C.c_int32(Cc), C.c_int32(n_out), C.c_int32(act), L.ptr(out))
         ctx.save_for_backward(f2, b2)
         ctx.cfg = (n_out, act, f.shape, basis.shape)
-        return out
+        return out.reshape(*f.shape[:-1], n_out)
 
     @staticmethod
     def backward(ctx: Any, g: torch.Tensor):  # type: ignore

@@ -56,7 +56,11 @@ def test_weights_fwd_bwd_vs_oracle(max_len, n_rays):
     w_ref = orc.weights_fwd(s, d, info, 1e-4)
     st = cu(s).requires_grad_(True)
     w = core().NerfWeights.apply(st, cu(d), cu(info, torch.int32), 1e-4)
-    ok = ~np.repeat(danger_rays(s, d, info, 1e-4), info[:, 1])
+    bad = danger_rays(s, d, info, 1e-4)
+    # a ray is excluded only when its transmittance passes within 1e-4 (relative) of the threshold: with T falling by a
+    # factor >= 1.001 per sample that is at most a handful of rays per case -- bounded, so the exclusion cannot hide a bug
+    assert bad.sum() <= max(2, n_rays // 50), int(bad.sum())
+    ok = ~np.repeat(bad, info[:, 1])
     np.testing.assert_allclose(w.detach().cpu().numpy()[ok], w_ref[ok], rtol=0, atol=1e-6)
     assert (w_ref == 0).any() and np.array_equal((w.detach().cpu().numpy() == 0)[ok], (w_ref == 0)[ok])
     w.backward(cu(g))

@@ -303,6 +303,17 @@ int tn_cobafa_fwd(const tn_cobafa_desc *desc, const float *x, int64_t n, float *
 int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const float *grad_feat, float *grad_coef,
                   float *const *grad_basis, void *stream);
 
+/* north star: "the K-Planes bilinear grid sample ... fused into the same launch" as the persistent MLP.  tn_kplanes_fwd +
+ * tn_mlp_fwd_stash_pair in ONE launch (reference call chain core.py:239-249 -> models.py:153-163 -> models.py:70-89): every
+ * wave gathers the 3 x 3 planes x 4 taps of its 32 samples straight into the first-layer MFMA operand registers of both
+ * heads; `feat` [n, 96] is written once for the backward (weight gradient of the first layers, plane scatter) and never read
+ * here.  Requirements: 3 scales x 32 channels, all planes present, both heads as in tn_mlp_fwd_stash_pair with in_dim 96.
+ * Results are bit-identical to the two-launch sequence. */
+int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kdesc, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc,
+                            const tn_mlp_desc *partner, const float *aux, int64_t n, float *feat, float *y, float *partner_y,
+                            void *workspace, int64_t workspace_bytes, void *partner_workspace, int64_t partner_workspace_bytes,
+                            void *stream);
+
 /* Product stage of the explicit K-Planes decoders (models.py:183-205, exercised by the reference's tests/test_models.py:35-69;
  * train() itself uses the Vanilla decoders, run.py:135-139):
  *   out[n,k] = act(sum_c f[n,c] * basis[n,k,c]),   f [n,C], basis [n,K,C] row-major, 1 <= K <= 4.

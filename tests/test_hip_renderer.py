@@ -90,3 +90,33 @@ def test_fused_accumulates_into_existing_grads():
     for name, p in r.named_parameters():
         ref = 2 * g["grad." + name]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * max(1.0, np.abs(ref).max() / 1e-2), err_msg=name)
+
+
+@pytest.mark.parametrize("n_rays,per_ray", [(37, 29), (300, 113)])
+def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypatch):
+    """tn_kplanes_mlp_fwd_pair (gather inside the MLP launch, north star) against tn_kplanes_fwd + tn_mlp_fwd_stash_pair:
+    same arithmetic in the same order -> identical bits for the rendered colours (gradients: the same terms through fp32
+    atomics in a different order).  Points partly outside [-1, 1], ragged rays."""
+    from tinynerf_amd import core, fused, models as m
+    torch.manual_seed(n_rays)
+    field = m.KPlanesFeatureField(32, (16, 40, 96))
+    r = core.NerfRenderer(field, m.VanillaOpacityDecoder(96), m.VanillaColorDecoder(8, 96, 64, 3), torch.ones(3)).to(DEV)
+    cnt = torch.randint(0, per_ray, (n_rays,), dtype=torch.int32)
+    info = torch.stack([torch.cumsum(cnt, 0, dtype=torch.int32) - cnt, cnt], -1).to(DEV)
+    n = int(cnt.sum())
+    packed = torch.rand(n, 7, device=DEV)
+    packed[:, :3] = packed[:, :3] * 2.2 - 1.1
+    packed[:, 3:6] = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=DEV), dim=-1)[torch.repeat_interleave(
+        torch.arange(n_rays, device=DEV), cnt.to(DEV).long())]
+    packed[:, 6] = 0.02
+    target = torch.rand(n_rays, 3, device=DEV)
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(fused, "FUSE_GATHER", fuse)
+        r.zero_grad(set_to_none=True)
+        out = r(packed, info)
+        torch.nn.functional.mse_loss(out, target).backward()
+        res[fuse] = (out.detach().clone(), {k: p.grad.clone() for k, p in r.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g in res[True][1].items():         # every gradient ends in fp32 atomics: same terms, different order
+        np.testing.assert_allclose(g.cpu().numpy(), res[False][1][k].cpu().numpy(), rtol=0, atol=2e-6 * float(g.abs().max()), err_msg=k)

@@ -23,9 +23,16 @@ struct PlaneTaps {
 
 // ATen grid_sampler_2d conventions: align_corners=True, zeros padding; u indexes W, v indexes H.
 __device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, int C) {
+    // One rounding per operation, like ATen, and the same bits in every kernel that inlines this: under -ffp-contract=fast the
+    // compiler folds the product ix = t * (W - 1) into the subtractions that follow (fx = fma(t, W - 1, -x0)) wherever it
+    // sees fit -- observed in one kernel and not in another: features 6e-6 apart at W = 96 -- per-statement pragmas
+    // notwithstanding; the empty asm statements pin the sums and the products.
     PlaneTaps t;
-    const float ix = ((u + 1.0f) * 0.5f) * (float)(W - 1);
-    const float iy = ((v + 1.0f) * 0.5f) * (float)(H - 1);
+    float u1 = u + 1.0f, v1 = v + 1.0f;
+    asm volatile("" : "+v"(u1), "+v"(v1));
+    float ix = (u1 * 0.5f) * (float)(W - 1);
+    float iy = (v1 * 0.5f) * (float)(H - 1);
+    asm volatile("" : "+v"(ix), "+v"(iy));
     const float x0f = floorf(ix), y0f = floorf(iy);
     const float fx = ix - x0f, fy = iy - y0f;
     const float gx = (x0f + 1.0f) - ix, gy = (y0f + 1.0f) - iy;
@@ -46,7 +53,9 @@ __device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, 
 // interpolate NV float4 groups (channels c0 .. c0+4*NV) of one plane.  All 4*NV loads are unconditional (an
 // out-of-bounds tap reads texel 0 with weight 0): a load under `if (in bounds)` has to be waited for at the end of
 // that branch, which serialises the four taps' L2 latencies instead of overlapping all loads of a plane.
-template <int NV>
+// CS = distance in floats between consecutive groups: 4 = one contiguous channel run (lane owns channels c0 .. c0+4*NV),
+// 8 = the MFMA B-operand pattern of mlp_device.h (lane half h owns channels 8v + 4h .. +3, v = 0..NV-1, with c0 = 4h)
+template <int NV, int CS = 4>
 __device__ __forceinline__ void plane_gather(const float *__restrict__ plane, const PlaneTaps &t, int c0, f32x4k (&out)[NV]) {
     f32x4k tex[4][NV];
     float w[4];
@@ -56,14 +65,15 @@ __device__ __forceinline__ void plane_gather(const float *__restrict__ plane, co
         const f32x4k *p = reinterpret_cast<const f32x4k *>(plane + (in ? t.off[k] : 0) + c0);
         w[k] = in ? t.w[k] : 0.0f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) tex[k][v] = p[v];
+        for (int v = 0; v < NV; ++v) tex[k][v] = p[v * (CS / 4)];
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        f32x4k acc = tex[0][v] * w[0];          // same order as before: ((0 + t0 w0) + t1 w1) + ...
-        acc += tex[1][v] * w[1];
-        acc += tex[2][v] * w[2];
-        acc += tex[3][v] * w[3];
+        f32x4k acc = tex[0][v] * w[0];          // an explicit fma chain: the same instructions in every kernel
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(tex[k][v][e], w[k], acc[e]);
         out[v] = acc;
     }
 }

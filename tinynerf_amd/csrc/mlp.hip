@@ -14,7 +14,9 @@
 //   TN_ENC_DIR_CAT : enc(x, d) = cat[PE_F(d), d, x]          (models.py:79-89, VanillaColorDecoder)
 // Output activations: exp(y-1) (models.py:74) and sigmoid (models.py:85).
 #include "mlp_stage.h"
+#include "kplanes_device.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -29,15 +31,30 @@ using namespace tn::mlp;
 // weights sit behind the first head's in LDS), so x is read from HBM once for both.
 struct FwdPair { MlpArgs b; const float *aux; float *y; float *stash; };
 
+// KP (with STASH, PAIR, FAST; north star: "the K-Planes bilinear grid sample ... fused into the same launch"): the x rows are
+// not read from memory but gathered here -- 3 scales x 3 planes of 32 channels, Hadamard product per scale (models.py:153-163) --
+// straight into the first layer's B-operand registers: lane (sample j, half h) gathers channels 8q + 4h .. +3 (q = 0..3) of
+// every texel, which are exactly the slots 8g + 4h .. +3 it feeds to the MFMAs of group g = 4 * scale + q.  The feature row
+// is also written out once (the backward's weight-gradient and scatter kernels read it); it is never read back here.  While
+// one wave waits for its 36 texel lines the other waves of the SIMD run their MFMA layers.
+struct KpFwd {
+    int H[3], W[3];
+    const float *planes[3][3];
+    const float *coords;
+    int64_t coord_stride;
+    float *feat;
+};
+
 // FAST: every head takes the plain-column first layer (TN_ENC_NONE with in_dim % 4 == 0, or TN_ENC_AUX_CAT).  Compiled
 // separately because the generic first layer drags the sin / cos range reduction of the fused encodings into the kernel
 // (14 k VALU instructions, ~120 KB of code against a 64 KB instruction cache shared by two CUs).
-template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false>
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
                                                            const float *__restrict__ aux0, int64_t n,
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
-                                                           float *__restrict__ stash0, FwdPair pr)
+                                                           float *__restrict__ stash0, FwdPair pr, KpFwd kp = KpFwd())
 {
+    static_assert(!KP || (FAST && STASH && H == 64), "the fused gather feeds the plain-column first layer of the width-64 heads");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     if constexpr (WLDS) {
@@ -50,6 +67,35 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
     const int64_t n_tiles = (n + 31) >> 5;
 
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+      f32x4 fr[KP ? 12 : 1];                 // KP: the tile's feature rows as first-layer operands (slots 8g + 4h .. +3)
+      if constexpr (KP) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        const float *cr = kp.coords + (valid ? row : 0) * kp.coord_stride;
+        const float xs[3] = {cr[0], cr[1], cr[2]};
+#pragma unroll
+        for (int sc = 0; sc < 3; ++sc) {
+            tn::f32x4k prod[4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float u, v;
+                tn::pair_uv(xs, p, u, v);
+                const tn::PlaneTaps t = tn::plane_taps(u, v, kp.H[sc], kp.W[sc], 32);
+                tn::f32x4k val[4];
+                tn::plane_gather<4, 8>(kp.planes[sc][p], t, 4 * h, val);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) prod[q] = p == 0 ? val[q] : prod[q] * val[q];      // (1*p0)*p1*p2, models.py:157-160
+                __builtin_amdgcn_sched_barrier(0);              // one plane's 16 loads in flight at a time (register budget)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fr[4 * sc + q] = f32x4{prod[q][0], prod[q][1], prod[q][2], prod[q][3]};
+                if (valid) *reinterpret_cast<tn::f32x4k *>(kp.feat + row * 96 + 32 * sc + 8 * q + 4 * h) = prod[q];
+            }
+        }
+      }
       auto head = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
                       float *__restrict__ pre_act, float *__restrict__ stash) {
         const int L = a.n_layers;
@@ -73,7 +119,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                 }
             }
         }
-        const float *xrow = x + (valid ? row : 0) * a.in_dim;
+        const float *xrow = KP ? nullptr : x + (valid ? row : 0) * a.in_dim;
         float aux3[3] = {0.f, 0.f, 0.f};
         const float *auxrow = nullptr;
         if (!FAST && valid) {
@@ -106,17 +152,41 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         if constexpr (FAST) {
             const float *arow = a.enc == TN_ENC_AUX_CAT
                                     ? aux + (int64_t)(a.aux_index ? a.aux_index[valid ? row : 0] : (valid ? row : 0)) * a.aux_stride
-                                    : xrow;
+                                    : (KP ? kp.feat : xrow);
             auto in_ptr = [&](int g) {
                 const int q0 = 8 * (g < G0 ? g : G0 - 1) + 4 * h;
-                const float *p = q0 < a.in_dim ? xrow + q0 : (a.enc == TN_ENC_AUX_CAT ? arow + (q0 - a.in_dim) : xrow);
+                // (KP: the x slots live in registers; a head without aux columns requests a dummy line it never uses)
+                const float *xp = KP ? kp.feat : xrow + q0;
+                const float *p = q0 < a.in_dim ? xp : (a.enc == TN_ENC_AUX_CAT ? arow + (q0 - a.in_dim) : (KP ? kp.feat : xrow));
                 return reinterpret_cast<const f32x4 *>(p);
             };
-            f32x4 b0 = *in_ptr(0), b1 = *in_ptr(1);
+            // (KP: the aux-table slots behind the features are requested before the 12 register groups run)
+            f32x4 b0 = *in_ptr(KP ? 12 : 0), b1 = *in_ptr(KP ? 13 : 1);
             f32x4 w[T], wn[T];
 #pragma unroll
             for (int ob = 0; ob < T; ++ob) w[ob] = load_a4<true>(W0, 32 * ob + j, 4 * h, a.K0, a.stride[0]);
-            for (int g = 0; g < G0; ++g) {
+            int g_first = 0;
+            if constexpr (KP) {                 // slots 0..95: the gathered features, already in registers
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    const int gn = g + 1 < G0 ? g + 1 : g;
+#pragma unroll
+                    for (int ob = 0; ob < T; ++ob) wn[ob] = load_a4<true>(W0, 32 * ob + j, 8 * gn + 4 * h, a.K0, a.stride[0]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int ob = 0; ob < T; ++ob) act[ob] = tn::mfma32(w[ob][u], fr[g][u], act[ob]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ob = 0; ob < T; ++ob) w[ob] = wn[ob];
+                }
+                g_first = 12;
+                // the loop below may not run at all (head without aux columns): results are materialised HERE, in straight-line
+                // code behind the last MFMA (see tn::pin16 -- hipcc under-counts the MFMA wait states on the short path)
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) tn::pin16(act[ob]);
+            }
+            for (int g = g_first; g < G0; ++g) {
                 const f32x4 b2 = *in_ptr(g + 2);
                 const int gn = g + 1 < G0 ? g + 1 : g;           // weights of the next group, requested before this group's MFMAs
 #pragma unroll
@@ -277,7 +347,7 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t n, int C, con
 
 template <int H>
 int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s,
-               const FwdPair *pair = nullptr)
+               const FwdPair *pair = nullptr, const KpFwd *kp = nullptr)
 {
     const int64_t n_tiles = (n + 31) / 32;
     size_t lds_bytes = (size_t)a.lds_floats * 4;
@@ -296,10 +366,20 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
                 if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wps * 64)));
                 const int64_t blocks = std::min<int64_t>((n_tiles + wps - 1) / wps, 256 * per_cu);
-                kern<<<dim3((unsigned)blocks), dim3(wps * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
+                kern<<<dim3((unsigned)blocks), dim3(wps * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, KpFwd());
                 return TN_OK;
             };
             int rc;
+            if (kp) {                   // gather fused in: 12 waves (170-VGPR budget: 48 registers hold the tile's features)
+                if (!(fast && pair)) return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: both heads must take the plain-column first layer");
+                const int wv = getenv("TN_KPF_WAVES") ? atoi(getenv("TN_KPF_WAVES")) : 12;
+                auto kern = wv == 8 ? mlp_fwd_kernel<H, true, 8, true, true, true, true> : mlp_fwd_kernel<H, true, 12, true, true, true, true>;
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+                const int64_t blocks = std::min<int64_t>((n_tiles + wv - 1) / wv, 256);
+                kern<<<dim3((unsigned)blocks), dim3(wv * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+                return tn::check_launch("mlp_fwd_kernel(kplanes)");
+            }
             if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
             else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
             if (rc) return rc;
@@ -310,13 +390,13 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, KpFwd());
     } else {
         if (stash) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: weights must fit LDS");
         // weights streamed from L2
         auto kern = mlp_fwd_kernel<H, false, WPB, false>;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
-        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act, nullptr, pr);
+        kern<<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, n, y, pre_act, nullptr, pr, KpFwd());
     }
     return tn::check_launch("mlp_fwd_kernel");
 }
@@ -336,20 +416,21 @@ __global__ void dir_encode_kernel(const float *__restrict__ d, int64_t n, const 
 }
 
 int fwd_common(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash,
-               hipStream_t s, const char *who, const FwdPair *pair = nullptr)
+               hipStream_t s, const char *who, const FwdPair *pair = nullptr, const KpFwd *kp = nullptr)
 {
     MlpArgs a;
     int H = 0;
     if (int rc = plan(desc, a, H)) return rc;
     TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mlp_fwd: negative n");
     if (n == 0) return TN_OK;
-    TN_REQUIRE(x && y, TN_E_NULL, "tn_mlp_fwd: null pointer");
+    TN_REQUIRE((x || kp) && y, TN_E_NULL, "tn_mlp_fwd: null pointer");
     TN_REQUIRE((a.enc != TN_ENC_DIR_CAT && a.enc != TN_ENC_AUX_CAT) || aux, TN_E_NULL, "tn_mlp_fwd: dir_cat / aux_cat need aux");
     TN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: x / y must be 16-byte aligned");
+    TN_REQUIRE(!kp || H == 64, TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: width-64 heads only");
     TN_REQUIRE(a.enc != TN_ENC_AUX_CAT || ((uintptr_t)aux & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd: aux table must be 16-byte aligned");
     switch (H) {
     case 32: return launch_fwd<32>(a, x, aux, n, y, pre_act, stash, s, pair);
-    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, stash, s, pair);
+    case 64: return launch_fwd<64>(a, x, aux, n, y, pre_act, stash, s, pair, kp);
     case 128: return launch_fwd<128>(a, x, aux, n, y, pre_act, stash, s, pair);
     default: return launch_fwd<256>(a, x, aux, n, y, pre_act, stash, s, pair);
     }
@@ -414,6 +495,49 @@ extern "C" int tn_mlp_fwd_stash_pair(const tn_mlp_desc *desc, const tn_mlp_desc 
     if (int rc = plan(partner, pr.b, Hb)) return rc;
     pr.aux = nullptr; pr.y = partner_y; pr.stash = (float *)partner_workspace;
     return fwd_common(desc, x, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_mlp_fwd_stash_pair", &pr);
+}
+
+extern "C" int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kd, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc,
+                                       const tn_mlp_desc *partner, const float *aux, int64_t n, float *feat, float *y, float *partner_y,
+                                       void *workspace, int64_t workspace_bytes, void *partner_workspace, int64_t partner_workspace_bytes,
+                                       void *stream)
+{
+    TN_REQUIRE(kd && desc && partner, TN_E_NULL, "tn_kplanes_mlp_fwd_pair: null descriptor");
+    TN_REQUIRE(kd->n_scales == 3 && kd->channels == 32 && desc->in_dim == 96 && partner->in_dim == 96, TN_E_CONFIG,
+               "tn_kplanes_mlp_fwd_pair: 3 scales x 32 channels feeding two heads with in_dim 96 (run.py:136-139)");
+    TN_REQUIRE(coord_stride >= 3, TN_E_SIZE, "tn_kplanes_mlp_fwd_pair: bad coordinate stride");
+    if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_kplanes_mlp_fwd_pair: negative n");
+    TN_REQUIRE(coords && feat, TN_E_NULL, "tn_kplanes_mlp_fwd_pair: null pointer");
+    TN_REQUIRE(((uintptr_t)feat & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd_pair: feat must be 16-byte aligned");
+    KpFwd kp;
+    for (int s = 0; s < 3; ++s) {
+        TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 31), TN_E_SIZE,
+                   "tn_kplanes_mlp_fwd_pair: bad plane resolution");
+        kp.H[s] = kd->height[s]; kp.W[s] = kd->width[s];
+        for (int p = 0; p < 3; ++p) {
+            TN_REQUIRE(kd->planes[s][p], TN_E_NULL, "tn_kplanes_mlp_fwd_pair: null plane pointer");
+            TN_REQUIRE(((uintptr_t)kd->planes[s][p] & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd_pair: planes must be 16-byte aligned");
+            kp.planes[s][p] = kd->planes[s][p];
+        }
+    }
+    kp.coords = coords; kp.coord_stride = coord_stride; kp.feat = feat;
+    // the rest is tn_mlp_fwd_stash_pair with the x rows replaced by the gather
+    const int H = desc->dims[1];
+    TN_REQUIRE(H == 64 && partner->dims[1] == 64 && desc->n_layers >= 2 && desc->n_layers <= 5 && partner->n_layers >= 2 &&
+                   partner->n_layers <= 5 && desc->dims[desc->n_layers] <= 4 && partner->dims[partner->n_layers] <= 4 &&
+                   (desc->encoding == TN_ENC_NONE || desc->encoding == TN_ENC_AUX_CAT) && partner->encoding == TN_ENC_NONE,
+               TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: two width-64 heads (<= 5 layers, <= 4 outputs); partner without encoding");
+    const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
+    TN_REQUIRE(need_a > 0 && need_b > 0, TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: configuration not covered by the two-pass backward");
+    TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b && y && partner_y, TN_E_NULL,
+               "tn_kplanes_mlp_fwd_pair: workspace / output missing or too small");
+    TN_REQUIRE((((uintptr_t)workspace | (uintptr_t)partner_workspace | (uintptr_t)partner_y | (uintptr_t)y) & 15) == 0, TN_E_ALIGN,
+               "tn_kplanes_mlp_fwd_pair: buffers must be 16-byte aligned");
+    FwdPair pr;
+    int Hb = 0;
+    if (int rc = plan(partner, pr.b, Hb)) return rc;
+    pr.aux = nullptr; pr.y = partner_y; pr.stash = (float *)partner_workspace;
+    return fwd_common(desc, nullptr, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_kplanes_mlp_fwd_pair", &pr, &kp);
 }
 
 extern "C" int tn_dir_encode(const float *dirs, int64_t n, const float *freqs, int n_freqs, float *out, int stride, void *stream)

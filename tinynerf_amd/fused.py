@@ -43,6 +43,7 @@ class Arena:
 
 
 PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)
+FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
 
 
@@ -93,7 +94,6 @@ class _RenderKPlanes(Function):
         kdesc, keep = _kplanes_desc(planes)
         F = kdesc.n_scales * kdesc.channels
         feat = _alloc(arena, "feat", (n, F), dev)
-        L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
         table, ray_ids, stride, steps = _ray_aux(packed, info, freqs, n_freqs, arena, hint)
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
         rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, 0, ray_ids, stride)
@@ -105,7 +105,15 @@ class _RenderKPlanes(Function):
         sigma = _alloc(arena, "sigma", (n,), dev)
         rgbs = _alloc(arena, "rgbs", (n, 3), dev)
         pair = (ws_s is not None and ws_r is not None and PAIR_FORWARD and F % 4 == 0 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64)
-        if pair:           # both heads in one launch: the feature rows are read from HBM once
+        gather_fused = pair and FUSE_GATHER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
+        if gather_fused:   # gather + both heads in ONE launch: the feature rows go from the texel lines to the MFMA operands
+            L.call("tn_kplanes_mlp_fwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(rdesc), C.byref(sdesc), L.ptr(table),
+                   C.c_int64(n), L.ptr(feat), L.ptr(rgbs), L.ptr(sigma), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
+        if gather_fused:
+            pass
+        elif pair:         # both heads in one launch: the feature rows are read from HBM once
             L.call("tn_mlp_fwd_stash_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs),
                    L.ptr(sigma), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
         elif ws_s is not None:

@@ -314,6 +314,19 @@ int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kdesc, const float *coords, i
                             void *workspace, int64_t workspace_bytes, void *partner_workspace, int64_t partner_workspace_bytes,
                             void *stream);
 
+/* Backward twin: tn_mlp_bwd_pair with the plane scatter (tn_kplanes_bwd) inside the data-gradient chain launch.  d(loss)/d(feat)
+ * never leaves the registers of the wave that computed it: each wave scatters its 32 samples' three 32-channel blocks into
+ * grad_planes[s][p] (+=, fp32 atomics; NULL entries are skipped) while the other waves of its SIMD run their MFMA chains.
+ * `grad_feat` may be NULL (it is only written on request).  `feat` is the row-major [n, 96] feature tensor the forward wrote
+ * (the weight-gradient kernels read it).  desc->flags: TN_MLP_STASHED required; TN_MLP_CHAIN_ONLY / TN_MLP_WGRAD_ONLY split the
+ * call as in tn_mlp_bwd_pair (CHAIN_ONLY leaves the plane gradients final). */
+int tn_kplanes_mlp_bwd_pair(const tn_kplanes_desc *kdesc, const float *coords, int64_t coord_stride,
+                            float *const (*grad_planes)[3], const tn_mlp_desc *desc, const tn_mlp_desc *partner,
+                            const float *feat, const float *aux, const float *grad_y, const float *partner_grad_y, int64_t n,
+                            float *const *grad_weights, float *const *grad_biases, float *const *partner_grad_weights,
+                            float *const *partner_grad_biases, float *grad_feat, void *workspace, int64_t workspace_bytes,
+                            void *partner_workspace, int64_t partner_workspace_bytes, void *stream);
+
 /* Product stage of the explicit K-Planes decoders (models.py:183-205, exercised by the reference's tests/test_models.py:35-69;
  * train() itself uses the Vanilla decoders, run.py:135-139):
  *   out[n,k] = act(sum_c f[n,c] * basis[n,k,c]),   f [n,C], basis [n,K,C] row-major, 1 <= K <= 4.

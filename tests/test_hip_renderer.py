@@ -94,7 +94,8 @@ def test_fused_accumulates_into_existing_grads():
 
 @pytest.mark.parametrize("n_rays,per_ray", [(37, 29), (300, 113)])
 def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypatch):
-    """tn_kplanes_mlp_fwd_pair (gather inside the MLP launch, north star) against tn_kplanes_fwd + tn_mlp_fwd_stash_pair:
+    """tn_kplanes_mlp_fwd_pair / tn_kplanes_mlp_bwd_pair (gather / scatter inside the MLP launches, north star) against
+    tn_kplanes_fwd + tn_mlp_fwd_stash_pair and tn_mlp_bwd_pair + tn_kplanes_bwd:
     same arithmetic in the same order -> identical bits for the rendered colours (gradients: the same terms through fp32
     atomics in a different order).  Points partly outside [-1, 1], ragged rays."""
     from tinynerf_amd import core, fused, models as m
@@ -113,6 +114,7 @@ def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypa
     res = {}
     for fuse in (False, True):
         monkeypatch.setattr(fused, "FUSE_GATHER", fuse)
+        monkeypatch.setattr(fused, "FUSE_SCATTER", fuse)            # backward twin: tn_kplanes_mlp_bwd_pair
         r.zero_grad(set_to_none=True)
         out = r(packed, info)
         torch.nn.functional.mse_loss(out, target).backward()

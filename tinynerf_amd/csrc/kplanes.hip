@@ -2,7 +2,7 @@
 // lookups, Hadamard product over the planes of a scale, scales concatenated.
 // Replaces 9 x (grid_sampler_2d + transpose + contiguous) + 6 muls + cat of the reference
 // (27+ launches) with one launch; backward scatters with hardware fp32 atomics.
-#include "kplanes_device.h"
+#include "kplanes_scatter.h"
 #include <algorithm>
 
 namespace {
@@ -50,30 +50,14 @@ __global__ __launch_bounds__(256) void kplanes_fwd_kernel(KpArgs a, const float 
     }
 }
 
-// ---- backward: transposed, run-merged scatter ------------------------------------------------------
-// Measured on MI355X (scratch/atomic_bench.hip): a wave64 global_atomic_add_f32 whose lanes hit 64 different
-// cache lines retires ~20 G lane-atomics/s, one whose half-waves each cover the 32 consecutive dwords of ONE
-// line ~270 G/s.  The forward mapping (lane = sample) is the slow pattern, so the scatter is transposed
-// through a 5 KiB per-wave LDS tile: phase A (lane = sample, channel half) writes the 32x32 tile of
-// d(feat)/d(plane value) plus the 4 tap offsets / weights of every sample; phase B (lane = channel) walks the
-// samples in order -- consecutive samples of a ray fall into the same cell for several steps (a straight
-// line visits the cells of a plane monotonically), so the contributions of a RUN of samples are accumulated
-// in registers and ONE full-line atomic per tap is issued at the end of the run.  Run boundaries depend on
-// the cell only, so they are the same for all four taps: phase A ballots them into a 32-bit scalar mask and
-// phase B's control flow is scalar (s_bitcmp + s_cbranch, no exec-mask divergence).  Half-wave 0 handles the
-// taps (nw, ne), half-wave 1 (sw, se).
-constexpr int GS = 36;                                   // floats per tile row: conflict-free b128 writes
-constexpr int KP_WAVE_LDS = 32 * GS + 2 * 4 * 32;        // tile + offsets + weights (floats)
-
+// ---- backward: transposed, run-merged scatter (kplanes_scatter.h), one scale after the other ----
 template <int NV>
 __global__ __launch_bounds__(256, 3) void kplanes_bwd_kernel(KpArgs a, const float *__restrict__ x, int64_t x_stride,
                                                           int64_t n, const float *__restrict__ grad_feat)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * KP_WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) float lds[4 * tn::KP_WAVE_LDS];
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
-    float *tileG = lds + (threadIdx.x >> 6) * KP_WAVE_LDS;
-    int *tileO = reinterpret_cast<int *>(tileG + 32 * GS);
-    float *tileW = tileG + 32 * GS + 4 * 32;
+    float *wave_lds = lds + (threadIdx.x >> 6) * tn::KP_WAVE_LDS;
     const int64_t n_tiles = (n + 31) >> 5;
     const int C = a.C, FD = a.n_scales * C;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
@@ -82,108 +66,14 @@ __global__ __launch_bounds__(256, 3) void kplanes_bwd_kernel(KpArgs a, const flo
         const int64_t rr = valid ? row : 0;
         const float xs[3] = {x[rr * x_stride], x[rr * x_stride + 1], x[rr * x_stride + 2]};
         for (int s = 0; s < a.n_scales; ++s) {
-            tn::PlaneTaps t[3];
-            f32x4k val[3][NV];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                float u, v;
-                tn::pair_uv(xs, p, u, v);
-                t[p] = tn::plane_taps(u, v, a.H[s], a.W[s], C);
-                if (a.planes[s][p]) {
-                    tn::plane_gather<NV>(a.planes[s][p], t[p], h * (C / 2), val[p]);
-                    __builtin_amdgcn_sched_barrier(0);      // one plane's 16 loads in flight at a time (register budget)
-                } else {
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
-                }
-            }
             f32x4k g[NV];
 #pragma unroll
             for (int q = 0; q < NV; ++q)
                 g[q] = valid ? reinterpret_cast<const f32x4k *>(grad_feat + row * FD + s * C + h * (C / 2))[q]
                              : f32x4k{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (a.grads[s][p] == nullptr) continue;
-                // ---- phase A: lane = (sample j, channel half h) ----
-#pragma unroll
-                for (int q = 0; q < NV; ++q) {
-                    const f32x4k gp = p == 0 ? g[q] * val[1][q] * val[2][q]
-                                             : (p == 1 ? g[q] * val[0][q] * val[2][q] : g[q] * (val[0][q] * val[1][q]));
-                    *reinterpret_cast<f32x4k *>(tileG + j * GS + h * (C / 2) + 4 * q) = gp;
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {          // this lane publishes taps 2h, 2h+1 of its sample
-                    const int o0 = t[p].off[0 + k], o1 = t[p].off[2 + k];
-                    const float w0 = t[p].w[0 + k], w1 = t[p].w[2 + k];
-                    tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
-                    tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
-                }
-                // run boundaries: sample j closes a run when the next sample falls into another cell.  When the next
-                // cell is a 4-neighbour, two of the four texels are shared with it: instead of flushing them, their
-                // partial sums are carried into the next run (x moves: within the half-wave; y moves: across halves).
-                const int cell = valid ? t[p].cell : -1 - j;
-                const int next_cell = __shfl_down(cell, 1, 64);
-                const int dcell = (j < 31) ? next_cell - cell : 0x40000000;
-                const int rowlen = a.W[s] + 4;
-                const unsigned run_end = (unsigned)__ballot(dcell != 0);                       // low 32 bits: half 0 == half 1
-                const unsigned mv_xp = (unsigned)__ballot(dcell == 1), mv_xm = (unsigned)__ballot(dcell == -1);
-                const unsigned mv_yp = (unsigned)__ballot(dcell == rowlen), mv_ym = (unsigned)__ballot(dcell == -rowlen);
-                asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
-                // ---- phase B: lane = (tap pair h, channel c) ----
-                const int c = j;                       // channel
-                float *gbase = a.grads[s][p] + c;
-                if (c < C) {
-                    const int *O0 = tileO + (2 * h) * 32, *O1 = O0 + 32;
-                    const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
-                    const f32x4k *W1 = W0 + 8;
-                    float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
-                    // (not unrolled: fully unrolled, the 32-sample walk with its five-way run logic made the kernel 12 k
-                    // instructions = 72 KB, more than the instruction cache two CUs share)
-#pragma clang loop unroll(disable)
-                    for (int s4 = 0; s4 < 8; ++s4) {
-                        const f32x4k w0 = W0[s4], w1 = W1[s4];
-                        float gv[4];                   // four samples at a time: 32 at once cost 12 spilled registers
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) gv[u] = tileG[(4 * s4 + u) * GS + c];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int sI = 4 * s4 + u;
-                            a0 = fmaf(gv[u], w0[u], a0);
-                            a1 = fmaf(gv[u], w1[u], a1);
-                            if ((run_end >> sI) & 1u) {          // wave-uniform (scalar) control flow from here on
-                                const int o0 = O0[sI], o1 = O1[sI];
-                                if ((mv_xp >> sI) & 1u) {        // next cell = x+1: right texel becomes the left one
-                                    if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                    a0 = a1; a1 = 0.0f;
-                                } else if ((mv_xm >> sI) & 1u) { // next cell = x-1
-                                    if (o1 >= 0) atomicAdd(gbase + o1, a1);
-                                    a1 = a0; a0 = 0.0f;
-                                } else if ((mv_yp >> sI) & 1u) { // next cell = y+1: the lower row (half 1) becomes the upper row
-                                    const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
-                                    if (h == 0) {
-                                        if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                        if (o1 >= 0) atomicAdd(gbase + o1, a1);
-                                    }
-                                    a0 = h == 0 ? t0 : 0.0f; a1 = h == 0 ? t1 : 0.0f;
-                                } else if ((mv_ym >> sI) & 1u) { // next cell = y-1
-                                    const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
-                                    if (h == 1) {
-                                        if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                        if (o1 >= 0) atomicAdd(gbase + o1, a1);
-                                    }
-                                    a0 = h == 1 ? t0 : 0.0f; a1 = h == 1 ? t1 : 0.0f;
-                                } else {
-                                    if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                    if (o1 >= 0) atomicAdd(gbase + o1, a1);
-                                    a0 = 0.0f; a1 = 0.0f;
-                                }
-                            }
-                        }
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
+            const float *const pl[3] = {a.planes[s][0], a.planes[s][1], a.planes[s][2]};
+            float *const gr[3] = {a.grads[s][0], a.grads[s][1], a.grads[s][2]};
+            tn::kp_scatter_scale<NV, 4>(pl, gr, a.H[s], a.W[s], C, xs, valid, g, h * (C / 2), wave_lds, j, h);
         }
     }
 }

@@ -1,0 +1,133 @@
+// K-Planes backward for ONE scale and one wave's 32 samples: transposed, run-merged scatter (see kplanes.hip for the
+// measurements behind it).  Shared by the stand-alone kernel (kplanes.hip) and by the MLP data-gradient chain, which
+// hands its d(loss)/d(features) registers straight to it (mlp_bwd2.hip, tn_kplanes_mlp_bwd_pair).
+//
+// Measured on MI355X (scripts/microbench/atomic_patterns.hip): a wave64 global_atomic_add_f32 whose lanes hit 64 different
+// cache lines retires ~20 G lane-atomics/s, one whose half-waves each cover the 32 consecutive dwords of ONE line ~270 G/s.
+// The forward mapping (lane = sample) is the slow pattern, so the scatter is transposed through a 5.5 KiB per-wave LDS
+// tile: phase A (lane = sample, channel group) writes the 32x32 tile of d(feat)/d(plane value) plus the 4 tap offsets /
+// weights of every sample; phase B (lane = channel) walks the samples in order -- consecutive samples of a ray fall into
+// the same cell for several steps (a straight line visits the cells of a plane monotonically), so the contributions of a
+// RUN of samples are accumulated in registers and ONE full-line atomic per tap is issued at the end of the run.  Run
+// boundaries depend on the cell only, so they are the same for all four taps: phase A ballots them into a 32-bit scalar
+// mask and phase B's control flow is scalar (s_bitcmp + s_cbranch, no exec-mask divergence).  Half-wave 0 handles the taps
+// (nw, ne), half-wave 1 (sw, se).
+#pragma once
+#include "kplanes_device.h"
+
+namespace tn {
+
+constexpr int KP_GS = 36;                                      // floats per tile row: conflict-free b128 writes
+constexpr int KP_WAVE_LDS = 32 * KP_GS + 2 * 4 * 32;           // tile + offsets + weights (floats)
+
+// lane (j = sample, h): g[q] = d loss / d feature for channels c0 + CS * q .. + 3 of this scale (q < NV), the channel
+// pattern of plane_gather<NV, CS>.  planes / grads: the three [H][W][C] planes of the scale (grads[p] == nullptr: no
+// gradient wanted for that plane).  wave_lds: KP_WAVE_LDS floats private to the wave.
+template <int NV, int CS>
+__device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3], float *const (&grads)[3], int H, int W, int C,
+                                                 const float (&xs)[3], bool valid, const f32x4k (&g)[NV], int c0,
+                                                 float *__restrict__ wave_lds, int j, int h)
+{
+    float *tileG = wave_lds;
+    int *tileO = reinterpret_cast<int *>(tileG + 32 * KP_GS);
+    float *tileW = tileG + 32 * KP_GS + 4 * 32;
+    PlaneTaps t[3];
+    f32x4k val[3][NV];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float u, v;
+        pair_uv(xs, p, u, v);
+        t[p] = plane_taps(u, v, H, W, C);
+        if (planes[p]) {
+            plane_gather<NV, CS>(planes[p], t[p], c0, val[p]);
+            __builtin_amdgcn_sched_barrier(0);      // one plane's 16 loads in flight at a time (register budget)
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (grads[p] == nullptr) continue;
+        // ---- phase A: lane = (sample j, channel group) ----
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const f32x4k gp = p == 0 ? g[q] * val[1][q] * val[2][q]
+                                     : (p == 1 ? g[q] * val[0][q] * val[2][q] : g[q] * (val[0][q] * val[1][q]));
+            *reinterpret_cast<f32x4k *>(tileG + j * KP_GS + c0 + CS * q) = gp;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {          // this lane publishes taps 2h, 2h+1 of its sample
+            const int o0 = t[p].off[0 + k], o1 = t[p].off[2 + k];
+            const float w0 = t[p].w[0 + k], w1 = t[p].w[2 + k];
+            tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
+            tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
+        }
+        // run boundaries: sample j closes a run when the next sample falls into another cell.  When the next
+        // cell is a 4-neighbour, two of the four texels are shared with it: instead of flushing them, their
+        // partial sums are carried into the next run (x moves: within the half-wave; y moves: across halves).
+        const int cell = valid ? t[p].cell : -1 - j;
+        const int next_cell = __shfl_down(cell, 1, 64);
+        const int dcell = (j < 31) ? next_cell - cell : 0x40000000;
+        const int rowlen = W + 4;
+        const unsigned run_end = (unsigned)__ballot(dcell != 0);                       // low 32 bits: half 0 == half 1
+        const unsigned mv_xp = (unsigned)__ballot(dcell == 1), mv_xm = (unsigned)__ballot(dcell == -1);
+        const unsigned mv_yp = (unsigned)__ballot(dcell == rowlen), mv_ym = (unsigned)__ballot(dcell == -rowlen);
+        asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
+        // ---- phase B: lane = (tap pair h, channel c) ----
+        const int c = j;                       // channel
+        float *gbase = grads[p] + c;
+        if (c < C) {
+            const int *O0 = tileO + (2 * h) * 32, *O1 = O0 + 32;
+            const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
+            const f32x4k *W1 = W0 + 8;
+            float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
+            // (not unrolled: fully unrolled, the 32-sample walk with its five-way run logic made the kernel 12 k
+            // instructions = 72 KB, more than the instruction cache two CUs share)
+#pragma clang loop unroll(disable)
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const f32x4k w0 = W0[s4], w1 = W1[s4];
+                float gv[4];                   // four samples at a time: 32 at once cost 12 spilled registers
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gv[u] = tileG[(4 * s4 + u) * KP_GS + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sI = 4 * s4 + u;
+                    a0 = fmaf(gv[u], w0[u], a0);
+                    a1 = fmaf(gv[u], w1[u], a1);
+                    if ((run_end >> sI) & 1u) {          // wave-uniform (scalar) control flow from here on
+                        const int o0 = O0[sI], o1 = O1[sI];
+                        if ((mv_xp >> sI) & 1u) {        // next cell = x+1: right texel becomes the left one
+                            if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                            a0 = a1; a1 = 0.0f;
+                        } else if ((mv_xm >> sI) & 1u) { // next cell = x-1
+                            if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            a1 = a0; a0 = 0.0f;
+                        } else if ((mv_yp >> sI) & 1u) { // next cell = y+1: the lower row (half 1) becomes the upper row
+                            const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
+                            if (h == 0) {
+                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            }
+                            a0 = h == 0 ? t0 : 0.0f; a1 = h == 0 ? t1 : 0.0f;
+                        } else if ((mv_ym >> sI) & 1u) { // next cell = y-1
+                            const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
+                            if (h == 1) {
+                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            }
+                            a0 = h == 1 ? t0 : 0.0f; a1 = h == 1 ? t1 : 0.0f;
+                        } else {
+                            if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                            if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            a0 = 0.0f; a1 = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+}  // namespace tn

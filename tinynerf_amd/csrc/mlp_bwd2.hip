@@ -18,6 +18,7 @@
 //
 // Workspace: (2*NH*H + 4) rows of 128 B per 32 samples (2.06 KB/sample for the K-Planes colour head).
 #include "mlp_stage.h"
+#include "kplanes_scatter.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -57,6 +58,19 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 // sum of both heads instead of written by one launch and read-modified-written by the next.
 struct PairArgs { MlpArgs b; const float *gy; float *stash; };
 
+// KP (with STASHED, PAIR; north star: the K-Planes lookup in the same launch as the MLP, backward half): x is the K-Planes
+// feature row, so d(loss)/d(x) is not an output but an intermediate: every wave keeps the three 32-column blocks of its
+// tile's data gradient in registers and scatters them into the nine plane gradients itself (kplanes_scatter.h) -- the
+// atomics of one wave's scatter travel while the other waves of the SIMD run their MFMA chains, and grad_x is written only
+// if the caller asks for it.
+struct KpBwd {
+    int H[3], W[3];
+    const float *planes[3][3];
+    float *grads[3][3];
+    const float *coords;
+    int64_t coord_stride;
+};
+
 template <int H>
 __device__ __forceinline__ void first_dgrad(const float *__restrict__ Wf, int sf, int out, const float (&gp)[4],
                                             const unsigned (&mask)[H / 32], int h, f32x16 (&G)[H / 32])
@@ -79,11 +93,12 @@ __device__ __forceinline__ void first_dgrad(const float *__restrict__ Wf, int sf
     }
 }
 
-template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false, bool PAIR = false>
+template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false, bool PAIR = false, bool KP = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
-                                                             float *__restrict__ stash, PairArgs pr)
+                                                             float *__restrict__ stash, PairArgs pr, KpBwd kp)
 {
+    static_assert(!KP || (STASHED && PAIR && !ACCUM && H == 64), "the fused scatter belongs to the paired, stashed chain of the width-64 heads");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     constexpr int L = NH + 1;
@@ -343,7 +358,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
 
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
-        if (gx != nullptr && a.enc != TN_ENC_POSENC) {
+        if ((KP || gx != nullptr) && a.enc != TN_ENC_POSENC) {
+            f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
             const int n_kt = (a.in_dim + 31) >> 5;
@@ -396,6 +412,10 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                                 acc = tn::mfma32(W0b[(32 * tn_ + 8 * q + 4 * h + u) * s0b + 32 * kt + j], Gb[tn_][4 * q + u], acc);
                 }
                 tn::pin16(acc);
+                if constexpr (KP) {                 // (uniform branches: kt is a loop counter)
+                    if (kt == 0) gacc[0] = acc; else if (kt == 1) gacc[1] = acc; else gacc[2] = acc;
+                    if (gx == nullptr) continue;
+                }
                 if constexpr (ACCUM) {
                     if (valid) {
 #pragma unroll
@@ -428,6 +448,21 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                                 }
                         }
                     }
+                }
+            }
+            if constexpr (KP) {
+                // ---------------- plane gradients: scatter of this tile's three 32-channel blocks ----------------
+                const float *cr = kp.coords + (valid ? row : 0) * kp.coord_stride;
+                const float xs[3] = {cr[0], cr[1], cr[2]};
+                float *wave_lds = lds + a.lds_floats + pr.b.lds_floats + wave * tn::KP_WAVE_LDS;
+#pragma unroll
+                for (int sc = 0; sc < 3; ++sc) {
+                    tn::f32x4k g4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g4[q] = tn::f32x4k{gacc[sc][4 * q], gacc[sc][4 * q + 1], gacc[sc][4 * q + 2], gacc[sc][4 * q + 3]};
+                    const float *const pl[3] = {kp.planes[sc][0], kp.planes[sc][1], kp.planes[sc][2]};
+                    float *const gr[3] = {kp.grads[sc][0], kp.grads[sc][1], kp.grads[sc][2]};
+                    tn::kp_scatter_scale<4, 8>(pl, gr, kp.H[sc], kp.W[sc], 32, xs, valid, g4, 4 * h, wave_lds, j, h);
                 }
             }
         }
@@ -829,13 +864,48 @@ WgradPlan wgrad_plan(int enc, int in_dim, int K0_pad, int H, int NH) {
 bool v2_supported(const tn_mlp_desc *d) { return two_pass_supported(d); }
 
 // phase bit 0: data-gradient chain, bit 1: weight gradient.  pair != nullptr: the chain also runs head `pair->b`.
+// first layer of a head without its aux columns: the stashed chain only ever reads W_0's x columns (W_0^T G_0 over the x
+// slots), and the 14 KB this saves in LDS are what the fused scatter's per-wave tiles need
+MlpArgs compact_first_layer(const MlpArgs &a)
+{
+    MlpArgs c = a;
+    const int H = a.N[0];
+    c.K0_pad = (a.in_dim + 7) & ~7;
+    int off = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int Kp = l == 0 ? c.K0_pad : H;
+        const int rows = (l == a.n_layers - 1) ? (a.out_dim <= 4 ? a.out_dim : ((a.out_dim + 31) & ~31)) : H;
+        c.stride[l] = Kp + 4;
+        c.w_off[l] = off; off += rows * c.stride[l];
+        c.b_off[l] = off; off += (rows + 3) & ~3;
+    }
+    c.lds_floats = off;
+    return c;
+}
+
 template <int H, int NH>
 int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
               float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s,
-              const PairArgs *pair = nullptr, int phase = 3)
+              const PairArgs *pair = nullptr, int phase = 3, const KpBwd *kpb = nullptr)
 {
     const int64_t n_tiles = (n + 31) / 32;
-    if (phase & 1) {
+    if ((phase & 1) && kpb) {                 // paired, stashed chain with the plane scatter inside
+        if constexpr (H == 64 && NH == 4) {
+            if (!(pair && stashed && a.enc == TN_ENC_AUX_CAT && a.in_dim == 96)) return tn::fail(TN_E_CONFIG, "mlp_bwd: fused scatter needs the paired K-Planes heads");
+            constexpr int WPK = 8;
+            const MlpArgs ac = compact_first_layer(a);
+            PairArgs pr = *pair;
+            pr.b = compact_first_layer(pair->b);
+            const size_t lds_bytes = ((size_t)ac.lds_floats + (size_t)pr.b.lds_floats + (size_t)WPK * tn::KP_WAVE_LDS) * 4;
+            if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights + scatter tiles do not fit LDS");
+            auto kern = mlp_chain_kernel<H, NH, WPK, true, false, true, true>;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+            const int64_t blocks = std::min<int64_t>((n_tiles + WPK - 1) / WPK, 256);
+            kern<<<dim3((unsigned)blocks), dim3(WPK * 64), lds_bytes, s>>>(ac, x, aux, gy, n, gx, stash, pr, *kpb);
+            if (int rc = tn::check_launch("mlp_chain_kernel(kplanes)")) return rc;
+        } else return tn::fail(TN_E_CONFIG, "mlp_bwd: fused scatter is built for the 5-layer colour head");
+    } else if (phase & 1) {
     size_t lds_bytes = (size_t)a.lds_floats * 4;
     constexpr int WPB = 8;
     constexpr int WPS = NH == 1 ? 10 : 16;   // stashed chain: no forward -> ~100 live registers: 4 waves per SIMD, or 2 x 10
@@ -858,7 +928,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));
     const int64_t blocks = std::min<int64_t>((n_tiles + wpb - 1) / wpb, 256 * per_cu);
-    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash, pr);
+    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash, pr, KpBwd());
     if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
     }
     if (!(phase & 2)) return TN_OK;
@@ -913,11 +983,11 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
 template <int H>
 int launch_v2_h(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const float *aux, const float *gy, int64_t n,
                 float *const *gw, float *const *gb, float *gx, float *stash, bool stashed, hipStream_t s,
-                const PairArgs *pair = nullptr, int phase = 3)
+                const PairArgs *pair = nullptr, int phase = 3, const KpBwd *kpb = nullptr)
 {
     // the reference's two decoder shapes (two_pass_supported): one hidden layer (sigma) or four (colour)
-    if (a.n_layers == 2) return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
-    return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase);
+    if (a.n_layers == 2) return launch_v2<H, 1>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase, kpb);
+    return launch_v2<H, 4>(a, d, x, aux, gy, n, gw, gb, gx, stash, stashed, s, pair, phase, kpb);
 }
 
 }  // namespace
@@ -970,11 +1040,11 @@ extern "C" int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *
     return launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, stashed, s);
 }
 
-extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
-                               const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
-                               float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
-                               float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
-                               int64_t partner_workspace_bytes, void *stream)
+static int bwd_pair_common(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
+                           const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
+                           float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
+                           float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                           int64_t partner_workspace_bytes, void *stream, const KpBwd *kpb)
 {
     TN_REQUIRE(desc && partner, TN_E_NULL, "tn_mlp_bwd_pair: null descriptor");
     TN_REQUIRE((desc->flags & TN_MLP_STASHED) && (partner->flags & TN_MLP_STASHED), TN_E_CONFIG,
@@ -987,7 +1057,7 @@ extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partn
     const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
     TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b, TN_E_NULL,
                "tn_mlp_bwd_pair: workspace missing or too small");
-    TN_REQUIRE(x && grad_y && partner_grad_y && grad_x && grad_weights && grad_biases && partner_grad_weights && partner_grad_biases,
+    TN_REQUIRE(x && grad_y && partner_grad_y && (grad_x || kpb) && grad_weights && grad_biases && partner_grad_weights && partner_grad_biases,
                TN_E_NULL, "tn_mlp_bwd_pair: null pointer");
     MlpArgs a, b;
     int H = 0, Hb = 0;
@@ -1004,8 +1074,50 @@ extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partn
     const bool chain = !(desc->flags & TN_MLP_WGRAD_ONLY), wgrad = !(desc->flags & TN_MLP_CHAIN_ONLY);
     TN_REQUIRE(chain || wgrad, TN_E_CONFIG, "tn_mlp_bwd_pair: TN_MLP_CHAIN_ONLY and TN_MLP_WGRAD_ONLY exclude each other");
     if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr,
-                                 (chain ? 1 : 0) | (wgrad ? 2 : 0))) return rc;
+                                 (chain ? 1 : 0) | (wgrad ? 2 : 0), kpb)) return rc;
     if (!wgrad) return TN_OK;
     return launch_v2_h<64>(b, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
                            (float *)partner_workspace, true, s, nullptr, 2);
+}
+
+extern "C" int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
+                               const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
+                               float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
+                               float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
+                               int64_t partner_workspace_bytes, void *stream)
+{
+    return bwd_pair_common(desc, partner, x, aux, grad_y, partner_grad_y, n, grad_weights, grad_biases, partner_grad_weights,
+                           partner_grad_biases, grad_x, workspace, workspace_bytes, partner_workspace, partner_workspace_bytes, stream,
+                           nullptr);
+}
+
+extern "C" int tn_kplanes_mlp_bwd_pair(const tn_kplanes_desc *kd, const float *coords, int64_t coord_stride,
+                                       float *const (*grad_planes)[3], const tn_mlp_desc *desc, const tn_mlp_desc *partner,
+                                       const float *feat, const float *aux, const float *grad_y, const float *partner_grad_y, int64_t n,
+                                       float *const *grad_weights, float *const *grad_biases, float *const *partner_grad_weights,
+                                       float *const *partner_grad_biases, float *grad_feat, void *workspace, int64_t workspace_bytes,
+                                       void *partner_workspace, int64_t partner_workspace_bytes, void *stream)
+{
+    TN_REQUIRE(kd && desc && partner && grad_planes, TN_E_NULL, "tn_kplanes_mlp_bwd_pair: null descriptor");
+    TN_REQUIRE(kd->n_scales == 3 && kd->channels == 32 && desc->in_dim == 96 && partner->in_dim == 96 && desc->encoding == TN_ENC_AUX_CAT,
+               TN_E_CONFIG, "tn_kplanes_mlp_bwd_pair: 3 scales x 32 channels feeding the aux-table colour head and the sigma head (run.py:136-139)");
+    TN_REQUIRE(coord_stride >= 3, TN_E_SIZE, "tn_kplanes_mlp_bwd_pair: bad coordinate stride");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(coords, TN_E_NULL, "tn_kplanes_mlp_bwd_pair: null coordinates");
+    KpBwd kp;
+    for (int s = 0; s < 3; ++s) {
+        TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 31), TN_E_SIZE,
+                   "tn_kplanes_mlp_bwd_pair: bad plane resolution");
+        kp.H[s] = kd->height[s]; kp.W[s] = kd->width[s];
+        for (int p = 0; p < 3; ++p) {
+            TN_REQUIRE(kd->planes[s][p], TN_E_NULL, "tn_kplanes_mlp_bwd_pair: null plane pointer");
+            TN_REQUIRE(((uintptr_t)kd->planes[s][p] & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_bwd_pair: planes must be 16-byte aligned");
+            kp.planes[s][p] = kd->planes[s][p];
+            kp.grads[s][p] = grad_planes[s][p];           // NULL: no gradient for that plane
+        }
+    }
+    kp.coords = coords; kp.coord_stride = coord_stride;
+    return bwd_pair_common(desc, partner, feat, aux, grad_y, partner_grad_y, n, grad_weights, grad_biases, partner_grad_weights,
+                           partner_grad_biases, grad_feat, workspace, workspace_bytes, partner_workspace, partner_workspace_bytes, stream,
+                           &kp);
 }

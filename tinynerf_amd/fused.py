@@ -44,6 +44,7 @@ class Arena:
 
 PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)
 FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
+FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient chain launch (tn_kplanes_mlp_bwd_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
 
 
@@ -199,18 +200,36 @@ class _RenderKPlanes(Function):
             for p in range(3):
                 gp[s][p] = _hwc(g_planes[3 * s + p]).data_ptr()
         scattered = False
+
+        def scatter():
+            L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         if ws_r is not None and ws_s is not None and PAIR_BACKWARD and F % 32 == 0 and ns == 2 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
             # both heads in one data-gradient pass: d/d feat is written once as the sum of the two
             rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED, ray_ids, stride)
             sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_STASHED)
             pair_args = (C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
                          C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
-            if ctx.planes_ready is not None:
+            scatter_fused = FUSE_SCATTER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
+            if scatter_fused:
+                # data gradients of both heads AND the plane scatter in one launch: d loss / d features stays in registers
+                def chain_and_weights(flags):
+                    rdesc.flags = L.MLP_STASHED | flags
+                    L.call("tn_kplanes_mlp_bwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), gp, C.byref(rdesc), C.byref(sdesc),
+                           L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma), C.c_int64(n), gw_r, gb_r, gw_s, gb_s, C.c_void_p(None),
+                           L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+                if ctx.planes_ready is not None:     # N > 1: plane gradients are final after the chain -> their all-reduce starts
+                    chain_and_weights(L.MLP_CHAIN_ONLY)
+                    ctx.planes_ready(g_planes)
+                    chain_and_weights(L.MLP_WGRAD_ONLY)
+                else:
+                    chain_and_weights(0)
+                scattered = True
+            elif ctx.planes_ready is not None:
                 # N > 1: data gradients -> plane scatter -> hand the finished plane gradients to the caller (it starts their
                 # all-reduce) -> weight gradients of the heads, which run while the planes are on the wire
                 rdesc.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
-                L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
+                scatter()
                 scattered = True
                 ctx.planes_ready(g_planes)
                 rdesc.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
@@ -231,7 +250,7 @@ class _RenderKPlanes(Function):
             L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s,
                    L.ptr(g_feat), L.ptr(ws_s), C.c_int64(sb))
         if not scattered:      # plane scatter
-            L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
+            scatter()
         grads = [None if in_place else g for (g, in_place) in bufs]
         return (None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 

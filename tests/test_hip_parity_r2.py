@@ -126,10 +126,14 @@ def _vanilla_renderer(g):
     return r.to(DEV)
 
 
-def test_vanilla_renderer_vs_reference():
+@pytest.mark.parametrize("fused", [True, False])
+def test_vanilla_renderer_vs_reference(fused):
+    """fused: heads + scan + composite as one autograd node, every sample through the colour head (tinynerf_amd.fused);
+    not fused: module by module with the boolean gather of core.py:246-249."""
     from tinynerf_amd import core
     g = load_golden("G14_renderer_vanilla")
     r = _vanilla_renderer(g)
+    r.fused = fused
     packed, info = cu(g["packed"]), cu(g["info"], torch.int32)
     with torch.no_grad():
         sig = r.sigma_decoder(r.feature_module(packed[:, :3])).ravel()
@@ -152,7 +156,8 @@ def test_vanilla_renderer_vs_reference():
 
 
 # ------------------------------------------------------------------------------------------------ G15 (BASELINE config 5)
-def test_config5_sampler_and_renderer_vs_reference():
+@pytest.mark.parametrize("fused", [True, False])
+def test_config5_sampler_and_renderer_vs_reference(fused):
     from tinynerf_amd import core, models as m
     g = load_golden("G15_config5_cobafa_unbounded")
     S = int(g["n_samples"])
@@ -171,6 +176,7 @@ def test_config5_sampler_and_renderer_vs_reference():
     r = core.NerfRenderer(cf, m.VanillaOpacityDecoder(128), m.VanillaColorDecoder(8, 128, 64, 3), None)
     r.load_state_dict(sub(g, "sd."))
     r.to(DEV).eval()                                                                   # Dropout(0.01) off, as in the golden
+    r.fused = fused
     pk, inf_ = cu(g["packed"]), cu(g["info"], torch.int32)
     out = r(pk, inf_)
     np.testing.assert_allclose(out.detach().cpu().numpy(), g["rendered"], rtol=0, atol=TOL)

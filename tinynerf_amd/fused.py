@@ -255,23 +255,153 @@ class _RenderKPlanes(Function):
         return (None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
+class _RenderHeads(Function):
+    """The part of NerfRenderer.forward behind the feature module (core.py:239-267) for ANY field with the Vanilla decoders
+    (Vanilla NeRF, Cobafa): sigma head -> weights scan -> colour head -> composite as one autograd node; ``feat`` is an
+    ordinary differentiable input, so the field's own backward (width-256 / 128 stacks, grid scatters) follows through
+    autograd.  Replaces the module-by-module path's ``mask.any()`` host sync, boolean gather / index_copy pair and their
+    autograd counterparts: every sample goes through the colour head in place -- samples with w == 0 contribute exactly 0 to
+    the composite in both directions, as in the reference (core.py:243-249)."""
+
+    @staticmethod
+    def forward(ctx: Any, feat: torch.Tensor, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
+                freqs: torch.Tensor, n_freqs: int, n_sigma: int, accumulate: bool, arena: Optional[Arena], train: bool,
+                hint: Optional[dict], stats: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+        sig_p = [p.contiguous() for p in params[:n_sigma]]
+        rgb_p = [p.contiguous() for p in params[n_sigma:]]
+        feat = feat.contiguous()
+        dev = L.require_cuda(feat, packed, info, *sig_p, *rgb_p)
+        n, R = packed.size(0), info.size(0)
+        F = feat.size(1)
+        # (the per-ray direction table of the K-Planes node needs the paired weight-gradient tiling, which is sized for 96
+        # features; here cat[PE(d), d] is evaluated per sample inside the colour head's kernels, TN_ENC_DIR_CAT)
+        if hint is not None and hint.get("key") == (packed.data_ptr(), n, R):
+            steps = hint["steps"]
+        else:
+            steps = _alloc(arena, "steps", (n,), dev)
+            steps.copy_(packed[:, 6])
+        table = _alloc(arena, "dirs", (n, 3), dev)
+        table.copy_(packed[:, 3:6])
+        ray_ids, stride = None, 0
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
+        ws_s = ws_r = None
+        sb = rb = 0
+        if train:
+            ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
+            ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
+            if ws_s is None or ws_r is None:
+                raise RuntimeError("tinynerf_amd: these decoder shapes are outside the fused render node (use renderer.fused = False)")
+        sigma = _alloc(arena, "sigma", (n,), dev)
+        rgbs = _alloc(arena, "rgbs", (n, 3), dev)
+        if train:
+            L.call("tn_mlp_fwd_stash", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            L.call("tn_mlp_fwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), C.c_void_p(None))
+        weights = _alloc(arena, "weights", (n,), dev)
+        covered = hint is not None and hint.get("key") == (packed.data_ptr(), n, R)
+        if not covered:
+            weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
+        L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), C.c_int64(n), C.c_int64(R))
+        if train:
+            L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
+        else:              # inference: the colour head is only evaluated where the weight is not 0 (core.py:246-251), tile-wise
+            rdesc.row_gate = weights.data_ptr()
+            L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
+            rdesc.row_gate = None
+        out = torch.empty((R, 3), device=dev)
+        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
+               C.c_int64(n), C.c_int64(R))
+        ctx.gate = weights.amax().reshape(1) if train else None       # "Empty iteration" (core.py:251-254), see _RenderKPlanes
+        if stats is not None:
+            stats["gate"] = ctx.gate
+        ctx.save_for_backward(feat, info, bg, freqs, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
+        ctx.cfg = (n_freqs, n_sigma, accumulate, stride, sb, rb, covered)
+        ctx.arena = arena
+        ctx.param_refs = params if accumulate else None
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, grad_out: torch.Tensor):  # type: ignore
+        feat, info, bg, freqs, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params = ctx.saved_tensors
+        n_freqs, n_sigma, accumulate, stride, sb, rb, covered = ctx.cfg
+        sig_p = [p.contiguous() for p in params[:n_sigma]]
+        rgb_p = [p.contiguous() for p in params[n_sigma:]]
+        dev = feat.device
+        n, R, F = feat.size(0), info.size(0), feat.size(1)
+        g_out = grad_out.contiguous()
+        if ctx.gate is not None:
+            g_out = g_out * (ctx.gate > 0).to(g_out.dtype)
+        refs: Sequence[Optional[torch.Tensor]] = ctx.param_refs if ctx.param_refs is not None else [None] * len(params)
+
+        def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
+            if accumulate and ref is not None and ref.grad is not None and ref.grad.stride() == p.stride():
+                return ref.grad, True
+            return torch.zeros_like(p), False
+        bufs = [grad_buffer(p, r) for p, r in zip(params, refs)]
+        g_sig = [b[0] for b in bufs[:n_sigma]]
+        g_rgb = [b[0] for b in bufs[n_sigma:]]
+        arena = ctx.arena
+        g_rgbs = _alloc(arena, "g_rgbs", (n, 3), dev)
+        g_w = _alloc(arena, "g_w", (n,), dev)
+        if not covered:
+            g_rgbs.zero_(); g_w.zero_()
+        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs), L.ptr(g_w),
+               C.c_int64(n), C.c_int64(R))
+        g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
+        L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
+               C.c_int64(n), C.c_int64(R))
+        g_feat = torch.empty((n, F), device=dev)             # handed to autograd (the field's backward): not an arena view
+        nr, ns = len(rgb_p) // 2, len(sig_p) // 2
+        gw_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[0::2]])
+        gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])
+        gw_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[0::2]])
+        gb_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[1::2]])
+        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED)
+        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw_r, gb_r, L.ptr(g_feat),
+               L.ptr(ws_r), C.c_int64(rb))
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | L.MLP_STASHED)     # g_feat += d sigma / d feat
+        L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s, L.ptr(g_feat),
+               L.ptr(ws_s), C.c_int64(sb))
+        grads = [None if in_place else g for (g, in_place) in bufs]
+        return (g_feat, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+
+
+def _vanilla_decoders(renderer) -> bool:
+    from .models import VanillaColorDecoder, VanillaOpacityDecoder
+    sd, cd = renderer.sigma_decoder, renderer.rgb_decoder
+    return type(sd) is VanillaOpacityDecoder and type(cd) is VanillaColorDecoder and sd.net.net[0].out_features == 64 and \
+        cd.net.net[0].out_features == 64 and len(cd.net.params()) == 10 and sd.net.net[0].in_features % 4 == 0
+
+
 def supports(renderer) -> bool:
-    from .models import KPlanesFeatureField, VanillaColorDecoder, VanillaOpacityDecoder
-    fm, sd, cd = renderer.feature_module, renderer.sigma_decoder, renderer.rgb_decoder
-    return (isinstance(fm, KPlanesFeatureField) and isinstance(sd, VanillaOpacityDecoder) and isinstance(cd, VanillaColorDecoder)
-            and fm.dropout.p == 0.0 and type(sd) is VanillaOpacityDecoder and type(cd) is VanillaColorDecoder)
+    """K-Planes field (whole render as one node, gather / scatter inside the MLP launches) or any other field in front of the
+    Vanilla decoders of run.py:133-134,138-139,149-150 (heads + scan + composite as one node)."""
+    from .models import KPlanesFeatureField
+    fm = renderer.feature_module
+    if not _vanilla_decoders(renderer):
+        return False
+    if isinstance(fm, KPlanesFeatureField):
+        return fm.dropout.p == 0.0
+    return True
 
 
 def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accumulate_into_grad: bool = False) -> torch.Tensor:
-    """Fused forward of ``renderer`` (a NerfRenderer with K-Planes field + Vanilla decoders) on packed samples."""
+    """Fused forward of ``renderer`` on packed samples (see supports())."""
+    from .models import KPlanesFeatureField
     fm, sd, cd = renderer.feature_module, renderer.sigma_decoder, renderer.rgb_decoder
-    planes = fm.plane_tensors()
     sig_p, rgb_p = sd.net.params(), cd.net.params()
     bg = renderer._bg(packed.device)
     arena = None
     if getattr(renderer, "reuse_buffers", False):
         arena = renderer.__dict__.setdefault("_arena", Arena())
-    train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
-    return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
-                                len(sig_p), accumulate_into_grad, arena, train, getattr(renderer, "_batch_aux", None),
-                                renderer.__dict__.setdefault("_stats", {}), *planes, *sig_p, *rgb_p)
+    hint, stats = getattr(renderer, "_batch_aux", None), renderer.__dict__.setdefault("_stats", {})
+    if isinstance(fm, KPlanesFeatureField):
+        planes = fm.plane_tensors()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
+        return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
+                                    len(sig_p), accumulate_into_grad, arena, train, hint, stats, *planes, *sig_p, *rgb_p)
+    feat = fm(packed[:, :3])
+    train = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in (*sig_p, *rgb_p)))
+    return _RenderHeads.apply(feat, packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(sig_p),
+                              accumulate_into_grad, arena, train, hint, stats, *sig_p, *rgb_p)

@@ -34,20 +34,30 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
+PMC_PROFILE = "profiles/round2_pmc_traffic.json"   # scripts/pmc.sh + scripts/pmc_to_json.py (cannot be collected live)
 
 # algorithmic work per unit of the kernels that can dominate
 FLOP_SIGMA_FWD = 2 * (96 * 64 + 64)                                   # 12 416   
 FLOP_RGB_FWD = 2 * (147 * 64 + 3 * 64 * 64 + 64 * 3)                  # 43 776   
+FLOP_HEADS = FLOP_RGB_FWD + FLOP_SIGMA_FWD                            # 56 192
 KERNEL_MODEL = {
-    # entry point            (bound, unit work per row, what a row is)
-    "tn_mlp_bwd:rgb": ("mfma", 2 * FLOP_RGB_FWD, "active sample"),
-    "tn_mlp_bwd:sigma": ("mfma", 2 * FLOP_SIGMA_FWD, "sample"),
-    "tn_mlp_fwd:rgb": ("mfma", FLOP_RGB_FWD, "active sample"),
-    "tn_mlp_fwd:sigma": ("mfma", FLOP_SIGMA_FWD, "sample"),
-    "tn_mlp_bwd_pair": ("mfma", 2 * (FLOP_RGB_FWD + FLOP_SIGMA_FWD), "sample"),     # both heads: data + weight gradients
-    "tn_mlp_fwd_stash_pair": ("mfma", FLOP_RGB_FWD + FLOP_SIGMA_FWD, "sample"),     # both heads' training forward
-    "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample"),            # coords + 36 texel-halves*... + feat row
-    "tn_kplanes_bwd": ("hbm", 12 + 384 + 4608 + 2 * 4608, "sample"),  # + gather again + atomic RMW
+    # timed tag              (bound, unit work per row, what a row is, kernels of the launch)
+    "tn_mlp_bwd:rgb": ("mfma", 2 * FLOP_RGB_FWD, "active sample", "chain + weight-gradient kernels of the colour head"),
+    "tn_mlp_bwd:sigma": ("mfma", 2 * FLOP_SIGMA_FWD, "sample", "chain + weight-gradient kernels of the sigma head"),
+    "tn_mlp_fwd:rgb": ("mfma", FLOP_RGB_FWD, "active sample", "mlp_fwd_kernel"),
+    "tn_mlp_fwd:sigma": ("mfma", FLOP_SIGMA_FWD, "sample", "mlp_fwd_kernel"),
+    "tn_mlp_bwd_pair": ("mfma", 2 * FLOP_HEADS, "sample", "mlp_chain_kernel + mlp_wgrad4_kernel + mlp_wgrad_kernel"),
+    "tn_mlp_fwd_stash_pair": ("mfma", FLOP_HEADS, "sample", "mlp_fwd_kernel (both heads)"),
+    # gather + both heads' training forward in one kernel: MFMA-bound (36 texel lines per sample ride under the MFMAs)
+    "tn_kplanes_mlp_fwd_pair": ("mfma", FLOP_HEADS, "sample", "mlp_fwd_kernel<..., KP> (gather + both heads, one kernel)"),
+    # data-gradient chain of both heads + the scatter into the nine plane gradients in one kernel: bound by the rate of
+    # memory-side fp32 atomics (the lane-atomic count per launch comes from the PMC pass: WRITE_SIZE / 4 B)
+    "tn_kplanes_mlp_bwd_pair:chain": ("atomic", FLOP_HEADS, "sample", "mlp_chain_kernel<..., KP> (both chains + plane scatter, one kernel)"),
+    "tn_kplanes_mlp_bwd_pair:wgrad": ("mfma", FLOP_HEADS, "sample", "mlp_wgrad4_kernel + mlp_wgrad_kernel"),
+    "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample", "kplanes_fwd_kernel"),
+    "tn_kplanes_bwd": ("atomic", 0, "sample", "kplanes_bwd_kernel"),
+    "tn_adam_reg_multi": ("hbm", 32, "plane element", "adam_reg_multi_kernel (p, g, m, v in; p, g, m, v out)"),
 }
 
 
@@ -60,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rates (profiling runs)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 19)
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the first one is the measurement")
     return ap.parse_args()
 
 
@@ -79,11 +90,16 @@ class KernelTimer:
             if name in ("tn_mlp_fwd", "tn_mlp_fwd_stash", "tn_mlp_bwd"):
                 desc = args[0]._obj
                 tag = name.replace("_stash", "") + (":rgb" if desc.encoding in (L.ENC_DIR_CAT, L.ENC_AUX_CAT) else ":sigma")
+            elif name == "tn_kplanes_mlp_bwd_pair":
+                tag = name + (":chain" if args[4]._obj.flags & L.MLP_CHAIN_ONLY else ":wgrad")
             if tag not in KERNEL_MODEL or not timer.enabled:
                 return orig(name, device, *args)
-            n_arg = {"tn_kplanes_fwd": 3, "tn_kplanes_bwd": 3, "tn_mlp_fwd": 3, "tn_mlp_fwd_stash": 3, "tn_mlp_bwd": 4,
-                     "tn_mlp_fwd_stash_pair": 4, "tn_mlp_bwd_pair": 6}[name]
-            rows = int(args[n_arg].value)
+            if name == "tn_adam_reg_multi":
+                rows = sum(int(it.n) for it in args[0])
+            else:
+                n_arg = {"tn_kplanes_fwd": 3, "tn_kplanes_bwd": 3, "tn_mlp_fwd": 3, "tn_mlp_fwd_stash": 3, "tn_mlp_bwd": 4,
+                         "tn_mlp_fwd_stash_pair": 4, "tn_mlp_bwd_pair": 6, "tn_kplanes_mlp_fwd_pair": 6, "tn_kplanes_mlp_bwd_pair": 10}[name]
+                rows = int(args[n_arg].value)
             s = torch.cuda.current_stream(device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
@@ -210,26 +226,32 @@ def main():
 
     for _ in range(args.warmup):
         tr.step()
-    sync()
-    timer.enabled = True
-    samples = 0.0
-    rays_n = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = tr.step()
-        samples += st["n_samples"]
-        rays_n += st["n_rays"]
-    sync()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    stats = torch.tensor([dt, samples, rays_n], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = stats[:1].clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(stats[1:])
-        stats[0] = tmax[0]
-    dt, samples, rays_n = stats.tolist()
+
+    def window(timed: bool):
+        """exactly `steps` steps between barrier + synchronize on both sides; max over ranks, samples summed over ranks"""
+        sync()
+        timer.enabled = timed
+        samples, rays_n = 0.0, 0.0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = tr.step()
+            samples += st["n_samples"]
+            rays_n += st["n_rays"]
+        sync()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        stats = torch.tensor([dt, samples, rays_n], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = stats[:1].clone()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(stats[1:])
+            stats[0] = tmax[0]
+        return stats.tolist()
+
+    dt, samples, rays_n = window(True)            # THE measurement: `value`, `ms_per_step`, kernel events
     loss = tr.loss_value()
+    extra_windows = [window(False) for _ in range(max(0, args.windows - 1))]      # variance only
+    window_ms = [dt / args.steps * 1e3] + [w[0] / args.steps * 1e3 for w in extra_windows]
 
     # stage rates on one batch of the same workload (BASELINE.md: sampler / render fwd / render fwd+bwd)
     stages = None
@@ -281,29 +303,47 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        dom = max(ks, key=lambda t: ks[t]["total_ms"]) if ks else None
-        roof = None
-        if dom:
-            bound, unit_work, unit = KERNEL_MODEL[dom]
-            k = ks[dom]
-            per_launch = unit_work * k["avg_rows"]
+        try:
+            pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        except Exception:
+            pmc = None
+
+        def roofline_of(tag):
+            bound, unit_work, unit, kernels = KERNEL_MODEL[tag]
+            k = ks[tag]
+            sec = k["avg_ms"] * 1e-3
+            traffic = pmc["per_entry"].get(tag) if pmc else None
+            r = {"kernel": tag, "kernels": kernels, "avg_launch_ms": k["avg_ms"], "ms_per_step": k["total_ms"] / args.steps,
+                 "rows_per_launch": k["avg_rows"], "row": unit, "algorithmic_per_row": unit_work, "traffic": traffic,
+                 "traffic_source": PMC_PROFILE if traffic is not None else None}
+            tflops = unit_work * k["avg_rows"] / sec / 1e12 if bound in ("mfma", "atomic") and unit_work else None
             if bound == "mfma":
-                achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
-            else:
-                achieved = per_launch / (k["avg_ms"] * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-            roof.update(kernel=dom, avg_launch_ms=k["avg_ms"], rows_per_launch=k["avg_rows"], row=unit,
-                        algorithmic_per_row=unit_work)
-            # HBM-side bytes per launch from the committed PMC passes (scripts/pmc.sh); they cannot be collected live
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_v12.json")))
-                roof["traffic"] = pmc["per_entry"].get(dom)
-                roof["traffic_source"] = "profiles/round1_pmc_traffic_v12.json"
-            except Exception:
-                pass
+                r.update(bound="mfma", achieved=tflops, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=tflops / PEAK_FP32_MFMA_TFLOPS)
+            elif bound == "hbm":
+                gbs = unit_work * k["avg_rows"] / sec / 1e9
+                r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS)
+            else:       # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
+                lanes = pmc["lane_atomics_per_entry"].get(tag) if pmc else None
+                ach = lanes / sec / 1e9 if lanes else None
+                r.update(bound="atomic", achieved=ach, peak=PEAK_ATOMIC_GLANES, unit="G lane-atomics/s",
+                         frac=ach / PEAK_ATOMIC_GLANES if ach else None, lane_atomics_per_launch=lanes,
+                         mfma_tflops=tflops, mfma_frac=tflops / PEAK_FP32_MFMA_TFLOPS if tflops else None)
+            if traffic is not None:
+                r["hbm_gbs"] = traffic / sec / 1e9
+            return r
+
+        step_ms = dt / args.steps * 1e3
+        # every timed launch that is >= 5 % of the step, largest first; `roofline` = the dominant one
+        roofs = [roofline_of(t) for t in sorted(ks, key=lambda t: -ks[t]["total_ms"]) if ks[t]["total_ms"] / args.steps >= 0.05 * step_ms]
+        roof = roofs[0] if roofs else None
+        per_gpu_samples = samples / args.steps / world
+        whole = {"mfma_tflops": 3 * FLOP_HEADS * per_gpu_samples / (step_ms * 1e-3) / 1e12,
+                 "mfma_frac": 3 * FLOP_HEADS * per_gpu_samples / (step_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                 "note": "algorithmic FLOP of both heads, forward + data gradient + weight gradient (3 x 56 192 per sample), over the whole step"}
+        if pmc and pmc.get("bytes_per_step"):
+            whole.update(hbm_bytes_per_step=pmc["bytes_per_step"], hbm_gbs=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9,
+                         hbm_frac=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, hbm_source=PMC_PROFILE)
+        srt = sorted(window_ms)
         line = {
             "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -317,8 +357,12 @@ def main():
             "loss": loss,
             "stages": stages,
             "other_configs": others,
+            "windows": {"n": len(window_ms), "steps_each": args.steps, "ms_per_step": window_ms, "min": srt[0], "median": srt[len(srt) // 2],
+                        "note": "window 0 is the measurement (value, ms_per_step, kernel events); the others show the spread"},
             "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
             "roofline": roof,
+            "rooflines": roofs,
+            "whole_step": whole,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.cpu_samples)

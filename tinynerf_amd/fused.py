@@ -217,12 +217,13 @@ class _RenderKPlanes(Function):
                     L.call("tn_kplanes_mlp_bwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), gp, C.byref(rdesc), C.byref(sdesc),
                            L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma), C.c_int64(n), gw_r, gb_r, gw_s, gb_s, C.c_void_p(None),
                            L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
-                if ctx.planes_ready is not None:     # N > 1: plane gradients are final after the chain -> their all-reduce starts
-                    chain_and_weights(L.MLP_CHAIN_ONLY)
+                # two calls (chain + scatter kernel, then the weight-gradient kernels): the same launches as one call makes, but the
+                # plane gradients are final in between -- with N > 1 their all-reduce starts there and travels under the
+                # weight-gradient kernels -- and each half can be timed on its own (bench.py)
+                chain_and_weights(L.MLP_CHAIN_ONLY)
+                if ctx.planes_ready is not None:
                     ctx.planes_ready(g_planes)
-                    chain_and_weights(L.MLP_WGRAD_ONLY)
-                else:
-                    chain_and_weights(0)
+                chain_and_weights(L.MLP_WGRAD_ONLY)
                 scattered = True
             elif ctx.planes_ready is not None:
                 # N > 1: data gradients -> plane scatter -> hand the finished plane gradients to the caller (it starts their

@@ -34,37 +34,42 @@ def _matches(got, ref, keys, rel) -> bool:
         return False
 
 
-def assert_grads_match_up_to_relu_ties(got: Dict[str, np.ndarray], compute_ref: Callable[[], Dict[str, np.ndarray]], rel: float,
-                                       eps: float = 2e-6, max_flips: int = 48) -> int:
+def assert_grads_match_up_to_relu_ties(got: Dict[str, np.ndarray], compute_ref: Callable[[], Dict[str, np.ndarray]], rel,
+                                       eps: float = 2e-6, max_flips: int = 48, weights_conditioning: bool = False) -> int:
     """``compute_ref()`` evaluates the reference gradients through oracle/torch_port.mlp (on any device) and returns
     {name: array}.  |got - ref| <= rel * max|ref| per tensor (``rel``: one number or {name: number}) for some assignment of the tie units (|pre| <= eps * sum |terms|;
     the rounding error of an fp32 dot product of K <= 307 terms is ~sqrt(K) * 6e-8 = 1e-6 of that sum).  Returns the number of
     tie units that had to be flipped."""
+    if weights_conditioning:
+        # render-level fixtures: the reference's fp32 weights backward (cuda.cu:49-56) is itself only this close to an exact
+        # evaluation of its formula (oracle/torch_port.weights_conditioning); no other fp32 order can be held to less
+        cond = tp.weights_conditioning(compute_ref)
+        rel = {k: max(rel[k] if isinstance(rel, dict) else rel, 4.0 * c) for k, c in cond.items()}
     with tp.ReluControl(eps) as ctrl:
         base = compute_ref()
     keys = sorted(base)
-    if _matches(got, base, keys, rel):
+
+    def tol(k, ref):
+        return (rel[k] if isinstance(rel, dict) else rel) * max(float(np.abs(np.asarray(ref[k])).max()), 1e-30)
+
+    def score(ref):          # worst violation in units of the tolerance; <= 1 passes
+        return max(float(np.abs(np.asarray(got[k], np.float64) - np.asarray(ref[k], np.float64)).max()) / tol(k, base) for k in keys)
+    if score(base) <= 1.0:
         return 0
     ties = sorted(dict.fromkeys(ctrl.found), key=lambda t: ctrl.state[t][1])[:max_flips]
-    if not ties:
-        _check(got, base, keys, rel, "no tie unit in the reference")
     cur = {k: np.asarray(v, np.float64).copy() for k, v in base.items()}
-    b, g = _flat(base, keys), _flat(got, keys)
     flips = {}
-    for t in ties:
+    for t in ties:           # a flip is kept when it brings the reference closer to `got`
         with tp.ReluControl(eps, force={t: not ctrl.state[t][0]}):
             alt = compute_ref()
-        d = _flat(alt, keys) - b
-        if not np.any(d):
-            continue
-        if float(np.dot(g - _flat(cur, keys), d) / np.dot(d, d)) > 0.5:
-            flips[t] = not ctrl.state[t][0]
-            for k in keys:
-                cur[k] += np.asarray(alt[k], np.float64) - np.asarray(base[k], np.float64)
-            if _matches(got, cur, keys, rel):
+        cand = {k: cur[k] + (np.asarray(alt[k], np.float64) - np.asarray(base[k], np.float64)) for k in keys}
+        if score(cand) < score(cur):
+            cur, flips[t] = cand, not ctrl.state[t][0]
+            if score(cur) <= 1.0:
                 break
     if len(flips) > 1:                      # several flips: evaluate them together (exact, not the first-order sum)
         with tp.ReluControl(eps, force=flips):
             cur = compute_ref()
-    _check(got, cur, keys, rel, f"{len(flips)} of {len(ties)} tie units flipped: {sorted(flips)}")
+    _check(got, cur, keys, {k: tol(k, base) / max(float(np.abs(np.asarray(cur[k])).max()), 1e-30) for k in keys},
+           f"{len(flips)} of {len(ties)} tie units flipped: {sorted(flips)}")
     return len(flips)

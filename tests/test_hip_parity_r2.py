@@ -152,7 +152,7 @@ def test_vanilla_renderer_vs_reference(fused):
     def ref():                                                                    # the CPU port, pinned to G14 by tests/test_oracle_golden_r2.py
         return tp.grads_of(sd, lambda p: torch.nn.functional.mse_loss(tp.render(p, pk, inf_, bg, vanilla_freqs=10), target))[0]
     # ten 256-wide layers deep, every one with its own fp32 summation order: 1e-4 of each tensor's largest element
-    assert_grads_match_up_to_relu_ties(got, ref, 1e-4)
+    assert_grads_match_up_to_relu_ties(got, ref, 1e-4, weights_conditioning=True)
 
 
 # ------------------------------------------------------------------------------------------------ G15 (BASELINE config 5)

@@ -40,10 +40,17 @@ def test_renderer_forward_backward_vs_reference(fused):
     loss = torch.nn.functional.mse_loss(out, cu(g["target"]))
     np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
     loss.backward()
-    for name, p in r.named_parameters():
-        ref = g["grad." + name]
-        assert p.grad is not None and p.grad.shape == ref.shape, name
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(ref).max() / 1e-2), err_msg=name)
+    got = {name: p.grad.cpu().numpy() for name, p in r.named_parameters()}
+    for name, v in got.items():
+        assert v.shape == g["grad." + name].shape, name
+    # against the CPU port (pinned to G9 by tests/test_oracle_torch_port.py): 5e-5 of each tensor's largest element (a plane
+    # texel sums ~100 atomics in arbitrary order behind a 4-layer chain), up to the state of fp32-tie ReLU units
+    from _ties import assert_grads_match_up_to_relu_ties
+    from oracle import torch_port as tp
+    sd = {k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("sd.")}
+    pk, inf_, bgc, tgt = torch.as_tensor(g["packed"]), torch.as_tensor(g["info"]), torch.as_tensor(g["bg"]), torch.as_tensor(g["target"])
+    assert_grads_match_up_to_relu_ties(got, lambda: tp.grads_of(sd, lambda p: torch.nn.functional.mse_loss(tp.render(p, pk, inf_, bgc), tgt))[0], 5e-5,
+                                       weights_conditioning=True)     # 83 % of this fixture's samples sit behind a terminated ray: sigma head 3e-4
     # no background colour
     out2 = build_renderer(g, bg=False)(packed, info)
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["rendered_nobg"], rtol=0, atol=TOL)
@@ -88,8 +95,11 @@ def test_fused_accumulates_into_existing_grads():
     for _ in range(2):
         torch.nn.functional.mse_loss(r(packed, info), target).backward()
     for name, p in r.named_parameters():
-        ref = 2 * g["grad." + name]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * max(1.0, np.abs(ref).max() / 1e-2), err_msg=name)
+        ref = 2 * g["grad." + name]        # (the tie-aware comparison of this fixture is test_renderer_forward_backward_vs_reference;
+        # here only "twice one step": 1e-4 of the largest element per tensor, 2e-3 for the sigma head, whose gradient the
+        # reference's own fp32 weights backward only determines to 3e-4 on this fixture)
+        tol = 2e-3 if name.startswith("sigma_decoder") else 1e-4
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=tol * float(np.abs(ref).max()), err_msg=name)
 
 
 @pytest.mark.parametrize("n_rays,per_ray", [(37, 29), (300, 113)])

@@ -197,7 +197,7 @@ def test_config5_sampler_and_renderer_vs_reference(fused):
     assert cond["rgb_decoder.net.net.0.weight"] == 0.0 and cond["sigma_decoder.net.net.2.bias"] > 1e-3
     assert_grads_match_up_to_relu_ties(got, ref, {k: max(2e-5, 4.0 * c) for k, c in cond.items()})
     # the same composition where the reference is well conditioned: thin medium (sigma bias - 4: no ray terminates),
-    # every tensor to <= 5e-5 against the CPU port
+    # every tensor to 2e-5 ... 4 x its (small) conditioning against the CPU port
     sd2 = dict(sd)
     sd2["sigma_decoder.net.net.2.bias"] = sd["sigma_decoder.net.net.2.bias"] - 4.0
     r.load_state_dict(sd2)
@@ -208,7 +208,7 @@ def test_config5_sampler_and_renderer_vs_reference(fused):
     def ref2():
         return tp.grads_of(sd2, lambda p: torch.nn.functional.mse_loss(tp.render(p, pc, ic, None, cobafa_freqs=freqs), target))[0]
     cond2 = tp.weights_conditioning(ref2)
-    assert max(cond2.values()) < 2e-5
+    assert max(cond2.values()) < 1e-4
     assert_grads_match_up_to_relu_ties(got2, ref2, {k: max(2e-5, 4.0 * c) for k, c in cond2.items()})
 
 

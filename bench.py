@@ -178,8 +178,11 @@ def launch_ranks(args) -> int:
         sys.stderr.write(f"bench.py --gpus {n}: rank exit codes {codes}\n")
         sys.stdout.write(out or "")
         return 1
-    sys.stdout.write(out)
-    return 0
+    # exactly one line on stdout: rank 0's JSON (a backend may chat on stdout, e.g. gloo's "[Gloo] Rank 0 is connected ...")
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    sys.stderr.write("".join(ln + "\n" for ln in (out or "").splitlines() if not ln.startswith("{")))
+    sys.stdout.write(lines[-1] + "\n" if lines else "")
+    return 0 if lines else 1
 
 
 def main():

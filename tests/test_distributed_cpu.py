@@ -14,10 +14,16 @@ def _free_port():
 
 
 class _Stub:
-    """the two attributes Trainer.all_reduce_grads / global_mse read"""
+    """what Trainer.all_reduce_grads / _planes_ready / global_mse read"""
     def __init__(self, renderer, world):
+        from tinynerf_amd.run import Trainer
         self.renderer, self.world, self.device = renderer, world, torch.device("cpu")
         self._early = {}
+        # K-Planes row restriction of the exchange (Trainer._refresh_reduce_rows): plane 0 = `renderer.plane`, only rows 16..99
+        # can carry a gradient this step, rows 10..79 could in the step before: the union travels
+        self._plane_of = {id(renderer.plane): 0}
+        self._reduce_rows, self._reduce_rows_prev = [(16, 100)], [(10, 80)]
+        self._reduce_view = lambda g, plane: Trainer._reduce_view(self, g, plane)
 
 
 def _make_model():
@@ -41,16 +47,20 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     rendered_in = torch.rand(n, 96, generator=g)
     target = torch.rand(n, 3, generator=g)
-    rendered = m.head(torch.relu(m.lin(rendered_in))).expand(n, 3) * m.plane[0, :3, 0, 0] + m.grid[0, :3, 1, 2, 3] * rendered_in[:, :3]
+    rendered = m.head(torch.relu(m.lin(rendered_in))).expand(n, 3) * m.plane[0, :3, 40, 7] + m.grid[0, :3, 1, 2, 3] * rendered_in[:, :3]
     loss = Trainer.global_mse(stub, rendered, target)
     for p in m.parameters():
         p.grad = torch.zeros_like(p)
     loss.backward()
+    with torch.no_grad():
+        m.plane.grad[:, :, :10] = 0; m.plane.grad[:, :, 100:] = 0     # outside the live rows the gradient is zero on every rank
     assert m.plane.grad.is_contiguous(memory_format=torch.channels_last)
     assert m.grid.grad.is_contiguous(memory_format=torch.channels_last_3d) and not m.grid.grad.is_contiguous()
     for g in (m.plane.grad, m.grid.grad):                 # the exchange works on the parameter's own memory, no copies
         v = Trainer._dense_view(g)
         assert v is not None and v.is_contiguous() and v.data_ptr() == g.data_ptr() and v.numel() == g.numel()
+    view = Trainer._reduce_view(stub, m.plane.grad, 0)
+    assert view.shape == (1, 90, 128, 32) and view.is_contiguous() and view.data_ptr() == m.plane.grad[:, :, 10:].data_ptr()
     Trainer._planes_ready(stub, [m.plane.grad])          # the fused node starts the plane all-reduces mid-backward
     assert len(stub._early) == 1
     Trainer.all_reduce_grads(stub)                        # ... which are awaited here, everything else is reduced now
@@ -78,9 +88,11 @@ def test_two_rank_gradient_exchange_equals_single_process():
         g = torch.Generator().manual_seed(100 + rank)
         ins.append(torch.rand(n, 96, generator=g)); tgts.append(torch.rand(n, 3, generator=g))
     x, t = torch.cat(ins), torch.cat(tgts)
-    rendered = m.head(torch.relu(m.lin(x))).expand(x.size(0), 3) * m.plane[0, :3, 0, 0] + m.grid[0, :3, 1, 2, 3] * x[:, :3]
+    rendered = m.head(torch.relu(m.lin(x))).expand(x.size(0), 3) * m.plane[0, :3, 40, 7] + m.grid[0, :3, 1, 2, 3] * x[:, :3]
     loss = torch.nn.functional.mse_loss(rendered, t)
     loss.backward()
+    with torch.no_grad():
+        m.plane.grad[:, :, :10] = 0; m.plane.grad[:, :, 100:] = 0
     assert abs(res[0][1] + res[1][1] - float(loss)) < 1e-6          # local losses sum to the global mean
     for k, p in m.named_parameters():
         for rank in range(2):                                        # every rank holds the full-batch gradient

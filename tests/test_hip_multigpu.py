@@ -105,6 +105,20 @@ def _cfg(method):
 N_STEPS = 3
 
 
+def _half_empty_grid(tr):
+    """an occupancy grid with empty borders and no refresh during the test: the plane-gradient exchange of the 2-rank run is then
+    restricted to the live rows (Trainer._refresh_reduce_rows), and must still equal the 1-rank result everywhere"""
+    g = tr.occupancy_grid
+    g.grid.zero_()
+    g.grid[6:22, 9:27, 4:30] = 1.0
+    g.mean = float(g.grid.mean().item())
+    tr.occupancy_grid_updates = 10 ** 9
+    tr.train_step = 1
+    tr._refresh_reduce_rows(); tr._refresh_reduce_rows()
+    if tr.world > 1 and tr._plane_of:
+        assert all(r1 - r0 < p.size(2) for (r0, r1), p in zip(tr._reduce_rows, tr.renderer.feature_module.plane_tensors()))
+
+
 def _no_dropout(tr):
     """Cobafa's Dropout(0.01) (models.py:250) draws from the process RNG: switched off so that 2 ranks and 1 rank see the same function"""
     drop = getattr(tr.renderer.feature_module, "dropout", None)
@@ -115,7 +129,7 @@ def _no_dropout(tr):
 def _grads(t):
     """every reduced gradient on step 0; later steps skip the multi-million-element grids (queue traffic), keep all the rest"""
     return {k: p.grad.detach().cpu().contiguous().numpy().copy() for k, p in t.renderer.named_parameters()
-            if t.train_step == 0 or p.numel() < (1 << 20)}          # numpy: pickled through the queue, no shared-memory handles
+            if t.train_step == 1 or p.numel() < (1 << 20)}          # numpy: pickled through the queue, no shared-memory handles
 
 
 def _rank_main(rank, world, port, method, q):
@@ -129,6 +143,7 @@ def _rank_main(rank, world, port, method, q):
     tr = Trainer(_cfg(method), o[half].to(dev), d[half].to(dev), rgb[half].to(dev), torch.ones(3, device=dev), dev, rank=rank,
                  world_size=world)
     _no_dropout(tr)
+    _half_empty_grid(tr)
     cap = {}
     tr.grad_hook = lambda t: cap.__setitem__("g", _grads(t))
     early_calls = [0]
@@ -168,6 +183,7 @@ def test_two_ranks_equal_one_rank_on_the_union(method):
     o, d, rgb = _scene()
     tr = Trainer(_cfg(method), o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev)
     _no_dropout(tr)
+    _half_empty_grid(tr)
     cap = {}
     tr.grad_hook = lambda t: cap.__setitem__("g", _grads(t))
     for step in range(N_STEPS):
@@ -182,12 +198,23 @@ def test_two_ranks_equal_one_rank_on_the_union(method):
         assert packed.size(0) == res[0][step]["n_samples"] + res[1][step]["n_samples"]
         tr.step_on_batch(packed, info, tu, prefetch=False)
         loss = tr.loss_value()
-        tol = 2e-5 if step == 0 else 2e-3                          # later steps: Adam (eps 1e-15) amplifies summation-order noise
+        # first step: the same per-sample arithmetic on both sides, summed by atomics in another order (a grid voxel of the
+        # half-empty scene collects thousands of terms: 1e-4 of the largest element); later steps: Adam (eps 1e-15) amplifies it
+        tol = 1e-4 if step == 0 else 2e-3
         for rank in range(2):
             r = res[rank][step]
             assert abs(r["loss"] - loss) <= tol * abs(loss), (step, rank, r["loss"], loss)
             for k, ref in cap["g"].items():
-                np.testing.assert_allclose(r["grads"][k], ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
+                got = r["grads"][k]
+                if ref.size >= (1 << 16):
+                    # a grid voxel / plane texel sums thousands of atomics whose terms cancel (+-1e-3 summing to 1e-4): single
+                    # elements carry 1e-4 of the largest element as order noise, and from the second step on Adam (eps 1e-15)
+                    # turns that noise into full-size updates of the elements it hits; the tensor as a whole must agree to
+                    # 2e-5 on the first step and to 5e-3 afterwards
+                    assert float(np.linalg.norm((got - ref).astype(np.float64))) <= (2e-5 if step == 0 else 5e-3) * float(np.linalg.norm(ref.astype(np.float64))), (k, step)
+                    np.testing.assert_allclose(got, ref, rtol=0, atol=(5e-3 if step == 0 else 5e-2) * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
+                else:
+                    np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
             if step == 0:
                 assert np.array_equal(r["grid"], tr.occupancy_grid.grid.cpu().numpy())      # identical grids without communication
         assert np.array_equal(res[0][step]["grid"], res[1][step]["grid"])

@@ -117,6 +117,12 @@ class Trainer:
         self.grad_hook: Optional[Callable[["Trainer"], None]] = None   # called with the final (reduced) gradients, before Adam
         self._early: Dict[int, object] = {}              # all-reduces started during the backward pass (N > 1)
         self._pending: Optional[dict] = None             # sampler pass of the next step, already in flight
+        # N > 1, K-Planes: rows of every plane that can receive a gradient at all (see _refresh_reduce_rows)
+        self._plane_of: Dict[int, int] = {}
+        self._reduce_rows: Optional[List[Tuple[int, int]]] = None
+        self._reduce_rows_prev: Optional[List[Tuple[int, int]]] = None
+        if world_size > 1 and isinstance(self.renderer.feature_module, KPlanesFeatureField):
+            self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
         self._plan_host: Optional[torch.Tensor] = None
         self.prefetch = True
 
@@ -214,6 +220,7 @@ class Trainer:
                 jit = torch.full((r, r, r, 3), 0.5, device=self.device)
             # same jitter on every rank (identical grids without communication); a dedicated seed, not the global RNG
             self.occupancy_grid.update(self.sigma_fn, jitters=jit, seed=(cfg.seed * 7919 + 104729 * (self.train_step + 1)) % (2 ** 62))
+            self._refresh_reduce_rows()
         rendered = self.renderer(packed, info)                                    # run.py:251
         if self.prefetch if prefetch is None else prefetch:
             self._launch_plan()            # next step's sampler pass runs between this forward and backward
@@ -297,28 +304,73 @@ class Trainer:
         v = g.permute(order)
         return v if v.is_contiguous() else None
 
+    @torch.no_grad()
+    def _refresh_reduce_rows(self) -> None:
+        """N > 1, K-Planes: the image-loss gradient of a plane is exactly zero outside the rows its samples can touch, and
+        samples only exist where the trilinear occupancy lookup passes -- next to a grid node above the threshold.  The grids
+        are identical on all ranks (same parameters, same jitter seed), so every rank derives the same row range per plane
+        from the node range along the plane's v axis (+- one node, +- one texel row) and the all-reduce moves only those rows
+        (contiguous in the channel-last layout): for a scene that fills the middle half of the box, half of the 126 MiB.  The
+        batch of the step that refreshes the grid was still sampled with the previous grid: the union of both ranges is used.
+        One 6-integer read-back per refresh (every 16 * 4096 / B steps)."""
+        if not self._plane_of:
+            return
+        g = self.occupancy_grid
+        occ = g.grid > g.threshold                                   # [D, H, W] <-> (z, y, x)
+        lo_hi = []
+        for keep in (2, 1, 0):                                       # x, y, z: reduce over the other two dimensions
+            line = occ.amax(dim=tuple(d for d in range(3) if d != keep)).to(torch.int32)
+            idx = torch.arange(line.numel(), device=line.device, dtype=torch.int32)
+            big = line.numel() + 1
+            lo_hi += [torch.where(line > 0, idx, torch.full_like(idx, big)).amin(), torch.where(line > 0, idx, torch.full_like(idx, -1)).amax()]
+        vals = torch.stack(lo_hi).tolist()
+        dims = (g.grid.size(2), g.grid.size(1), g.grid.size(0))      # nodes along x, y, z
+        rows: List[Tuple[int, int]] = []
+        for i, p in enumerate(self.renderer.feature_module.plane_tensors()):
+            axis = (1, 2, 2)[i % 3]                                  # v axis of plane (x,y), (x,z), (y,z): models.py:144-146
+            i0, i1, S, Hp = vals[2 * axis], vals[2 * axis + 1], dims[axis], p.size(2)
+            if i1 < 0:
+                rows.append((0, 0))
+                continue
+            v_lo = max(-1.0, -1.0 + 2.0 * (i0 - 1) / max(S - 1, 1)); v_hi = min(1.0, -1.0 + 2.0 * (i1 + 1) / max(S - 1, 1))
+            r0 = int(math.floor((v_lo + 1.0) * 0.5 * (Hp - 1))) - 1
+            r1 = int(math.floor((v_hi + 1.0) * 0.5 * (Hp - 1))) + 3
+            rows.append((max(0, r0), min(Hp, r1)))
+        prev = self._reduce_rows if self._reduce_rows is not None else [(0, p.size(2)) for p in self.renderer.feature_module.plane_tensors()]
+        self._reduce_rows_prev, self._reduce_rows = prev, rows
+
+    def _reduce_view(self, g: torch.Tensor, plane: Optional[int]) -> Optional[torch.Tensor]:
+        """the part of gradient `g` that has to travel: all of it, or -- for K-Planes plane number `plane` -- its live rows"""
+        flat = Trainer._dense_view(g) if g.numel() >= (1 << 18) else None
+        if flat is None or plane is None or self._reduce_rows is None or flat.dim() != 4 or not g.is_contiguous(memory_format=torch.channels_last):
+            return flat
+        (a0, a1), (b0, b1) = self._reduce_rows[plane], self._reduce_rows_prev[plane]
+        r0, r1 = (min(a0, b0), max(a1, b1)) if a1 > a0 and b1 > b0 else ((a0, a1) if a1 > a0 else (b0, b1))
+        return flat[:, r0:r1] if r1 > r0 else flat[:, :0]            # flat: [1, H, W, C] in memory order
+
     def _planes_ready(self, grads) -> None:
         """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are
         final: their all-reduces start here and travel while the heads' weight gradients are still being computed."""
-        for g in grads:
-            flat = Trainer._dense_view(g) if g.numel() >= (1 << 18) else None
+        for i, g in enumerate(grads):
+            flat = self._reduce_view(g, i if self._plane_of else None)
             if flat is not None:
-                self._early[g.data_ptr()] = torch.distributed.all_reduce(flat, async_op=True)
+                self._early[g.data_ptr()] = torch.distributed.all_reduce(flat, async_op=True) if flat.numel() else None
 
     def all_reduce_grads(self) -> None:
         """Sum gradients over ranks with RCCL.  Large plane gradients go as individual in-place all-reduces
         (each drives all xGMI peers; started early by ``_planes_ready`` when the fused path is in use); everything
         small is packed into one bucket."""
-        small, handles = [], list(self._early.values())
+        small, handles = [], [h for h in self._early.values() if h is not None]
         early, self._early = self._early, {}
         for p in self.renderer.parameters():
             if p.grad is None:
                 continue
             if p.grad.data_ptr() in early:
                 continue
-            flat = Trainer._dense_view(p.grad) if p.grad.numel() >= (1 << 18) else None
-            if flat is not None:                 # large and dense in memory: its own in-place all-reduce
-                handles.append(torch.distributed.all_reduce(flat, async_op=True))
+            flat = self._reduce_view(p.grad, self._plane_of.get(id(p)))
+            if flat is not None:                 # large and dense in memory: its own in-place all-reduce (live rows only)
+                if flat.numel():
+                    handles.append(torch.distributed.all_reduce(flat, async_op=True))
             else:
                 small.append(p.grad)
         if small:

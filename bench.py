@@ -203,6 +203,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")      # RCCL's stream ahead of the weight-gradient kernels it overlaps
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:

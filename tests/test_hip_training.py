@@ -97,6 +97,41 @@ def test_kplanes_training_matches_cpu_port():
     assert p_late > p_init + 3.0, (p_init, p_late)
 
 
+def test_kplanes_full_resolution_training_matches_cpu_port():
+    """BASELINE config 3's model as trained (128 / 256 / 512 planes, 33 M parameters, fused gather / scatter launches, TV folded
+    into Adam on channel-last planes) against the CPU port of train(): per-step loss, batch structure, and PSNR at equal step
+    count within 0.1 dB (north star)."""
+    from tinynerf_amd.run import TrainConfig, Trainer, psnr
+    from oracle import tinynerf_oracle as orc
+    o, d, rgb = _scene()
+    n_steps = 8
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=256, n_samples=32, seed=6, occupancy_res=32, deterministic=True)
+    tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+    assert tr.renderer.feature_module.planes[2][0].plane.shape == (1, 32, 512, 512)
+    sd0 = {k: v.detach().cpu().contiguous().clone() for k, v in tr.renderer.state_dict().items()}
+    ref_losses, ref_sd, ref_counts = tp.reference_training(sd0, o.numpy(), d.numpy(), rgb.numpy(), method="kplanes", batch_size=256,
+                                                           n_samples=32, n_steps=n_steps, occupancy_res=32)
+    losses, counts = [], []
+    for _ in range(n_steps):
+        st = tr.step()
+        losses.append(tr.loss_value())
+        counts.append((int(st["n_samples"]), int(st["n_rays"])))
+    assert counts[0] == ref_counts[0]
+    np.testing.assert_allclose(losses[0], ref_losses[0], rtol=1e-5)
+    np.testing.assert_allclose(losses, ref_losses, rtol=3e-2)
+    test_idx = torch.arange(0, o.size(0), 5)
+    with torch.no_grad():
+        img = tr.render_rays(o[test_idx].to(DEV), d[test_idx].to(DEV), batch_size=1024).cpu()
+    aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
+    packed, info = orc.ray_provider(o[test_idx].numpy(), d[test_idx].numpy(), marcher="aabb", contraction="aabb",
+                                    grid=tr.occupancy_grid.grid.cpu().numpy(), threshold=tr.occupancy_grid.threshold,
+                                    n_samples=32, near=0.1, aabb=aabb)
+    with torch.no_grad():
+        img_ref = tp.render(ref_sd, torch.from_numpy(packed), torch.from_numpy(info), torch.ones(3))
+    p_hip, p_ref = float(psnr(img, rgb[test_idx])), float(psnr(img_ref, rgb[test_idx]))
+    assert abs(p_hip - p_ref) < 0.1, (p_hip, p_ref)
+
+
 def test_train_entry_point_on_a_scene_on_disk(tmp_path):
     """train() end to end on a Blender-format scene written to disk: loader -> device ray tables -> training
     loop -> test render -> metrics_*.json + model.pt; the checkpoint loads back with reference key names."""

@@ -62,6 +62,26 @@ def test_argument_errors_are_reported(lib):
     assert rc == -2
 
 
+def test_fused_entry_points_validate_their_configuration(lib):
+    """tn_kplanes_mlp_fwd_pair / _bwd_pair / tn_adam_multi_gated / tn_basis_dot_* reject bad arguments before any launch."""
+    from tinynerf_amd import _lib as L
+    lib.tn_last_error_string.restype = ctypes.c_char_p
+    kd, md = L.KPlanesDesc(), L.MlpDesc()
+    kd.n_scales, kd.channels = 2, 32                       # the fused launches are built for 3 scales x 32 channels
+    md.in_dim = 96
+    args = (ctypes.byref(kd), None, ctypes.c_int64(7), ctypes.byref(md), ctypes.byref(md), None, ctypes.c_int64(64), None, None, None,
+            None, ctypes.c_int64(0), None, ctypes.c_int64(0), None)
+    assert lib.tn_kplanes_mlp_fwd_pair(*args) == -3 and b"3 scales" in lib.tn_last_error_string()
+    assert lib.tn_kplanes_mlp_fwd_pair(None, *args[1:]) == -1
+    rc = lib.tn_kplanes_mlp_bwd_pair(ctypes.byref(kd), None, ctypes.c_int64(7), None, ctypes.byref(md), ctypes.byref(md), None, None, None, None,
+                                     ctypes.c_int64(64), None, None, None, None, None, None, ctypes.c_int64(0), None, ctypes.c_int64(0), None)
+    assert rc == -1                                        # null grad_planes
+    assert lib.tn_adam_multi_gated(None, ctypes.c_int32(1), *[ctypes.c_float(0.1)] * 5, None, None, ctypes.c_int32(0), None) == -1
+    assert lib.tn_basis_dot_fwd(None, None, ctypes.c_int64(8), ctypes.c_int32(96), ctypes.c_int32(5), ctypes.c_int32(0), None, None) == -2
+    assert lib.tn_basis_dot_bwd(None, None, None, ctypes.c_int64(0), ctypes.c_int32(96), ctypes.c_int32(3), ctypes.c_int32(2), None, None,
+                                ctypes.c_int32(0), None) == 0          # n == 0: nothing to do
+
+
 def test_no_cpu_path():
     """CPU tensors are rejected like the reference's CHECK_CUDA (cuda.cu:62) -- no fallback."""
     from tinynerf_amd import core

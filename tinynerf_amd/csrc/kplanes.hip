@@ -86,7 +86,7 @@ int make_args(const tn_kplanes_desc *d, KpArgs &a, float *const (*grads)[3])
     a.n_scales = d->n_scales; a.C = d->channels;
     for (int s = 0; s < d->n_scales; ++s) {
         TN_REQUIRE(d->height[s] > 0 && d->width[s] > 0, TN_E_SIZE, "kplanes: bad plane resolution");
-        TN_REQUIRE((int64_t)d->height[s] * d->width[s] * d->channels < (1ll << 31), TN_E_SIZE, "kplanes: plane too large");
+        TN_REQUIRE((int64_t)d->height[s] * d->width[s] * d->channels < (1ll << 30), TN_E_SIZE, "kplanes: plane too large (2^30 elements)");
         a.H[s] = d->height[s]; a.W[s] = d->width[s];
         TN_REQUIRE(d->planes[s][0], TN_E_NULL, "kplanes: null plane pointer");
         for (int p = 0; p < 3; ++p) {     // planes 1 and 2 may be NULL: the factor is then 1 (single-plane lookup)

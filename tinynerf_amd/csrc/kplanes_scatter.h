@@ -58,10 +58,14 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {          // this lane publishes taps 2h, 2h+1 of its sample
-            const int o0 = t[p].off[0 + k], o1 = t[p].off[2 + k];
-            const float w0 = t[p].w[0 + k], w1 = t[p].w[2 + k];
-            tileO[(2 * h + k) * 32 + j] = valid ? (h ? o1 : o0) : -1;
-            tileW[(2 * h + k) * 32 + j] = h ? w1 : w0;
+            const int o = h ? t[p].off[2 + k] : t[p].off[0 + k];
+            const float w = h ? t[p].w[2 + k] : t[p].w[0 + k];
+            // a tap outside the plane (or a row past n) gets weight 0 and points at texel 0: its running sum stays exactly 0, so
+            // phase B needs no per-atomic bounds test (compare + exec save / restore around every atomic) -- at worst it adds
+            // +0.0 to a valid line when a run ends at the plane's border
+            const bool live = valid && o >= 0;
+            tileO[(2 * h + k) * 32 + j] = live ? 4 * o : 0;            // BYTE offset (planes are < 2^30 elements)
+            tileW[(2 * h + k) * 32 + j] = live ? w : 0.0f;
         }
         // run boundaries: sample j closes a run when the next sample falls into another cell.  When the next
         // cell is a 4-neighbour, two of the four texels are shared with it: instead of flushing them, their
@@ -76,9 +80,11 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
         asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
         // ---- phase B: lane = (tap pair h, channel c) ----
         const int c = j;                       // channel
-        float *gbase = grads[p] + c;
+        char *const gplane = reinterpret_cast<char *>(grads[p]);     // wave-uniform base + 32-bit byte offsets: no 64-bit VALU
+        const unsigned c4 = 4u * (unsigned)c;                        // address arithmetic per atomic (saddr form)
+        auto add_at = [&](unsigned byte_off, float v) { atomicAdd(reinterpret_cast<float *>(gplane + byte_off), v); };
         if (c < C) {
-            const int *O0 = tileO + (2 * h) * 32, *O1 = O0 + 32;
+            const int4 *O0 = reinterpret_cast<const int4 *>(tileO + (2 * h) * 32), *O1 = O0 + 8;
             const f32x4k *W0 = reinterpret_cast<const f32x4k *>(tileW + (2 * h) * 32);
             const f32x4k *W1 = W0 + 8;
             float a0 = 0.0f, a1 = 0.0f;        // running sums of this half's left / right texel
@@ -87,6 +93,8 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
 #pragma clang loop unroll(disable)
             for (int s4 = 0; s4 < 8; ++s4) {
                 const f32x4k w0 = W0[s4], w1 = W1[s4];
+                const int4 o0v = O0[s4], o1v = O1[s4];   // offsets of the group up front: a read per run end would expose an LDS latency each
+                const int o0a[4] = {o0v.x, o0v.y, o0v.z, o0v.w}, o1a[4] = {o1v.x, o1v.y, o1v.z, o1v.w};
                 float gv[4];                   // four samples at a time: 32 at once cost 12 spilled registers
 #pragma unroll
                 for (int u = 0; u < 4; ++u) gv[u] = tileG[(4 * s4 + u) * KP_GS + c];
@@ -96,30 +104,30 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
                     a0 = fmaf(gv[u], w0[u], a0);
                     a1 = fmaf(gv[u], w1[u], a1);
                     if ((run_end >> sI) & 1u) {          // wave-uniform (scalar) control flow from here on
-                        const int o0 = O0[sI], o1 = O1[sI];
+                        const unsigned o0 = (unsigned)o0a[u] + c4, o1 = (unsigned)o1a[u] + c4;
                         if ((mv_xp >> sI) & 1u) {        // next cell = x+1: right texel becomes the left one
-                            if (o0 >= 0) atomicAdd(gbase + o0, a0);
+                            add_at(o0, a0);
                             a0 = a1; a1 = 0.0f;
                         } else if ((mv_xm >> sI) & 1u) { // next cell = x-1
-                            if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            add_at(o1, a1);
                             a1 = a0; a0 = 0.0f;
                         } else if ((mv_yp >> sI) & 1u) { // next cell = y+1: the lower row (half 1) becomes the upper row
                             const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
                             if (h == 0) {
-                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                add_at(o0, a0);
+                                add_at(o1, a1);
                             }
                             a0 = h == 0 ? t0 : 0.0f; a1 = h == 0 ? t1 : 0.0f;
                         } else if ((mv_ym >> sI) & 1u) { // next cell = y-1
                             const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
                             if (h == 1) {
-                                if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                                if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                                add_at(o0, a0);
+                                add_at(o1, a1);
                             }
                             a0 = h == 1 ? t0 : 0.0f; a1 = h == 1 ? t1 : 0.0f;
                         } else {
-                            if (o0 >= 0) atomicAdd(gbase + o0, a0);
-                            if (o1 >= 0) atomicAdd(gbase + o1, a1);
+                            add_at(o0, a0);
+                            add_at(o1, a1);
                             a0 = 0.0f; a1 = 0.0f;
                         }
                     }

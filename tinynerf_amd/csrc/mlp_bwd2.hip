@@ -1106,7 +1106,7 @@ extern "C" int tn_kplanes_mlp_bwd_pair(const tn_kplanes_desc *kd, const float *c
     TN_REQUIRE(coords, TN_E_NULL, "tn_kplanes_mlp_bwd_pair: null coordinates");
     KpBwd kp;
     for (int s = 0; s < 3; ++s) {
-        TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 31), TN_E_SIZE,
+        TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 30), TN_E_SIZE,
                    "tn_kplanes_mlp_bwd_pair: bad plane resolution");
         kp.H[s] = kd->height[s]; kp.W[s] = kd->width[s];
         for (int p = 0; p < 3; ++p) {

@@ -314,6 +314,11 @@ int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kdesc, const float *coords, i
                             void *workspace, int64_t workspace_bytes, void *partner_workspace, int64_t partner_workspace_bytes,
                             void *stream);
 
+/* Inference form: the gather inside the launch of ONE head without encoding (the sigma head; tn_kplanes_fwd + tn_mlp_fwd):
+ * y [n, dims[last]] and the feature rows `feat` [n, 96], which the colour head then reads where the weight is not 0. */
+int tn_kplanes_mlp_fwd(const tn_kplanes_desc *kdesc, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc, int64_t n,
+                       float *feat, float *y, void *stream);
+
 /* Backward twin: tn_mlp_bwd_pair with the plane scatter (tn_kplanes_bwd) inside the data-gradient chain launch.  d(loss)/d(feat)
  * never leaves the registers of the wave that computed it: each wave scatters its 32 samples' three 32-channel blocks into
  * grad_planes[s][p] (+=, fp32 atomics; NULL entries are skipped) while the other waves of its SIMD run their MFMA chains.

@@ -128,7 +128,10 @@ def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypa
         r.zero_grad(set_to_none=True)
         out = r(packed, info)
         torch.nn.functional.mse_loss(out, target).backward()
-        res[fuse] = (out.detach().clone(), {k: p.grad.clone() for k, p in r.named_parameters()})
-    assert torch.equal(res[True][0], res[False][0])
+        with torch.no_grad():                      # inference form: tn_kplanes_mlp_fwd (gather + sigma head), colour head gated by w
+            out_eval = r(packed, info)
+        res[fuse] = (out.detach().clone(), {k: p.grad.clone() for k, p in r.named_parameters()}, out_eval.clone())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    np.testing.assert_allclose(res[True][2].cpu().numpy(), res[True][0].cpu().numpy(), rtol=0, atol=1e-6)      # eval == train forward
     for k, g in res[True][1].items():         # every gradient ends in fp32 atomics: same terms, different order
         np.testing.assert_allclose(g.cpu().numpy(), res[False][1][k].cpu().numpy(), rtol=0, atol=2e-6 * float(g.abs().max()), err_msg=k)

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
                                                            float *__restrict__ stash0, FwdPair pr, KpFwd kp = KpFwd())
 {
-    static_assert(!KP || (FAST && STASH && H == 64), "the fused gather feeds the plain-column first layer of the width-64 heads");
+    static_assert(!KP || (FAST && H == 64), "the fused gather feeds the plain-column first layer of the width-64 heads");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     if constexpr (WLDS) {
@@ -383,6 +383,17 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
             else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
             if (rc) return rc;
         } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: the register-resident training forward is built for width 64");
+    } else if (wlds && kp) {      // inference: gather + one head (the sigma head; the colour head then reads the feature rows where w > 0)
+        if constexpr (H == 64) {
+            if (!fast) return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd: the head must take the plain-column first layer");
+            auto kern = mlp_fwd_kernel<H, true, 12, false, false, true, true>;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (12 * 64)));
+            const int64_t blocks = std::min<int64_t>((n_tiles + 11) / 12, 256 * per_cu);
+            kern<<<dim3((unsigned)blocks), dim3(12 * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+            return tn::check_launch("mlp_fwd_kernel(kplanes, inference)");
+        } else return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd: width-64 heads only");
     } else if (wlds) {
         auto kern = fast ? mlp_fwd_kernel<H, true, WPB, false, false, true> : mlp_fwd_kernel<H, true, WPB, false, false, false>;
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -494,6 +505,40 @@ extern "C" int tn_mlp_fwd_stash_pair(const tn_mlp_desc *desc, const tn_mlp_desc 
     if (int rc = plan(partner, pr.b, Hb)) return rc;
     pr.aux = nullptr; pr.y = partner_y; pr.stash = (float *)partner_workspace;
     return fwd_common(desc, x, aux, n, y, nullptr, (float *)workspace, (hipStream_t)stream, "tn_mlp_fwd_stash_pair", &pr);
+}
+
+static int kp_fwd_args(const tn_kplanes_desc *kd, const float *coords, int64_t coord_stride, float *feat, KpFwd &kp, const char *who)
+{
+    TN_REQUIRE(kd, TN_E_NULL, "tn_kplanes_mlp_fwd: null descriptor");
+    TN_REQUIRE(kd->n_scales == 3 && kd->channels == 32, TN_E_CONFIG, "tn_kplanes_mlp_fwd: 3 scales x 32 channels (run.py:136)");
+    TN_REQUIRE(coord_stride >= 3, TN_E_SIZE, "tn_kplanes_mlp_fwd: bad coordinate stride");
+    TN_REQUIRE(coords && feat, TN_E_NULL, "tn_kplanes_mlp_fwd: null pointer");
+    TN_REQUIRE(((uintptr_t)feat & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd: feat must be 16-byte aligned");
+    for (int s = 0; s < 3; ++s) {
+        TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 30), TN_E_SIZE,
+                   "tn_kplanes_mlp_fwd: bad plane resolution");
+        kp.H[s] = kd->height[s]; kp.W[s] = kd->width[s];
+        for (int p = 0; p < 3; ++p) {
+            TN_REQUIRE(kd->planes[s][p], TN_E_NULL, "tn_kplanes_mlp_fwd: null plane pointer");
+            TN_REQUIRE(((uintptr_t)kd->planes[s][p] & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd: planes must be 16-byte aligned");
+            kp.planes[s][p] = kd->planes[s][p];
+        }
+    }
+    kp.coords = coords; kp.coord_stride = coord_stride; kp.feat = feat;
+    return TN_OK;
+}
+
+extern "C" int tn_kplanes_mlp_fwd(const tn_kplanes_desc *kd, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc, int64_t n,
+                                  float *feat, float *y, void *stream)
+{
+    TN_REQUIRE(desc, TN_E_NULL, "tn_kplanes_mlp_fwd: null descriptor");
+    TN_REQUIRE(desc->in_dim == 96 && desc->encoding == TN_ENC_NONE && desc->dims[1] == 64 && desc->row_gate == nullptr, TN_E_CONFIG,
+               "tn_kplanes_mlp_fwd: an ungated width-64 head without encoding on the 96 features");
+    if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_kplanes_mlp_fwd: negative n");
+    KpFwd kp;
+    if (int rc = kp_fwd_args(kd, coords, coord_stride, feat, kp, "tn_kplanes_mlp_fwd")) return rc;
+    TN_REQUIRE(y && ((uintptr_t)y & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd: y must be a 16-byte aligned pointer");
+    return fwd_common(desc, nullptr, nullptr, n, y, nullptr, nullptr, (hipStream_t)stream, "tn_kplanes_mlp_fwd", nullptr, &kp);
 }
 
 extern "C" int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kd, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc,

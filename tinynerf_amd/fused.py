@@ -107,12 +107,16 @@ class _RenderKPlanes(Function):
         rgbs = _alloc(arena, "rgbs", (n, 3), dev)
         pair = (ws_s is not None and ws_r is not None and PAIR_FORWARD and F % 4 == 0 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64)
         gather_fused = pair and FUSE_GATHER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
-        if gather_fused:   # gather + both heads in ONE launch: the feature rows go from the texel lines to the MFMA operands
+        gather_sigma = (not train and FUSE_GATHER and F % 4 == 0 and sig_p[0].size(0) == 64 and kdesc.n_scales == 3 and kdesc.channels == 32
+                        and len(keep) == 9)
+        if gather_sigma:   # inference: gather + sigma head in one launch
+            L.call("tn_kplanes_mlp_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(sdesc), C.c_int64(n), L.ptr(feat), L.ptr(sigma))
+        elif gather_fused:   # gather + both heads in ONE launch: the feature rows go from the texel lines to the MFMA operands
             L.call("tn_kplanes_mlp_fwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(rdesc), C.byref(sdesc), L.ptr(table),
                    C.c_int64(n), L.ptr(feat), L.ptr(rgbs), L.ptr(sigma), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
         else:
             L.call("tn_kplanes_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(feat))
-        if gather_fused:
+        if gather_fused or gather_sigma:
             pass
         elif pair:         # both heads in one launch: the feature rows are read from HBM once
             L.call("tn_mlp_fwd_stash_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs),

@@ -368,7 +368,7 @@ def main():
             "rooflines": roofs,
             "whole_step": whole,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (the other ranks would sit in the closing barrier)
             line["cpu_baseline"] = cpu_baseline(tr, args.cpu_samples)
         print(json.dumps(line))
     if world > 1:

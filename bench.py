@@ -259,7 +259,7 @@ def main():
 
     # stage rates on one batch of the same workload (sampler / render fwd / render fwd+bwd)
     stages = None
-    if rank == 0 and not args.no_stages:
+    if rank == 0 and world == 1 and not args.no_stages:      # (N = 1 only: a one-rank backward would start collectives nobody joins)
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
             t = time.perf_counter()

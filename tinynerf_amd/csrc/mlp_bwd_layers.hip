@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
             act[ob] = tn::relu16(act[ob]);
             store_rows(st, act[ob], ob, j, h);
         }
-        if constexpr (FIRST_ONLY) continue;        // the remaining layers run as fwd_lds_kernel launches
+        if constexpr (FIRST_ONLY) continue;        // the remaining layers run as fwd_wreg_kernel launches
         for (int l = 1; l + 1 < L; ++l) {
             tn::hidden_layer<H>(a.W[l], a.B[l], H, act, j, h);
 #pragma unroll
@@ -347,12 +347,10 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// training forward of one wide layer (H = 128 / 256, K == H) with the weights in LDS -- the forward twin of
-// dgrad_lds_kernel.  The all-layers kernel above re-reads each 256 KB weight matrix from L2 per 32-sample tile (16.7 ms for
-// the 10-layer 256-wide stack and 2^20 samples where the MFMAs need 8.5); here a workgroup stages the 32*NOT weight ROWS
-// (output features) it is responsible for once, every wave walks its tiles with the layer input H_{l-1} in registers (read
-// back from the workspace rows the previous launch wrote, which are already in B-operand layout) and one ds_read_b128 per
-// four MFMAs.  LAST: no ReLU; writes y and the pre-activation rows the backward's out_grad_kernel expects.
+// training forward of the FIRST layer of a wide stack (positional-encoding inputs, K0_pad <= 64) with the weights in LDS:
+// a workgroup stages all H weight rows (zero-padded to 64 columns) once, every wave walks its tiles with the encoded
+// inputs (workspace rows written by enc_rows_kernel, already in B-operand layout) in registers and one ds_read_b128 per
+// four MFMAs.  The hidden and output layers run as fwd_wreg_kernel launches (below).
 // ------------------------------------------------------------------------------------------------
 // positional-encoding inputs of a tile as workspace rows [slot][32 samples] (the E rows of the layout)
 __global__ __launch_bounds__(256) void enc_rows_kernel(MlpArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ stash,
@@ -383,9 +381,9 @@ struct FwdLayerArgs {
     int out_act;
 };
 
-// T = 32-row blocks of the layer input: H / 32 for hidden layers; 2 for the positional-encoding first layer, whose encoded
-// inputs (<= 64 slots) enc_rows_kernel has written as workspace rows (the rows the weight gradient reads anyway)
-template <int H, int T, int NOT, int WPB, bool LAST>
+// T = 32-row blocks of the layer input: 2 for the positional-encoding first layer, whose encoded inputs (<= 64 slots)
+// enc_rows_kernel has written as workspace rows (the rows the weight gradient reads anyway)
+template <int H, int T, int NOT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -429,8 +427,6 @@ __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64
                     A[t][r] = k < a.Kp ? v : 0.0f;                            // rows past Kp belong to another buffer
                 }
             }
-        const int64_t row = tile * 32 + j;
-        const bool valid = row < n;
 #pragma clang loop unroll(disable)
         for (int otl = 0; otl < n_ot; ++otl) {
             const int ot = ot0 + otl;
@@ -448,20 +444,294 @@ __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64
                 }
             }
             tn::pin16(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outp[(32 * ot + frow(r, h)) * 32 + j] = fmaxf(acc[r], 0.0f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hidden layers of the wide stacks (N == K == H = 128 / 256), weights in REGISTERS, activations through LDS.
+//
+// The LDS-weight form (dgrad_lds_kernel above; its forward twin was removed) keeps half a layer's weights in LDS and a
+// tile's 128 input values per lane in registers: every wave reads its own tile from HBM (two column groups -> every input
+// row twice), pays ~3 VALU instructions of address arithmetic per row load, and stalls on a full memory latency per tile
+// whenever its SIMD partner does too (measured: matrix pipes 71-77 % busy; this form 78-88 %).  Here the roles are swapped: wave `ob` of a workgroup owns output block `ob` of the
+// layer and holds W[32 ob .. 32 ob + 31][0 .. H) as A operands in 4 H / 32 registers for the whole launch; the H / 32 waves
+// of a tile stream share each 32-sample input tile through LDS, [sample][feature] with a 4-float pad, so that the B operand
+// of four consecutive MFMAs is one conflict-free ds_read_b128.  A wave brings in 32 of the tile's H rows (16 row loads per
+// lane with immediate offsets, 4 ds_write_b128).  Three LDS tile buffers and ONE barrier per tile, placed in the middle of
+// the tile's MFMAs: tile it+1 is written at the top of iteration it (requested a whole iteration earlier), read from the top
+// of iteration it+1, and its buffer is reused for tile it+4 only after the barrier of iteration it+2 -- no wave ever waits
+// at the barrier unless it is half a tile ahead of the slowest one.  Same MFMA steps in the same order as the LDS-weight
+// kernels: bit-identical results.  What is left of the idle time is the vector-memory instructions themselves (ablation in
+// scripts/microbench/wreg_layer.hip: no loads and no stores -> 97.6 % busy; staggering the two waves of a SIMD, spreading
+// the instructions between the MFMAs, LDS-direct loads with ds_read_b32 operands and wide accesses through LDS transposes
+// were all measured and are not faster).
+// ------------------------------------------------------------------------------------------------
+template <int H> struct WregGeom {
+    static constexpr int T = H / 32;               // 32-row blocks of the layer's input and of its output
+    static constexpr int STREAMS = 8 / T;          // tile streams per 8-wave workgroup
+    static constexpr int SW = H + 4;               // LDS tile row stride (floats)
+    static constexpr int TILE = 32 * SW;           // floats per tile buffer
+    static constexpr size_t lds_bytes = (size_t)STREAMS * 3 * TILE * sizeof(float);
+};
+
+// Vector-memory instructions of these kernels use the SGPR-base form (wave-uniform 64-bit base + one 32-bit lane offset +
+// immediate): a 64-bit per-lane address costs the SIMD measurably more matrix-pipe time per instruction
+// (scripts/microbench/wreg_layer.hip: 84.8 -> 87.8 % busy for the same loads and stores).
+__device__ __forceinline__ const float *urow(const float *base, int64_t row) {          // wave-uniform row pointer
+    const int64_t o = row * 32;
+    return base + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+}
+__device__ __forceinline__ float *urow(float *base, int64_t row) { return const_cast<float *>(urow(const_cast<const float *>(base), row)); }
+
+// the 32 rows [32 ob, 32 ob + 32) of a [row][32 samples] tile -> registers (lane (j, h): rows 32 ob + 16 h + 0..15, sample j)
+__device__ __forceinline__ void wreg_load_rows(const float *__restrict__ rows, int ob, int j, int h, float (&stage)[16]) {
+    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(16 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));       // (keeps the zero-extension next to the access: base + zext(off) selects the SGPR-base form)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) stage[e] = *reinterpret_cast<const float *>(p + off + (unsigned)(e * 128));
+}
+// D-layout rows of block `ob` (lane (j, h), reg r: row 32 ob + frow(r, h), sample j) from / to [row][32 samples] rows
+__device__ __forceinline__ void wreg_store_block(float *__restrict__ rows, int ob, int j, int h, const f32x16 &v) {
+    char *p = reinterpret_cast<char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = v[r];
+}
+__device__ __forceinline__ void wreg_load_block(const float *__restrict__ rows, int ob, int j, int h, float (&m)[16]) {
+    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[r] = *reinterpret_cast<const float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
+}
+// ... -> LDS tile [sample j][feature]: four ds_write_b128
+__device__ __forceinline__ void wreg_write_rows(float *__restrict__ tile, int SW, int ob, int j, int h, const float (&stage)[16]) {
+    float *p = tile + j * SW + 32 * ob + 16 * h;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        *reinterpret_cast<f32x4 *>(p + 4 * v) = f32x4{stage[4 * v], stage[4 * v + 1], stage[4 * v + 2], stage[4 * v + 3]};
+}
+
+// MFMAs of reduction groups [G0, G1) (group g = 8 in-features: B operand = one ds_read_b128 at bt + 8 g) with the operands of
+// the next PAIR of groups requested before the current pair's eight MFMAs are issued (left alone, hipcc sinks each read to
+// just in front of its first use: read -> wait -> MFMAs -> read ...; both waves of a SIMD then wait at the same time)
+template <int G0, int G1, int T>
+__device__ __forceinline__ void wreg_mfma_run(f32x16 &acc, const f32x4 (&W)[T][4], const float *__restrict__ bt, f32x4 (&b)[2]) {
+#pragma unroll
+    for (int g = G0; g < G1; g += 2) {
+        f32x4 nb[2];
+        if (g + 2 < G1) {
+            nb[0] = *reinterpret_cast<const f32x4 *>(bt + 8 * (g + 2));
+            nb[1] = *reinterpret_cast<const f32x4 *>(bt + 8 * (g + 3));
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = tn::mfma32(W[(g + e) >> 2][(g + e) & 3][u], b[e][u], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G1) { b[0] = nb[0]; b[1] = nb[1]; }
+    }
+}
+__device__ __forceinline__ void wreg_first_pair(const float *__restrict__ bt, int g, f32x4 (&b)[2]) {
+    b[0] = *reinterpret_cast<const f32x4 *>(bt + 8 * g);
+    b[1] = *reinterpret_cast<const f32x4 *>(bt + 8 * (g + 1));
+}
+
+template <int H, bool LAST>
+__global__ __launch_bounds__(512) void fwd_wreg_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
+{
+    using G = WregGeom<H>;
+    constexpr int T = G::T, SW = G::SW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stream = wave / T, ob = wave % T;
+    float *buf = lds + stream * 3 * G::TILE;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int64_t stride = (int64_t)gridDim.x * G::STREAMS;
+    const int64_t first = (int64_t)blockIdx.x * G::STREAMS;          // the workgroup's lowest tile: defines its iteration count
+    const int64_t iters = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    if (iters == 0) return;
+    // A operands: W[32 ob + j][32 t + 8 q + 4 h .. + 3]
+    f32x4 W[T][4];
+    {
+        const int nn = 32 * ob + j;
+        const float *wrow = a.W + (int64_t)(nn < a.N ? nn : 0) * a.K + 4 * h;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 32 * t + 8 * q);
+                W[t][q] = nn < a.N ? w : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    f32x16 bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int f = 32 * ob + frow(r, h); bias[r] = a.B[f < a.N ? f : 0]; }
+    auto tile_of = [&](int64_t it) { const int64_t t = first + stream + it * stride; return t < n_tiles ? t : n_tiles - 1; };
+    float stage[16];
+    wreg_load_rows(urow(stash, tile_of(0) * a.rows_total + a.off_in), ob, j, h, stage);
+    wreg_write_rows(buf, SW, ob, j, h, stage);
+    wreg_load_rows(urow(stash, tile_of(1) * a.rows_total + a.off_in), ob, j, h, stage);
+    __syncthreads();
+    // results of a tile: [feature][32 samples] rows (+ y for the last layer).  A stream past the end recomputes the last tile
+    // (same inputs -> same values) rather than branching around its stores.
+    auto emit = [&](int64_t tile, f32x16 acc) {
+        if (!LAST || 32 * ob < a.N) {
             if constexpr (!LAST) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) outp[(32 * ot + frow(r, h)) * 32 + j] = fmaxf(acc[r], 0.0f);
+                wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc);
             } else {
+                float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
+                const int64_t row = tile * 32 + j;
+                const bool valid = row < n;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = 32 * ot + frow(r, h);
-                    const bool ok = valid && f < a.N;
-                    outp[f * 32 + j] = ok ? acc[r] : 0.0f;
-                    if (ok) y[row * a.N + f] = tn::apply_act(acc[r], a.out_act);
+                for (int q = 0; q < 4; ++q) {
+                    const int f = 32 * ob + 8 * q + 4 * h;
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = valid && f + u < a.N;
+                        outp[(u + 8 * q) * 32] = ok ? acc[4 * q + u] : 0.0f;
+                        v[u] = tn::apply_act(acc[4 * q + u], a.out_act);
+                    }
+                    if (valid) {
+                        if ((a.N & 3) == 0) { if (f < a.N) *reinterpret_cast<f32x4 *>(y + row * a.N + f) = v; }
+                        else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (f + u < a.N) y[row * a.N + f + u] = v[u];
+                        }
+                    }
                 }
             }
         }
+    };
+    int cur = 0;
+    f32x16 res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < iters; ++it) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        wreg_write_rows(buf + nxt * G::TILE, SW, ob, j, h, stage);              // tile it+1 (requested a whole iteration ago)
+        // VMEM queue order: the PREVIOUS tile's stores, then the requests for tile it+2 -- the s_waitcnt vmcnt in front of the
+        // next iteration's ds_write then waits for exactly these loads (stores issued after them would have to drain first:
+        // vmcnt counts loads and stores in one in-order queue on gfx9)
+        if (it > 0) emit(tile_of(it - 1), res);
+        wreg_load_rows(urow(stash, tile_of(it + 2) * a.rows_total + a.off_in), ob, j, h, stage);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *bt = buf + cur * G::TILE + j * SW + 4 * h;
+        f32x16 acc = bias;
+        f32x4 b[2];
+        wreg_first_pair(bt, 0, b);
+        wreg_mfma_run<0, 2 * T, T>(acc, W, bt, b);
+        __syncthreads();
+        wreg_first_pair(bt, 2 * T, b);
+        wreg_mfma_run<2 * T, 4 * T, T>(acc, W, bt, b);
+        tn::pin16(acc);
+        if constexpr (!LAST) res = tn::relu16(acc); else res = acc;
+        cur = nxt;
     }
+    emit(tile_of(iters - 1), res);
+}
+
+// data gradient twin: wave `kb` owns input-feature block kb and holds W[0 .. H)[32 kb .. 32 kb + 31] (W^T rows) in registers
+template <int H>
+__global__ __launch_bounds__(512) void dgrad_wreg_kernel(DgradArgs a, int64_t n, float *__restrict__ stash)
+{
+    using G = WregGeom<H>;
+    constexpr int T = G::T, SW = G::SW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stream = wave / T, kb = wave % T;
+    float *buf = lds + stream * 3 * G::TILE;
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int64_t stride = (int64_t)gridDim.x * G::STREAMS;
+    const int64_t first = (int64_t)blockIdx.x * G::STREAMS;
+    const int64_t iters = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    if (iters == 0) return;
+    // A operands: W[32 t + 8 q + 4 h + u][32 kb + j]   (N == K == H)
+    f32x4 W[T][4];
+    {
+        const float *wcol = a.W + (int64_t)(4 * h) * a.K + 32 * kb + j;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) W[t][q][u] = wcol[(int64_t)(32 * t + 8 * q + u) * a.K];
+    }
+    auto tile_of = [&](int64_t it) { const int64_t t = first + stream + it * stride; return t < n_tiles ? t : n_tiles - 1; };
+    float stage[16];
+    wreg_load_rows(urow(stash, tile_of(0) * a.rows_total + a.off_gin), kb, j, h, stage);
+    wreg_write_rows(buf, SW, kb, j, h, stage);
+    wreg_load_rows(urow(stash, tile_of(1) * a.rows_total + a.off_gin), kb, j, h, stage);
+    __syncthreads();
+    auto emit = [&](int64_t tile, const f32x16 &g) {
+        wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), kb, j, h, g);
+    };
+    int cur = 0;
+    f32x16 res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < iters; ++it) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        wreg_write_rows(buf + nxt * G::TILE, SW, kb, j, h, stage);
+        // VMEM queue order (see fwd_wreg_kernel): previous tile's stores, this tile's ReLU-mask rows, requests for tile it+2
+        if (it > 0) emit(tile_of(it - 1), res);
+        const int64_t tile = tile_of(it);
+        float m[16];
+        wreg_load_block(urow(stash, tile * a.rows_total + a.off_mask), kb, j, h, m);
+        wreg_load_rows(urow(stash, tile_of(it + 2) * a.rows_total + a.off_gin), kb, j, h, stage);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *bt = buf + cur * G::TILE + j * SW + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        f32x4 b[2];
+        wreg_first_pair(bt, 0, b);
+        wreg_mfma_run<0, 2 * T, T>(acc, W, bt, b);
+        __syncthreads();
+        wreg_first_pair(bt, 2 * T, b);
+        wreg_mfma_run<2 * T, 4 * T, T>(acc, W, bt, b);
+        tn::pin16(acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = m[r] > 0.0f ? acc[r] : 0.0f;
+        cur = nxt;
+    }
+    emit(tile_of(iters - 1), res);
+}
+
+template <int H, bool LAST>
+int launch_fwd_wreg(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    using G = WregGeom<H>;
+    auto kern = fwd_wreg_kernel<H, LAST>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_fwd: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(512), G::lds_bytes, s>>>(f, n, stash, y);
+    return tn::check_launch("fwd_wreg_kernel");
+}
+
+template <int H>
+int launch_dgrad_wreg(const DgradArgs &d, int64_t n, float *stash, hipStream_t s)
+{
+    using G = WregGeom<H>;
+    auto kern = dgrad_wreg_kernel<H>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(512), G::lds_bytes, s>>>(d, n, stash);
+    return tn::check_launch("dgrad_wreg_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,16 +835,32 @@ __global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const flo
     }
 }
 
-// Hidden layers of the 256-wide stack (N = K = 256, 8 x 8 output tiles): a wave owns a BN x BK block of tiles instead of
-// eight scattered ones, so per 32-sample tile it loads BN + BK operand row blocks instead of 2 * BN * BK (the generic kernel
-// spends its time in the texture path: 64 16-byte loads per wave and tile for 128 MFMAs; here 24).
-template <int BN, int BK>
-__global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
+// Hidden layers of the wide stacks (N == K == H = 128 / 256: H/32 x H/32 output tiles of 32 x 32): a wave owns a BN x BK block
+// of tiles (2 x 4 for H = 256: 128 accumulator registers), so a 32-sample tile costs it BN + BK operand blocks for
+// 16 BN BK MFMAs.  The workgroup brings a tile's 2 H rows (G_l and H_{l-1}, [feature][32 samples]) in ONCE, LDS-direct
+// (global_load_lds_dwordx4: no staging registers, no ds_write; H / 32 instructions per wave and tile), double-buffered with
+// one barrier per tile, and the operands are ds_read_b128.  (Each wave requesting its own operand blocks from L2 -- 24
+// 16-byte loads per lane and tile, every block fetched by 2-4 waves -- ran the matrix pipes at 74 %: a vector-memory
+// instruction costs its SIMD ~40-90 pipe cycles, scripts/microbench/wreg_layer.hip; this form: 84 %.)  The LDS image of an
+// LDS-direct load is lane-linear (no row padding possible), so the 16-byte chunks of a row are XOR-swizzled through the
+// SOURCE address: slot p of row r holds chunk p ^ ((r >> 1) & 7), which spreads the 16 rows of a ds_read_b128 phase over
+// all 64 banks.
+// global_load_lds_dwordx4: 16 bytes per lane from `src` (per lane) to LDS at `dst` (wave-uniform) + 16 * lane; counted in vmcnt.
+// (Kept in a __device__ function: the builtin inside a __global__ template makes hipcc's host pass drop the kernel's stub.)
+__device__ __forceinline__ void glds16(const float *src, float *dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+template <int H, int BN, int BK>
+__global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
 {
+    constexpr int TILE = 2 * H * 32;                      // floats per buffer: G rows [0, H), A rows [H, 2H)
+    constexpr int NI = H / 32;                            // LDS-direct loads per wave and tile (8 rows each)
+    constexpr int WK = (H / 32) / BK;                     // waves along k
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
-    const int WK = ((a.K + 31) >> 5) / BK;                 // waves along k
     const int tn0 = (wave / WK) * BN, tk0 = (wave % WK) * BK;
     f32x16 acc[BN][BK];
     float dbacc[BN];
@@ -586,52 +872,50 @@ __global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bn][bk][r] = 0.0f;
     }
-    const int64_t goff = (int64_t)(a.off_g + 32 * tn0 + i) * 32 + 16 * h;
-    const int64_t aoff = (int64_t)(a.off_a + 32 * tk0 + i) * 32 + 16 * h;
-    // the next tile's G blocks and first A block are requested before this tile's MFMAs (a tile's loads would otherwise be
-    // a full HBM latency in front of 32 * BN * BK MFMAs); the other A blocks follow one block ahead
-    f32x4 gvn[BN][4], avn[4];
-    auto prefetch = [&](int64_t tile) {
+    // this lane's part of a tile fetch: rows 8 (wave NI + e) + (lane >> 3), chunk slot lane & 7
+    int src_off[NI];
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+        const int row = 8 * (wave * NI + e) + (lane >> 3);
+        const int src_row = row < H ? a.off_g + row : a.off_a + row - H;
+        src_off[e] = src_row * 32 + 4 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    auto fetch = [&](int64_t tile, float *buf) {
         const float *st = stash + tile * (int64_t)a.rows_total * 32;
 #pragma unroll
-        for (int bn = 0; bn < BN; ++bn) {
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + goff + bn * 1024);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gvn[bn][e] = p[e];
-        }
-        const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) avn[e] = p[e];
+        for (int e = 0; e < NI; ++e)
+            glds16(st + src_off[e], buf + 256 * (wave * NI + e));
     };
-    if ((int64_t)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    // operand chunk e (samples 16 h + 4 e .. + 3) of row r: slot (4 h + e) ^ ((r >> 1) & 7)
+    int g_off[BN], a_off[BK];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn) g_off[bn] = (32 * (tn0 + bn) + i) * 32;
+#pragma unroll
+    for (int bk = 0; bk < BK; ++bk) a_off[bk] = (H + 32 * (tk0 + bk) + i) * 32;
+    const int swz = (i >> 1) & 7;                          // rows 32 b + i: (r >> 1) & 7 == (i >> 1) & 7
+    if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, lds);
+    __syncthreads();
+    int cur = 0;
+#pragma clang loop unroll(disable)
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const float *st = stash + tile * (int64_t)a.rows_total * 32;
-        f32x4 gv[BN][4], av[2][4];
+        const float *buf = lds + cur * TILE;
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x, lds + (cur ^ 1) * TILE);
+        f32x4 gv[BN][4];
 #pragma unroll
         for (int bn = 0; bn < BN; ++bn)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gv[bn][e] = gvn[bn][e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) av[0][e] = avn[e];
-        if (BK > 1) {
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff + 1024);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) av[1][e] = p[e];
-        }
-        prefetch(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
+            for (int e = 0; e < 4; ++e) gv[bn][e] = *reinterpret_cast<const f32x4 *>(buf + g_off[bn] + 4 * ((4 * h + e) ^ swz));
 #pragma unroll
         for (int bk = 0; bk < BK; ++bk) {
-            if (bk >= 1 && bk + 1 < BK) {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(st + aoff + (bk + 1) * 1024);
+            f32x4 av[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) av[(bk + 1) & 1][e] = p[e];
-            }
+            for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(buf + a_off[bk] + 4 * ((4 * h + e) ^ swz));
 #pragma unroll
             for (int bn = 0; bn < BN; ++bn)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[bn][bk] = tn::mfma32(gv[bn][e][u], av[bk & 1][e][u], acc[bn][bk]);
+                    for (int u = 0; u < 4; ++u) acc[bn][bk] = tn::mfma32(gv[bn][e][u], av[e][u], acc[bn][bk]);
         }
         if (tk0 == 0) {
 #pragma unroll
@@ -642,6 +926,8 @@ __global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n
                 dbacc[bn] += s;
             }
         }
+        __syncthreads();                                   // (drains this wave's LDS-direct loads: the next tile is in place)
+        cur ^= 1;
     }
 #pragma unroll
     for (int bn = 0; bn < BN; ++bn) {
@@ -663,12 +949,24 @@ __global__ __launch_bounds__(512) void wgrad_block_kernel(WgradArgs a, int64_t n
     }
 }
 
-template <int H, int T, int NOT, bool LAST>
+template <int H, int BN, int BK>
+int launch_wgrad_lds(const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
+{
+    constexpr size_t lds_bytes = (size_t)2 * 2 * H * 32 * sizeof(float);
+    auto kern = wgrad_lds_kernel<H, BN, BK>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    kern<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256)), dim3(512), lds_bytes, s>>>(w, n, stash);
+    return tn::check_launch("wgrad_lds_kernel");
+}
+
+template <int H, int T, int NOT>
 int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
 {
     constexpr int WL = 8;
     constexpr size_t lds_bytes = (size_t)32 * NOT * (32 * T + 4) * 4;
-    auto kern = fwd_lds_kernel<H, T, NOT, WL, LAST>;
+    auto kern = fwd_lds_kernel<H, T, NOT, WL>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
@@ -696,7 +994,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 FwdLayerArgs f;
                 f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = lay.total;
                 f.off_in = lay.rowsH; f.off_out = 0; f.out_act = a.out_act;
-                if (int rc = launch_fwd_lds<H, 2, H / 32, false>(f, n, stash, y, s)) return rc;
+                if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
                 fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
                     a, x, aux, nullptr, n, stash, y);
@@ -706,7 +1004,8 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 FwdLayerArgs f;
                 f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = lay.total;
                 f.off_in = (l - 1) * H; f.off_out = l + 1 < L ? l * H : lay.rowsH + lay.rowsE; f.out_act = a.out_act;
-                const int rc = l + 1 < L ? launch_fwd_lds<H, H / 32, 4, false>(f, n, stash, y, s) : launch_fwd_lds<H, H / 32, 4, true>(f, n, stash, y, s);
+                // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
+                const int rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;
             }
             return TN_OK;
@@ -742,8 +1041,14 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
-        if (!w.first && w.N == 256 && w.K == 256) wgrad_block_kernel<2, 4><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, n, stash);
-        else if (!w.first && w.N == 128 && w.K == 128) wgrad_block_kernel<2, 1><<<dim3((unsigned)std::min<int64_t>(n_tiles, 256)), dim3(512), 0, s>>>(w, n, stash);
+        bool staged = false;
+        if constexpr (H == 256 || H == 128) {
+            if (!w.first && w.N == H && w.K == H) {
+                if (int rc = launch_wgrad_lds<H, 2, H == 256 ? 4 : 1>(w, n, stash, s)) return rc;
+                staged = true;
+            }
+        }
+        if (staged) {}
         else if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else if (tiles <= 64) wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: layer too large for the wgrad tiling");
@@ -757,7 +1062,10 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if (l > 0) {
             bool done = false;
             if constexpr (H >= 128) {
-                if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS
+                if (a.K[l] == H && a.N[l] == H) {
+                    if (int rc = launch_dgrad_wreg<H>(d, n, stash, s)) return rc;
+                    done = true;
+                } else if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS
                     constexpr int NKT = 4, WL = 8;
                     constexpr size_t lds_bytes = (size_t)32 * NKT * (H + 4) * 4;
                     auto kern = dgrad_lds_kernel<H, NKT, WL>;

@@ -57,15 +57,19 @@ __device__ __forceinline__ PlaneTaps plane_taps(float u, float v, int H, int W, 
 // 8 = the MFMA B-operand pattern of mlp_device.h (lane half h owns channels 8v + 4h .. +3, v = 0..NV-1, with c0 = 4h)
 template <int NV, int CS = 4>
 __device__ __forceinline__ void plane_gather(const float *__restrict__ plane, const PlaneTaps &t, int c0, f32x4k (&out)[NV]) {
+    // SGPR-base addressing (wave-uniform plane pointer + one 32-bit byte offset per lane + immediate): a 64-bit per-lane
+    // address costs the SIMD measurably more issue time per vector-memory instruction (scripts/microbench/wreg_layer.hip)
     f32x4k tex[4][NV];
     float w[4];
+    const char *base = reinterpret_cast<const char *>(plane);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool in = t.off[k] >= 0;
-        const f32x4k *p = reinterpret_cast<const f32x4k *>(plane + (in ? t.off[k] : 0) + c0);
+        unsigned boff = (unsigned)((in ? t.off[k] : 0) + c0) * 4u;         // planes hold at most 2^30 floats
+        asm volatile("" : "+v"(boff));                                     // (keeps the zero-extension at the access)
         w[k] = in ? t.w[k] : 0.0f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) tex[k][v] = p[v * (CS / 4)];
+        for (int v = 0; v < NV; ++v) tex[k][v] = *reinterpret_cast<const f32x4k *>(base + boff + (unsigned)(v * CS * 4));
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {

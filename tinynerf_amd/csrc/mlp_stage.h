@@ -114,10 +114,22 @@ __host__ __device__ inline int stash_rows_w(int H, int nh, int extra) { return 2
 __host__ __device__ inline int stash_rows(int H, int nh, int extra) { return stash_rows_w(H, nh, extra) + 4 + 2 * nh * (H / 32); }
 
 // D-layout tile -> workspace rows [feature][32 samples]; two fully used 128-B lines per store instruction
+// `rows` is wave-uniform at every call site (a wave owns its tile): the stores take the SGPR-base form -- uniform 64-bit base,
+// one 32-bit lane offset, the 16 rows as immediate offsets.  (A 64-bit per-lane address costs the SIMD measurably more issue
+// time per vector-memory instruction, time the matrix pipe stands still: scripts/microbench/wreg_layer.hip.)
+typedef __attribute__((address_space(1))) char global_char;          // (an integer round trip must not turn the pointer generic: flat_store)
+__device__ __forceinline__ global_char *wave_uniform_global(const void *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<global_char *>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
-    float *base = rows + (32 * ob + 4 * h) * 32 + j;       // one address per tile; the 16 rows are immediate offsets
+    global_char *base = wave_uniform_global(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));                          // (keeps the zero-extension at the access)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * 32] = t[r];
+    for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<__attribute__((address_space(1))) float *>(base + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = t[r];
 }
 
 // Bit r = (t[r] > 0) for ReLU outputs (t >= 0, so "> 0" is "bit pattern != 0"; -0.0 cannot occur after fmaxf(x, 0)

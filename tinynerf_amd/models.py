@@ -47,6 +47,17 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
     return d
 
 
+def _bucket(n: int) -> int:
+    """n rounded up to 1/8-octave steps (<= 12.5 % more).  Dynamic batches move N by a few percent every step; a workspace
+    sized to N exactly (10 KB per sample for the Vanilla stack: 11 GB) gives the caching allocator a new size at every record
+    high of N, each answered by a fresh hipMalloc in the middle of the step (measured: 240 ms stalls, 70 GiB reserved after 15
+    steps) while the smaller blocks stay cached.  Bucketed sizes are re-used."""
+    if n <= 64:
+        return 64
+    g = 1 << max(n.bit_length() - 4, 0)
+    return (n + g - 1) // g * g
+
+
 class _FusedMLP(Function):
     """y = act(MLP(enc(x, aux))) in one launch; in training the forward also writes the activation workspace the backward
     consumes (tn_mlp_fwd_stash), otherwise the backward recomputes the hidden activations."""
@@ -69,7 +80,7 @@ class _FusedMLP(Function):
         if _FusedMLP.stash_forward and any(ctx.needs_input_grad) and n > 0:
             wsfn = L.lib().tn_mlp_bwd_workspace_bytes
             wsfn.restype = C.c_int64
-            ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
+            ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, device=dev)
             L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
@@ -96,7 +107,7 @@ class _FusedMLP(Function):
         gx = torch.empty_like(x2) if want_gx else None
         wsfn = L.lib().tn_mlp_bwd_workspace_bytes
         wsfn.restype = C.c_int64
-        ws_bytes = int(wsfn(C.byref(desc), C.c_int64(n)))
+        ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))
         ws = ws_fwd if ws_fwd is not None else (torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None)
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))

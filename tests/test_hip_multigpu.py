@@ -4,7 +4,9 @@
   (TN_MLP_WGRAD_ONLY) -- against the one-shot tn_mlp_bwd_pair;
 * two ranks sharing one GPU (gloo rendezvous on 127.0.0.1, CUDA tensors) run the real ``Trainer.step()`` on disjoint
   halves of a ray set; loss, every reduced ``param.grad`` before Adam and the occupancy grids equal one rank that
-  processes the union of the two ranks' batches.
+  processes the union of the two ranks' batches;
+* the same exchange path over the real backend: a one-rank RCCL group on this GPU under a Trainer told world_size = 2 (every
+  collective issued and awaited as on 8 GPUs, every sum the identity) equals the plain 1-rank step.
 """
 import ctypes as C
 import os
@@ -221,3 +223,67 @@ def test_two_ranks_equal_one_rank_on_the_union(method):
     assert not any(r["pending"] for rank in range(2) for r in res[rank])           # every early all-reduce was awaited
     if method == "kplanes":      # the fused node handed its plane gradients over mid-backward (CHAIN_ONLY -> scatter -> WGRAD_ONLY) every step
         assert all(res[rank][-1]["early_calls"] == N_STEPS for rank in range(2))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _rccl_main(port, method, q):
+    """The N > 1 step over the REAL backend: a one-rank RCCL ("nccl") group on this GPU, a Trainer told world_size = 2 -- every
+    collective of the exchange path (global ray count + gate, early per-plane all-reduces started inside the backward pass on
+    RCCL's stream while the weight-gradient kernels run, the bucket, the loss) is issued and awaited exactly as on 8 GPUs; with
+    one rank in the group each sum is the identity, so the result must equal the plain 1-rank step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", TORCH_NCCL_HIGH_PRIORITY="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device(DEV, 0)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from tinynerf_amd.run import Trainer
+    o, d, rgb = _scene()
+    out = {}
+    for world in (1, 2):
+        tr = Trainer(_cfg(method), o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev, rank=0, world_size=world)
+        _no_dropout(tr)
+        _half_empty_grid(tr)
+        cap = {}
+        tr.grad_hook = lambda t, cap=cap: cap.__setitem__("g", {k: p.grad.detach().clone() for k, p in t.renderer.named_parameters()})
+        calls = [0]
+        if world > 1:
+            ready = tr._planes_ready
+
+            def counted(grads, ready=ready, calls=calls):
+                calls[0] += 1
+                ready(grads)
+            tr._planes_ready = counted
+        steps = []
+        for _ in range(N_STEPS):
+            st = tr.step()
+            steps.append((int(st["n_samples"]), {k: v.cpu().numpy() for k, v in cap["g"].items()}, len(tr._early)))
+        torch.cuda.synchronize()
+        out[world] = dict(steps=steps, params={k: p.detach().cpu().numpy() for k, p in tr.renderer.named_parameters()}, early_calls=calls[0])
+    q.put(out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("method", ["kplanes", "cobafa"])
+def test_exchange_path_over_rccl_with_one_rank(method):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_main, args=(_free_port(), method, q))
+    p.start()
+    out = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    one, two = out[1], out[2]
+    for step in range(N_STEPS):
+        assert one["steps"][step][0] == two["steps"][step][0]                     # same batches
+        assert two["steps"][step][2] == 0                                         # every early all-reduce was awaited
+        for k, ref in one["steps"][step][1].items():
+            got = two["steps"][step][1][k]
+            # same kernels on the same batch; the MSE scale is a device scalar instead of a host float, plane / grid sums are atomics
+            nrm = float(np.linalg.norm(ref.astype(np.float64)))
+            assert float(np.linalg.norm((got - ref).astype(np.float64))) <= (2e-5 if step == 0 else 5e-3) * max(nrm, 1e-30), (k, step)
+    for k, ref in one["params"].items():
+        np.testing.assert_allclose(two["params"][k], ref, rtol=0, atol=2e-2 * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
+    if method == "kplanes":
+        assert two["early_calls"] == N_STEPS

@@ -24,6 +24,7 @@ class _Stub:
         self._plane_of = {id(renderer.plane): 0}
         self._reduce_rows, self._reduce_rows_prev = [(16, 100)], [(10, 80)]
         self._reduce_view = lambda g, plane: Trainer._reduce_view(self, g, plane)
+        self._flat, self._flat_used, self._flat_ids = None, 0, set()       # filled by the worker: small gradients as views of one bucket
 
 
 def _make_model():
@@ -36,7 +37,7 @@ def _make_model():
     return m
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, flat=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from tinynerf_amd.run import Trainer
@@ -51,6 +52,10 @@ def _worker(rank, world, port, q):
     loss = Trainer.global_mse(stub, rendered, target)
     for p in m.parameters():
         p.grad = torch.zeros_like(p)
+    if flat:                                              # the harness: every small gradient is a view into one flat bucket
+        stub._flat, stub._flat_used, stub._flat_ids = Trainer._flat_small_grads(list(m.parameters()), stub.device)
+        assert stub._flat_ids == {id(p) for p in (m.lin.weight, m.lin.bias, m.head.weight, m.head.bias)}
+        assert all(p.grad.data_ptr() % 256 == stub._flat.data_ptr() % 256 for p in m.lin.parameters())
     loss.backward()
     with torch.no_grad():
         m.plane.grad[:, :, :10] = 0; m.plane.grad[:, :, 100:] = 0     # outside the live rows the gradient is zero on every rank
@@ -63,19 +68,29 @@ def _worker(rank, world, port, q):
     assert view.shape == (1, 90, 128, 32) and view.is_contiguous() and view.data_ptr() == m.plane.grad[:, :, 10:].data_ptr()
     Trainer._planes_ready(stub, [m.plane.grad])          # the fused node starts the plane all-reduces mid-backward
     assert len(stub._early) == 1
-    Trainer.all_reduce_grads(stub)                        # ... which are awaited here, everything else is reduced now
-    assert not stub._early
+    # the "Empty iteration" gate rides with the bucket: rank 0's step reached nothing, rank 1's did -> not empty anywhere
+    gate = torch.tensor([0.0 if rank == 0 else 0.7])
+    Trainer.all_reduce_grads(stub, gate)                  # ... which are awaited here, everything else is reduced now
+    assert not stub._early and float(gate) > 0
+    # a second exchange with every rank's step empty: the gate stays 0.  (Each rank holds the sum S already: 0.5 S + 0.5 S = S,
+    # exactly, so the gradients compared below are unchanged; this time the plane goes through the non-early branch.)
+    gate0 = torch.zeros(1)
+    for p_ in m.parameters():
+        p_.grad.mul_(0.5)
+    Trainer.all_reduce_grads(stub, gate0)
+    assert float(gate0) == 0.0
     q.put((rank, float(loss.detach()), {k: p.grad.detach().contiguous().numpy().copy() for k, p in m.named_parameters()}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_gradient_exchange_equals_single_process():
+@pytest.mark.parametrize("flat", [True, False])
+def test_two_rank_gradient_exchange_equals_single_process(flat):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, flat)) for r in range(2)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
     for p in procs: p.join(timeout=30)

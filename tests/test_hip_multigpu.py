@@ -176,7 +176,7 @@ def test_two_ranks_equal_one_rank_on_the_union(method):
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, method, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=500) for _ in procs)
+    res = dict(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)

@@ -98,6 +98,9 @@ class Trainer:
         params = list(self.renderer.parameters())
         for p in params:                                # grads keep the parameter's (channels_last) layout
             p.grad = torch.zeros_like(p)
+        # N > 1: every small gradient is a view into ONE flat buffer, all-reduced in place as a single bucket (no cat / copy
+        # kernels); its last slot carries the step's "Empty iteration" gate through the same collective
+        self._flat, self._flat_used, self._flat_ids = Trainer._flat_small_grads(params, device) if world_size > 1 else (None, 0, set())
         self.renderer.accumulate_into_grad = True       # fused path adds into these buffers directly
         self.renderer.reuse_buffers = True              # and keeps its scratch in a capacity-based arena
         self._arena: Dict[str, torch.Tensor] = {}
@@ -221,6 +224,10 @@ class Trainer:
             # same jitter on every rank (identical grids without communication); a dedicated seed, not the global RNG
             self.occupancy_grid.update(self.sigma_fn, jitters=jit, seed=(cfg.seed * 7919 + 104729 * (self.train_step + 1)) % (2 ** 62))
             self._refresh_reduce_rows()
+        ray_count = None
+        if self.world > 1:                 # global ray count of the step (see global_ray_count): travels during the forward pass
+            ray_count = torch.full((1,), float(info.size(0)), device=self.device)
+            ray_count_done = torch.distributed.all_reduce(ray_count, async_op=True)
         rendered = self.renderer(packed, info)                                    # run.py:251
         if self.prefetch if prefetch is None else prefetch:
             self._launch_plan()            # next step's sampler pass runs between this forward and backward
@@ -236,8 +243,8 @@ class Trainer:
         if self.world == 1:
             inv, inv_dev = 1.0 / (3.0 * R), None
         else:                                                                     # MSE over ALL ranks' rays (see global_ray_count)
-            tot = self.global_ray_count(R, gate)
-            inv, inv_dev = 1.0, (1.0 / (3.0 * tot)).reshape(1).float()
+            ray_count_done.wait()
+            inv, inv_dev = 1.0, (1.0 / (3.0 * ray_count)).float()
         L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
         rendered.backward(grad)
@@ -249,7 +256,7 @@ class Trainer:
             plane_reg = {"spec": spec, "upstream": cfg.grad_scale, "sums": acc[1:]}
         self._loss_parts = (acc, inv, inv_dev, reg_coef)
         if self.world > 1:
-            self.all_reduce_grads()
+            self.all_reduce_grads(gate)
         if self.grad_hook is not None:
             self.grad_hook(self)
         self.optimizer.step(plane_reg=plane_reg, gate=gate)
@@ -348,32 +355,88 @@ class Trainer:
         r0, r1 = (min(a0, b0), max(a1, b1)) if a1 > a0 and b1 > b0 else ((a0, a1) if a1 > a0 else (b0, b1))
         return flat[:, r0:r1] if r1 > r0 else flat[:, :0]            # flat: [1, H, W, C] in memory order
 
+    @staticmethod
+    def _all_reduce_many(views):
+        """In-place all-reduce of several dense tensors as ONE collective call (the backend's coalesced all-reduce: one grouped
+        RCCL launch instead of one launch -- and 5-20 us of host time beside an idle GPU -- per tensor); returns a waitable."""
+        views = [v for v in views if v.numel()]
+        if not views:
+            return None
+        if len(views) == 1:
+            return torch.distributed.all_reduce(views[0], async_op=True)
+        if torch.distributed.get_backend() != "nccl" and views[0].is_cuda:      # (gloo's coalesced form takes CPU tensors only)
+            works = [torch.distributed.all_reduce(v, async_op=True) for v in views]
+
+            class _All:
+                def wait(self_inner):
+                    for w in works:
+                        w.wait()
+            return _All()
+        with torch.distributed._coalescing_manager(async_ops=True) as cm:
+            for v in views:
+                torch.distributed.all_reduce(v)
+        return cm
+
     def _planes_ready(self, grads) -> None:
         """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are
-        final: their all-reduces start here and travel while the heads' weight gradients are still being computed."""
+        final: their all-reduce starts here and travels while the heads' weight gradients are still being computed."""
+        views, ptrs = [], []
         for i, g in enumerate(grads):
             flat = self._reduce_view(g, i if self._plane_of else None)
             if flat is not None:
-                self._early[g.data_ptr()] = torch.distributed.all_reduce(flat, async_op=True) if flat.numel() else None
+                views.append(flat)
+                ptrs.append(g.data_ptr())
+        work = Trainer._all_reduce_many(views)
+        for k, ptr in enumerate(ptrs):
+            self._early[ptr] = work if k == 0 else None          # one handle for the whole group
 
-    def all_reduce_grads(self) -> None:
+    @staticmethod
+    def _flat_small_grads(params, device):
+        """``p.grad`` of every small contiguous parameter as a 256-byte-aligned view into one flat zero buffer; returns
+        (buffer, floats in use including the trailing gate slot, ids of the parameters it covers)"""
+        small = [p for p in params if p.numel() < (1 << 18) and p.is_contiguous()]
+        offs, off = [], 0
+        for p in small:
+            offs.append(off)
+            off = (off + p.numel() + 63) // 64 * 64
+        flat = torch.zeros(off + 64, device=device)
+        for p, o in zip(small, offs):
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        return flat, off + 1, {id(p) for p in small}
+
+    def all_reduce_grads(self, gate: Optional[torch.Tensor] = None) -> None:
         """Sum gradients over ranks with RCCL.  Large plane gradients go as individual in-place all-reduces
         (each drives all xGMI peers; started early by ``_planes_ready`` when the fused path is in use); everything
-        small is packed into one bucket."""
-        small, handles = [], [h for h in self._early.values() if h is not None]
+        small lives in one flat buffer (``_flat``) and travels as ONE in-place all-reduce, together with the step's
+        "Empty iteration" gate (in place: > 0 afterwards iff some rank's step reached a parameter -- the step on the union of all
+        ranks' rays is empty only when every rank's is)."""
+        small, large, handles = [], [], [h for h in self._early.values() if h is not None]
         early, self._early = self._early, {}
         for p in self.renderer.parameters():
-            if p.grad is None:
+            if p.grad is None or id(p) in self._flat_ids:
                 continue
             if p.grad.data_ptr() in early:
                 continue
             flat = self._reduce_view(p.grad, self._plane_of.get(id(p)))
-            if flat is not None:                 # large and dense in memory: its own in-place all-reduce (live rows only)
-                if flat.numel():
-                    handles.append(torch.distributed.all_reduce(flat, async_op=True))
+            if flat is not None:                 # large and dense in memory: reduced in place (live rows only)
+                large.append(flat)
             else:
                 small.append(p.grad)
-        if small:
+        work = Trainer._all_reduce_many(large)
+        if work is not None:
+            handles.append(work)
+        if self._flat is not None:
+            slot = self._flat[self._flat_used - 1:self._flat_used]
+            if gate is not None:
+                torch.sign(gate, out=slot)               # gate = the step's largest weight >= 0 (rewritten every step: no clearing)
+            torch.distributed.all_reduce(self._flat[:self._flat_used])
+            if gate is not None:
+                gate.copy_(slot)
+        elif gate is not None:
+            flag = (gate > 0).float()
+            torch.distributed.all_reduce(flag)
+            gate.copy_(flag)
+        if small:                                # (small tensors that are not views of the flat buffer: none in the harness)
             bucket = torch.cat([g.reshape(-1) for g in small])
             torch.distributed.all_reduce(bucket)
             off = 0

@@ -168,21 +168,35 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__
                                                        int off_g, float *__restrict__ stash)
 {
     // [32 samples][out] block of gy -> [out][32 samples] rows through LDS: both sides of the transposition are coalesced
-    __shared__ float t[32][257];
+    // (16-byte loads along a sample's row when `out` allows it, no integer division in the index arithmetic)
+    constexpr int TS = 260;                                 // row stride (floats): 16-byte aligned, 4 (mod 64) banks apart
+    __shared__ __attribute__((aligned(16))) float t[32 * TS];
     const int64_t n_tiles = (n + 31) >> 5;
     const int j = threadIdx.x & 31, sub = threadIdx.x >> 5;                 // 8 row slots per block
+    const bool vec = (out & 3) == 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         float *g = stash + (tile * (int64_t)rows_total + off_g) * 32;
         const int64_t r0 = tile * 32;
         for (int c0 = 0; c0 < out; c0 += 256) {                   // 256 output columns per pass through the LDS tile
             const int cw = min(out - c0, 256);
-            for (int e = threadIdx.x; e < 32 * cw; e += 256) {
-                const int r = e / cw, c = e - r * cw;
-                t[r][c] = r0 + r < n ? gy[(r0 + r) * out + c0 + c] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = sub + 8 * rr;
+                const bool rok = r0 + r < n;
+                const float *src = gy + (r0 + (rok ? r : 0)) * out + c0;
+                for (int c = 4 * j; c < cw; c += 128) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (vec) { if (rok) v = *reinterpret_cast<const f32x4 *>(src + c); }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (rok && c + u < cw) v[u] = src[c + u];
+                    }
+                    *reinterpret_cast<f32x4 *>(t + r * TS + c) = v;
+                }
             }
             __syncthreads();
             for (int f = sub; f < cw; f += 8) {
-                float v = t[j][f];
+                float v = t[j * TS + f];
                 if (out_act != TN_ACT_NONE) v *= act_grad(g[(c0 + f) * 32 + j], out_act);       // buffer A holds the pre-activation
                 g[(c0 + f) * 32 + j] = v;
             }

@@ -144,7 +144,30 @@ def cpu_baseline(trainer, n_target: int):
         t = min(times[1:])
         if best is None or t < best:
             best, cores = t, threads
-    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port",
+    # the other two stages of SURVEY 8(d), same thread count: render forward alone, and the sampler (numpy restatement of
+    # core.py:165-188, one loader batch of 1024 rays x 1024 candidates against the same occupancy grid)
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        p0 = {k: v for k, v in sd.items()}
+        tp.render(p0, packed, info, bg)
+        t0 = time.perf_counter()
+        tp.render(p0, packed, info, bg)
+        t_fwd = time.perf_counter() - t0
+    from oracle import tinynerf_oracle as orc
+    g = trainer.occupancy_grid
+    pick = torch.randint(0, trainer.rays_o.size(0), (1024,), generator=torch.Generator().manual_seed(0)).to(trainer.rays_o.device)
+    o_cpu, d_cpu = trainer.rays_o[pick].cpu().numpy(), trainer.rays_d[pick].cpu().numpy()
+    aabb = np.array([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]], np.float32)
+    kw = dict(marcher="aabb", contraction="aabb", grid=g.grid.cpu().numpy(), threshold=float(g.threshold), n_samples=trainer.cfg.n_samples,
+              near=0.1, aabb=aabb)
+    orc.ray_provider(o_cpu[:64], d_cpu[:64], **kw)
+    t0 = time.perf_counter()
+    pk, _ = orc.ray_provider(o_cpu, d_cpu, **kw)
+    t_samp = time.perf_counter() - t0
+    stages = {"render_fwd_samples_per_s": n / t_fwd, "sampler_samples_per_s": pk.shape[0] / t_samp,
+              "sampler_candidates_per_s": 1024 * trainer.cfg.n_samples / t_samp,
+              "note": "render forward: torch CPU ops on the same sample; sampler: numpy restatement (single thread) on 1024 rays"}
+    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port", "stages": stages,
             "sample": f"render fwd+loss+bwd of {n} packed samples / {R} rays of the same batch (no Adam step), "
                       f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, {cores} threads (best of 32/64), best of 2 after warm-up"}
 

@@ -380,6 +380,13 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     dict(kind="mlp", K=24, H=256, layers=3, out=200, n=999),
     dict(kind="mlp", K=147, H=128, layers=3, out=288, n=500),  # output wider than H: KPlanesExplicitColorDecoder(96, 8, 128)
     dict(kind="mlp", K=40, H=64, layers=4, out=100, n=300),
+    # edge sizes of the persistent layer kernels (weights in registers, tiles through LDS): one sample, one tile + one sample,
+    # fewer tiles than tile streams per workgroup (H = 128 runs two streams), an odd number of tiles
+    dict(kind="mlp", K=36, H=128, layers=3, out=128, n=1),
+    dict(kind="mlp", K=36, H=128, layers=3, out=128, n=33),
+    dict(kind="mlp", K=36, H=128, layers=3, out=96, n=65),
+    dict(kind="vanilla", F=10, H=256, layers=2, n=1),
+    dict(kind="vanilla", F=10, H=256, layers=3, n=33),
 ])
 @pytest.mark.parametrize("stash,seed", [(True, 11), (False, 11), (True, 12), (True, 13)])
 def test_wide_deep_mlp_backward_vs_torch(cfg, stash, seed, monkeypatch):

@@ -186,3 +186,31 @@ def test_train_entry_point_on_a_scene_on_disk(tmp_path):
     sd = torch.load(out / "model.pt")
     assert "feature_module.planes.0.0.plane" in sd and "rgb_decoder.net.net.5.weight" in sd
     tr.renderer.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("method", ["vanilla", "kplanes", "cobafa"])
+def test_inference_chunking_and_no_training_state(method):
+    """infer(): rays are independent, so the chunk size must not change one output bit (the default walks an image in 2^16-ray
+    chunks instead of the reference's training batch size, run.py:35-43); and inside torch.no_grad() no module may take its
+    training forward (the wide stacks' activation workspace is 10 KB per sample)."""
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    dev = torch.device(DEV)
+    cfg = TrainConfig(method=method, scene_type="aabb", batch_size=128, n_samples=64, seed=5, occupancy_res=32)
+    tr = Trainer(cfg, o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev)
+    for _ in range(2):
+        tr.step()
+    oo, dd = o[:6000].to(dev), d[:6000].to(dev)
+    a = tr.render_rays(oo, dd, batch_size=100)                       # ragged last chunk
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    b = tr.render_rays(oo, dd)                                        # default: one chunk here
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    n_kept = int(tr.ray_provider(oo, dd, training=False)[0].size(0))
+    assert n_kept > 10000
+    # packed samples, features, head outputs: under 3 KB per kept sample (+ 16 MiB of per-ray scratch); the training workspace
+    # of the Vanilla stack alone would be 10.5 KB per sample
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < n_kept * 3072 + (16 << 20), (peak / n_kept, n_kept)

@@ -77,7 +77,9 @@ class _FusedMLP(Function):
         y = torch.empty((n, ps[-1].numel()), device=dev)
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
-        if _FusedMLP.stash_forward and any(ctx.needs_input_grad) and n > 0:
+        # (inside torch.no_grad() -- infer(), the occupancy refresh -- needs_input_grad still reports the parameters' flags:
+        # the stash-writing forward must also ask whether a graph is being recorded at all)
+        if _FusedMLP.stash_forward and torch.is_grad_enabled() and any(ctx.needs_input_grad) and n > 0:
             wsfn = L.lib().tn_mlp_bwd_workspace_bytes
             wsfn.restype = C.c_int64
             ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))

@@ -736,3 +736,24 @@ def test_mlp_forward_row_gate_skips_dead_tiles_only():
     assert torch.equal(y1[live], y0[live])
     assert float(y1[64:192].abs().max()) == 0.0 and float(y1[992:].abs().max()) == 0.0
     assert torch.equal(y1[200:210], y0[200:210])          # dead rows of a live tile are still evaluated (harmless)
+
+
+def test_fused_mlp_takes_the_stash_forward_only_while_recording(monkeypatch):
+    """training: the forward writes the backward's activation workspace (tn_mlp_fwd_stash: nothing is recomputed); inside
+    torch.no_grad() (infer(), the occupancy refresh) the plain forward runs and no workspace is allocated.  (Inside
+    Function.forward grad mode is always off and needs_input_grad always reports the parameters: the call site decides.)"""
+    m = models()
+    from tinynerf_amd import _lib as L
+    names = []
+    orig = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1])
+    net = m.VanillaFeatureMLP(10, 256, 3).to(DEV)
+    x = torch.rand(500, 3, device=DEV) * 2 - 1
+    y = net(x)
+    assert names == ["tn_mlp_fwd_stash"]
+    y.sum().backward()
+    assert names == ["tn_mlp_fwd_stash", "tn_mlp_bwd"]
+    del names[:]
+    with torch.no_grad():
+        y2 = net(x)
+    assert names == ["tn_mlp_fwd"] and torch.equal(y2, y.detach())

@@ -66,7 +66,7 @@ class _FusedMLP(Function):
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
-                n_freqs: int, out_act: int, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                n_freqs: int, out_act: int, recording: bool, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.size(-1)).to(torch.float32).contiguous()
         aux2 = None if aux is None else aux.reshape(-1, aux.size(-1)).to(torch.float32).contiguous()
@@ -77,9 +77,9 @@ class _FusedMLP(Function):
         y = torch.empty((n, ps[-1].numel()), device=dev)
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
-        # (inside torch.no_grad() -- infer(), the occupancy refresh -- needs_input_grad still reports the parameters' flags:
-        # the stash-writing forward must also ask whether a graph is being recorded at all)
-        if _FusedMLP.stash_forward and torch.is_grad_enabled() and any(ctx.needs_input_grad) and n > 0:
+        # `recording` = torch.is_grad_enabled() at the call site: inside torch.no_grad() (infer(), the occupancy refresh)
+        # needs_input_grad still reports the parameters' flags, and inside Function.forward grad mode is always off
+        if _FusedMLP.stash_forward and recording and any(ctx.needs_input_grad) and n > 0:
             wsfn = L.lib().tn_mlp_bwd_workspace_bytes
             wsfn.restype = C.c_int64
             ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))
@@ -114,7 +114,7 @@ class _FusedMLP(Function):
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
-        return (gx_out, None, None, None, None, None, *grads)
+        return (gx_out, None, None, None, None, None, None, *grads)
 
 
 def _linear_params(net: torch.nn.Sequential) -> List[torch.Tensor]:
@@ -155,7 +155,7 @@ class MLP(torch.nn.Module):
 
     def fused(self, x: torch.Tensor, aux: Optional[torch.Tensor] = None, encoding: int = L.ENC_NONE, n_freqs: int = 0,
               out_act: int = L.ACT_NONE, freqs: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, *self.params())
+        return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, torch.is_grad_enabled(), *self.params())
 
     def forward(self, x: torch.Tensor):
         return self.fused(x)

@@ -214,3 +214,26 @@ def test_inference_chunking_and_no_training_state(method):
     # of the Vanilla stack alone would be 10.5 KB per sample
     peak = torch.cuda.max_memory_allocated() - base
     assert peak < n_kept * 3072 + (16 << 20), (peak / n_kept, n_kept)
+
+
+def test_random_ray_stream_walks_shuffled_epochs():
+    """run.py:116-122: DataLoader(shuffle=True) -- every ray exactly once per epoch, in loader batches of B; the device-side
+    stream (Trainer._epoch_block) must consume its permutation without gaps or repeats across steps, block redraws and the
+    epoch boundary."""
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    dev = torch.device(DEV)
+    n = o.size(0)
+    tag = torch.zeros(n, 3)
+    tag[:, 0] = torch.arange(n, dtype=torch.float32)                  # the target colour carries the ray index
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=128, n_samples=32, seed=9, occupancy_res=32, kplanes_resolutions=(16, 32, 64))
+    tr = Trainer(cfg, o.to(dev), d.to(dev), tag.to(dev), torch.ones(3, device=dev), dev)
+    seen = []
+    while sum(len(s) for s in seen) < 2 * n + 1000:
+        packed, info, target, k = tr.build_batch()
+        assert info.size(0) == k * cfg.batch_size
+        seen.append(target[:, 0].long().cpu())
+    seen = torch.cat(seen)
+    for e in range(2):                                                # two full epochs: each a permutation of all rays
+        assert torch.equal(torch.sort(seen[e * n:(e + 1) * n]).values, torch.arange(n))
+    assert not torch.equal(seen[:n], seen[n:2 * n])                   # reshuffled

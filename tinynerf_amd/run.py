@@ -111,6 +111,8 @@ class Trainer:
             gamma=0.33)
         self.train_step = 0
         self._cursor = 0                 # deterministic mode: position in the ray table
+        self._perm: Optional[torch.Tensor] = None      # random mode: the current shuffled epoch(s) of ray indices ...
+        self._perm_pos = 0                             # ... and the position of the next loader batch in it
         self._k_guess = 8
         # per-rank ray stream: same generator family, different seed -> disjoint draws
         self._gen = torch.Generator(device=device)
@@ -141,6 +143,20 @@ class Trainer:
         return t[:numel].view(*shape)
 
     # ------------------------------------------------------------------ a8: dynamic batch
+    def _epoch_block(self, m: int) -> torch.Tensor:
+        """The next ``m`` ray indices of the shuffled stream: the reference's ``DataLoader(shuffle=True)`` (run.py:116-122) walks a
+        fresh permutation of all rays per epoch -- every ray once per epoch, no replacement -- in loader batches of B; here the
+        permutation lives on the device (``torch.randperm`` from the trainer's own generator) and a step consumes the k batches
+        its dynamic batch took (``_perm_pos`` advances by R in build_batch; a block that is redrawn larger starts at the same place)."""
+        if self._perm is None or self._perm_pos + m > self._perm.numel():
+            chunks = [] if self._perm is None else [self._perm[self._perm_pos:]]
+            have = sum(c.numel() for c in chunks)
+            while have < m:
+                chunks.append(torch.randperm(self.rays_o.size(0), device=self.device, generator=self._gen))
+                have += chunks[-1].numel()
+            self._perm, self._perm_pos = torch.cat(chunks), 0
+        return self._perm[self._perm_pos:self._perm_pos + m]
+
     @torch.no_grad()
     def _launch_plan(self, n_b: Optional[int] = None) -> None:
         """First half of the dynamic-batch rule (run.py:215-244): draw a block of rays, count their live samples
@@ -157,7 +173,7 @@ class Trainer:
         if cfg.deterministic:
             idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
         else:
-            idx = torch.randint(0, self.rays_o.size(0), (n_b * B,), device=dev, generator=self._gen)
+            idx = self._epoch_block(n_b * B)
         o, d = self.rays_o[idx], self.rays_d[idx]
         desc = self.ray_provider._desc(dev, not cfg.deterministic, None)
         desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
@@ -190,6 +206,8 @@ class Trainer:
             self._k_guess = pend["n_b"] * 2             # not enough rays drawn: redraw a larger block
         self._k_guess = k
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
+        if not self.cfg.deterministic:
+            self._perm_pos += R
         info = self._buf("info", (R, 2), torch.int32)
         total = self._buf("total", (1,), torch.int32)
         L.call("tn_sample_scan", dev, L.ptr(pend["counts"]), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))

@@ -352,9 +352,18 @@ def main():
             else:       # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
                 lanes = pmc["lane_atomics_per_entry"].get(tag) if pmc else None
                 ach = lanes / sec / 1e9 if lanes else None
-                r.update(bound="atomic", achieved=ach, peak=PEAK_ATOMIC_GLANES, unit="G lane-atomics/s",
-                         frac=ach / PEAK_ATOMIC_GLANES if ach else None, lane_atomics_per_launch=lanes,
-                         mfma_tflops=tflops, mfma_frac=tflops / PEAK_FP32_MFMA_TFLOPS if tflops else None)
+                # the contract's two rooflines first (this launch also carries both heads' data-gradient MFMAs: bound "mfma" with
+                # the algorithmic FLOP), then what actually limits it: the chip's memory-side atomic rate
+                if tflops:
+                    r.update(bound="mfma", achieved=tflops, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=tflops / PEAK_FP32_MFMA_TFLOPS)
+                else:           # the stand-alone scatter has no matrix work: HBM-side bytes of the PMC pass against the HBM peak
+                    gbs = traffic / sec / 1e9 if traffic else None
+                    r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS if gbs else None)
+                r.update(
+                         co_bound={"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
+                                   "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
+                                   "note": "memory-side fp32 atomics of the plane scatter (full-line requests); peak = "
+                                           "scripts/microbench/atomic_patterns.hip; this is the limit the launch runs at"})
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
             return r

@@ -99,3 +99,21 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_workspace_buckets():
+    """host logic: workspace sizes are requested in 1/8-octave steps (models._bucket) -- monotone, never below n, at most 12.5 %
+    above it, and a stream of slowly drifting batch sizes maps to a handful of distinct sizes (the caching allocator re-uses
+    them instead of growing at every record high)."""
+    from tinynerf_amd.models import _bucket
+    prev = 0
+    for n in list(range(1, 3000)) + [10 ** 6 + 7919 * i for i in range(200)] + [2 ** 20, 2 ** 20 + 1, 2 ** 31 - 1]:
+        b = _bucket(n)
+        assert b >= n and (b <= n * 1.125 + 64)
+        if n > prev:
+            assert b >= _bucket(prev) if prev else True
+        prev = n
+    import random
+    rng = random.Random(0)
+    sizes = {_bucket(int(1.03e6 * (1 + 0.02 * rng.gauss(0, 1)))) for _ in range(5000)}
+    assert len(sizes) <= 3

@@ -301,7 +301,11 @@ def main():
             torch.nn.functional.mse_loss(tr.renderer(packed, info), target).backward()
         t_fb = timed(fwd_bwd)
         stages = {"sampler_samples_per_s": nb / t_samp, "render_fwd_samples_per_s": nb / t_fwd,
-                  "render_fwd_bwd_samples_per_s": nb / t_fb, "batch_samples": nb}
+                  "render_fwd_bwd_samples_per_s": nb / t_fb, "batch_samples": nb,
+                  # algorithmic FLOP of both heads over the stage time (the inference forward evaluates the colour head where
+                  # w > 0: every sample of this batch, random-init sigma never terminates a ray) against the fp32 MFMA peak
+                  "render_fwd_mfma_frac": FLOP_HEADS * nb / t_fwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                  "render_fwd_bwd_mfma_frac": 3 * FLOP_HEADS * nb / t_fb / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
     # the reference's other two model configurations on the same workload (BASELINE configs 2 and 5), N = 1 only: a short
     # run each, reported beside the headline (never part of `value`)

@@ -27,7 +27,7 @@ import os
 import sys
 import time
 
-import torch
+torch = None     # imported in main(), AFTER the launcher branch: the parent that starts the ranks never loads it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,30 +35,75 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
-PMC_PROFILE = "profiles/round2_pmc_traffic.json"   # scripts/pmc.sh + scripts/pmc_to_json.py (cannot be collected live)
+# counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
+PMC_PROFILES = ["profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
+MFMA_PROFILES = ["profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
 
 # algorithmic work per unit of the kernels that can dominate
 FLOP_SIGMA_FWD = 2 * (96 * 64 + 64)                                   # 12 416   
 FLOP_RGB_FWD = 2 * (147 * 64 + 3 * 64 * 64 + 64 * 3)                  # 43 776   
 FLOP_HEADS = FLOP_RGB_FWD + FLOP_SIGMA_FWD                            # 56 192
+# the data gradient of the colour head's first layer stops at the 96 feature columns: its 51 per-ray columns [PE(d), d]
+# are inputs, not parameters (models.py:87), so W_0^T G_0 is 96 x 64, not 147 x 64 -> 2 * 51 * 64 = 6 528 FLOP less
+FLOP_HEADS_DGRAD = FLOP_HEADS - 2 * 51 * 64                           # 49 664 (= 383 MFMAs per 32-sample tile: the MFMA_BUSY count)
+FLOP_STEP = FLOP_HEADS + FLOP_HEADS_DGRAD + FLOP_HEADS                # forward + data gradient + weight gradient = 162 048
 KERNEL_MODEL = {
     # timed tag              (bound, unit work per row, what a row is, kernels of the launch)
     "tn_mlp_bwd:rgb": ("mfma", 2 * FLOP_RGB_FWD, "active sample", "chain + weight-gradient kernels of the colour head"),
     "tn_mlp_bwd:sigma": ("mfma", 2 * FLOP_SIGMA_FWD, "sample", "chain + weight-gradient kernels of the sigma head"),
     "tn_mlp_fwd:rgb": ("mfma", FLOP_RGB_FWD, "active sample", "mlp_fwd_kernel"),
     "tn_mlp_fwd:sigma": ("mfma", FLOP_SIGMA_FWD, "sample", "mlp_fwd_kernel"),
-    "tn_mlp_bwd_pair": ("mfma", 2 * FLOP_HEADS, "sample", "mlp_chain_kernel + mlp_wgrad4_kernel + mlp_wgrad_kernel"),
+    "tn_mlp_bwd_pair": ("mfma", FLOP_HEADS_DGRAD + FLOP_HEADS, "sample", "mlp_chain_kernel + mlp_wgrad4_kernel + mlp_wgrad_kernel"),
     "tn_mlp_fwd_stash_pair": ("mfma", FLOP_HEADS, "sample", "mlp_fwd_kernel (both heads)"),
     # gather + both heads' training forward in one kernel: MFMA-bound (36 texel lines per sample ride under the MFMAs)
     "tn_kplanes_mlp_fwd_pair": ("mfma", FLOP_HEADS, "sample", "mlp_fwd_kernel<..., KP> (gather + both heads, one kernel)"),
     # data-gradient chain of both heads + the scatter into the nine plane gradients in one kernel: bound by the rate of
     # memory-side fp32 atomics (the lane-atomic count per launch comes from the PMC pass: WRITE_SIZE / 4 B)
-    "tn_kplanes_mlp_bwd_pair:chain": ("atomic", FLOP_HEADS, "sample", "mlp_chain_kernel<..., KP> (both chains + plane scatter, one kernel)"),
+    "tn_kplanes_mlp_bwd_pair:chain": ("atomic", FLOP_HEADS_DGRAD, "sample", "mlp_chain_kernel<..., KP> (both chains + plane scatter, one kernel)"),
     "tn_kplanes_mlp_bwd_pair:wgrad": ("mfma", FLOP_HEADS, "sample", "mlp_wgrad4_kernel + mlp_wgrad_kernel"),
     "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample", "kplanes_fwd_kernel"),
     "tn_kplanes_bwd": ("atomic", 0, "sample", "kplanes_bwd_kernel"),
     "tn_adam_reg_multi": ("hbm", 32, "plane element", "adam_reg_multi_kernel (p, g, m, v in; p, g, m, v out)"),
 }
+
+
+# kernel-name prefixes (scripts/pmc_mfma.sh output) behind each timed tag, for the counter-derived matrix-pipe fraction
+MFMA_KERNELS = {
+    "tn_kplanes_mlp_fwd_pair": ["mlp_fwd_kernel<64, true, 12, true, true, true, true>"],
+    "tn_kplanes_mlp_bwd_pair:chain": ["mlp_chain_kernel<64, 4, 8, true, false, true, true>"],
+    "tn_kplanes_mlp_bwd_pair:wgrad": ["mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1"],
+}
+
+
+def load_first(paths):
+    for p in paths:
+        try:
+            return json.load(open(os.path.join(ROOT, p))), p
+        except Exception:       # noqa: BLE001
+            continue
+    return None, None
+
+
+def visible_gpus() -> int:
+    """GPUs of this node WITHOUT touching HIP or torch.cuda (the launcher parent must stay GPU-free: it starts the ranks):
+    KFD topology nodes with SIMDs, filtered by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are set."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return -1                   # unknown (no KFD here): trust --gpus, the children validate
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def parse():
@@ -70,6 +115,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rates (profiling runs)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 19)
+    ap.add_argument("--other-steps", type=int, default=8, help="steps per window of the Vanilla / Cobafa side runs")
+    ap.add_argument("--other-windows", type=int, default=3)
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the first one is the measurement")
     return ap.parse_args()
 
@@ -172,17 +219,98 @@ def cpu_baseline(trainer, n_target: int):
                       f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, {cores} threads (best of 32/64), best of 2 after warm-up"}
 
 
+def alloc_counters():
+    """device-allocator events so far: a hipMalloc inside a timed window is a 60-240 ms stall"""
+    st = torch.cuda.memory_stats()
+    return {"device_allocs": int(st.get("num_device_alloc", 0)), "alloc_retries": int(st.get("num_alloc_retries", 0)),
+            "segments": int(st.get("segment.all.current", 0)), "reserved_gb": st.get("reserved_bytes.all.current", 0) / 2 ** 30}
+
+
+def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows):
+    """One of the reference's other model configurations on the headline's workload: warm up until the scratch arenas and the
+    allocator have stopped growing, then `n_windows` windows of `steps` steps (synchronize on both sides); min / median over
+    the windows, every step's time from HIP events on the launch stream, and the allocator's counters over the timed region
+    (device_allocs_in_windows must be 0: a fresh hipMalloc in a step is a stall, not kernel time)."""
+    from tinynerf_amd.run import TrainConfig, Trainer
+    c2 = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
+    t2 = Trainer(c2, o, d, rgbs, torch.ones(3, device=dev), dev)
+    t2.occupancy_grid.grid.copy_(tr_main.occupancy_grid.grid)
+    t2.occupancy_grid.mean = float(t2.occupancy_grid.grid.mean().item())
+    t2.occupancy_grid_updates = 10 ** 9                      # the refresh schedule is part of the headline run only
+    warm, grown = 0, -1
+    while warm < 4 or (warm < 16 and (grown != arenas_grown(t2) or before != alloc_counters()["device_allocs"])):
+        grown, before = arenas_grown(t2), alloc_counters()["device_allocs"]
+        t2.step()
+        torch.cuda.synchronize()
+        warm += 1
+    a0 = alloc_counters()
+    stream = torch.cuda.current_stream(dev)
+    win_ms, step_ms, rate = [], [], []
+    for _ in range(n_windows):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        evs[0].record(stream)
+        n_ = 0.0
+        for i in range(steps):
+            n_ += t2.step()["n_samples"]
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        t_ = time.perf_counter() - t_
+        win_ms.append(t_ / steps * 1e3)
+        rate.append(n_ / t_)
+        step_ms += [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    a1 = alloc_counters()
+    srt = sorted(win_ms)
+    best = win_ms.index(srt[0])
+    out = {"ms_per_step": srt[len(srt) // 2], "samples_per_s": sorted(rate)[len(rate) // 2], "min_ms_per_step": srt[0],
+           "best_samples_per_s": rate[best], "windows_ms_per_step": win_ms, "steps_each": steps, "warmup_steps": warm,
+           "step_ms_events": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms)},
+           "device_allocs_in_windows": a1["device_allocs"] - a0["device_allocs"], "alloc_retries": a1["alloc_retries"],
+           "segments": a1["segments"], "reserved_gb": a1["reserved_gb"], "loss": t2.loss_value(),
+           "note": "ms_per_step / samples_per_s = median window; per-step times from HIP events on the launch stream"}
+    # width-256 / 128 stacks: algorithmic FLOP of the whole model (forward + data gradient + weight gradient) over the step
+    flop = model_flop_per_sample(t2.renderer)
+    if flop:
+        out["mfma_frac"] = flop * out["samples_per_s"] / 1e12 / PEAK_FP32_MFMA_TFLOPS
+        out["flop_per_sample_step"] = flop
+    del t2
+    return out
+
+
+def arenas_grown(trainer) -> int:
+    g = trainer.scratch.grown if hasattr(trainer, "scratch") else 0
+    a = trainer.renderer.__dict__.get("_arena")
+    return g + (a.grown if a is not None else 0) + getattr(trainer, "_arena_grown", 0)
+
+
+def model_flop_per_sample(renderer):
+    """2 * MACs of every Linear of the model per sample, x3 for forward + data gradient + weight gradient, minus the data
+    gradients nobody needs (first layers whose inputs are encodings of the sample position / ray direction)"""
+    lin = [m for m in renderer.modules() if isinstance(m, torch.nn.Linear)]
+    fwd = sum(2 * m.in_features * m.out_features for m in lin)
+    skip = 0
+    fm = renderer.feature_module
+    first = next((m for m in fm.modules() if isinstance(m, torch.nn.Linear)), None)
+    if first is not None and type(fm).__name__ == "VanillaFeatureMLP":
+        skip += 2 * first.in_features * first.out_features            # d / d PE(x): not needed
+    cd_first = next((m for m in renderer.rgb_decoder.modules() if isinstance(m, torch.nn.Linear)), None)
+    if cd_first is not None:
+        skip += 2 * 51 * cd_first.out_features                        # d / d [PE(d), d]: not needed
+    return 3 * fwd - skip
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as fresh child processes and
-    relay rank 0's JSON line.  The parent never touches the GPU (`torch.cuda.device_count()` does not initialise it
-    on this image), the children are plain `python bench.py` processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    relay rank 0's JSON line.  The parent never touches the GPU (no call under `torch.cuda`: GPUs are counted from the
+    KFD topology files), the children are plain `python bench.py` processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
     set -- the same environment `python -m torch.distributed.run` gives them.  Any failing rank fails the run."""
     import socket
     import subprocess
     n = args.gpus
-    visible = torch.cuda.device_count()
+    visible = visible_gpus()
     shared = os.environ.get("TN_BENCH_BACKEND", "nccl") != "nccl"
-    if visible < n and not shared:
+    if 0 <= visible < n and not shared:
         sys.stderr.write(f"bench.py --gpus {n}: only {visible} GPU(s) visible (TN_BENCH_BACKEND=gloo shares GPUs between "
                          f"ranks for debugging; its numbers are not scaling measurements)\n")
         return 2
@@ -212,6 +340,8 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
+    global torch
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -275,7 +405,9 @@ def main():
             stats[0] = tmax[0]
         return stats.tolist()
 
+    a0, g0 = alloc_counters()["device_allocs"], arenas_grown(tr)
     dt, samples, rays_n = window(True)            # THE measurement: `value`, `ms_per_step`, kernel events
+    alloc_w0, grown_w0 = alloc_counters()["device_allocs"] - a0, arenas_grown(tr) - g0
     loss = tr.loss_value()
     extra_windows = [window(False) for _ in range(max(0, args.windows - 1))]      # variance only
     window_ms = [dt / args.steps * 1e3] + [w[0] / args.steps * 1e3 for w in extra_windows]
@@ -305,39 +437,36 @@ def main():
                   # algorithmic FLOP of both heads over the stage time (the inference forward evaluates the colour head where
                   # w > 0: every sample of this batch, random-init sigma never terminates a ray) against the fp32 MFMA peak
                   "render_fwd_mfma_frac": FLOP_HEADS * nb / t_fwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                  "render_fwd_bwd_mfma_frac": 3 * FLOP_HEADS * nb / t_fb / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                  "render_fwd_bwd_mfma_frac": FLOP_STEP * nb / t_fb / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
-    # the reference's other two model configurations on the same workload (BASELINE configs 2 and 5), N = 1 only: a short
-    # run each, reported beside the headline (never part of `value`)
+    # the reference's other two model configurations on the same workload (BASELINE configs 2 and 5), N = 1 only, reported
+    # beside the headline (never part of `value`)
     others = None
     if rank == 0 and world == 1 and not args.no_stages:
         others = {}
         for method in ("vanilla", "cobafa"):
             try:
-                c2 = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
-                t2 = Trainer(c2, o, d, rgbs, torch.ones(3, device=dev), dev)
-                t2.occupancy_grid.grid.copy_(tr.occupancy_grid.grid)
-                t2.occupancy_grid.mean = float(t2.occupancy_grid.grid.mean().item())
-                t2.occupancy_grid_updates = 10 ** 9                      # the refresh schedule is part of the headline run only
-                for _ in range(3):
-                    t2.step()
-                torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                n_ = sum(t2.step()["n_samples"] for _ in range(8))
-                torch.cuda.synchronize()
-                t_ = time.perf_counter() - t_
-                others[method] = {"ms_per_step": t_ / 8 * 1e3, "samples_per_s": n_ / t_, "loss": t2.loss_value()}
-                del t2
-                torch.cuda.empty_cache()
+                others[method] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
                 others[method] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ks = timer.summary()
-        try:
-            pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-        except Exception:
-            pmc = None
+        pmc, PMC_PROFILE = load_first(PMC_PROFILES)
+        mfma, MFMA_PROFILE = load_first(MFMA_PROFILES)
+
+        def mfma_busy_of(tag):
+            """matrix-pipe busy fraction of the tag's kernels from the committed counter pass: sum of MFMA busy cycles over
+            sum of (GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- what the MFMA roofline fraction must agree with"""
+            if not mfma or tag not in MFMA_KERNELS:
+                return None
+            busy = act = 0.0
+            for k, v in mfma["per_kernel"].items():
+                if any(k.startswith(pref) for pref in MFMA_KERNELS[tag]):
+                    busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+                    act += v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 1024.0
+            return busy / act if act else None
 
         def roofline_of(tag):
             bound, unit_work, unit, kernels = KERNEL_MODEL[tag]
@@ -370,6 +499,11 @@ def main():
                                            "scripts/microbench/atomic_patterns.hip; this is the limit the launch runs at"})
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
+            busy = mfma_busy_of(tag)
+            if busy is not None:
+                r["mfma_busy"] = {"frac": busy, "source": MFMA_PROFILE,
+                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the same kernels (profiled pass: "
+                                          "clocks ~3 % lower than the timed run)"}
             return r
 
         step_ms = dt / args.steps * 1e3
@@ -377,9 +511,10 @@ def main():
         roofs = [roofline_of(t) for t in sorted(ks, key=lambda t: -ks[t]["total_ms"]) if ks[t]["total_ms"] / args.steps >= 0.05 * step_ms]
         roof = roofs[0] if roofs else None
         per_gpu_samples = samples / args.steps / world
-        whole = {"mfma_tflops": 3 * FLOP_HEADS * per_gpu_samples / (step_ms * 1e-3) / 1e12,
-                 "mfma_frac": 3 * FLOP_HEADS * per_gpu_samples / (step_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                 "note": "algorithmic FLOP of both heads, forward + data gradient + weight gradient (3 x 56 192 per sample), over the whole step"}
+        whole = {"mfma_tflops": FLOP_STEP * per_gpu_samples / (step_ms * 1e-3) / 1e12,
+                 "mfma_frac": FLOP_STEP * per_gpu_samples / (step_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                 "note": "algorithmic FLOP of both heads: forward 56 192 + data gradient 49 664 (no gradient for the 51 per-ray input "
+                         "columns) + weight gradient 56 192 = 162 048 per sample, over the whole step"}
         if pmc and pmc.get("bytes_per_step"):
             whole.update(hbm_bytes_per_step=pmc["bytes_per_step"], hbm_gbs=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9,
                          hbm_frac=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, hbm_source=PMC_PROFILE)
@@ -400,6 +535,7 @@ def main():
             "windows": {"n": len(window_ms), "steps_each": args.steps, "ms_per_step": window_ms, "min": srt[0], "median": srt[len(srt) // 2],
                         "note": "window 0 is the measurement (value, ms_per_step, kernel events); the others show the spread"},
             "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
+            "allocator": dict(alloc_counters(), device_allocs_in_window0=alloc_w0, arenas_grown_in_window0=grown_w0),
             "roofline": roof,
             "rooflines": roofs,
             "whole_step": whole,

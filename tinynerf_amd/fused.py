@@ -19,27 +19,8 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from .arena import Arena
 from .models import _hwc, _kplanes_desc, _mlp_desc
-
-
-class Arena:
-    """Capacity-based scratch buffers for the harness: dynamic batches change N by a few percent every step, and a
-    caching allocator that sees a new 2.4 GB workspace size every few steps falls back to hipMalloc in the middle of
-    the step (measured: +60 ms stalls).  Buffers are allocated once with 25 % headroom and handed out as views.
-    Only valid when each forward's backward runs before the next forward (the training loop); opt-in."""
-
-    def __init__(self):
-        self.buf = {}
-
-    def get(self, name: str, shape, dev: torch.device, dtype=torch.float32) -> torch.Tensor:
-        numel = 1
-        for d in shape:
-            numel *= int(d)
-        t = self.buf.get(name)
-        if t is None or t.numel() < numel or t.device != dev or t.dtype != dtype:
-            t = torch.empty(int(numel * 1.25) + 1024, device=dev, dtype=dtype)
-            self.buf[name] = t
-        return t[:numel].view(*shape)
 
 
 PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)

@@ -66,7 +66,7 @@ class _FusedMLP(Function):
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
-                n_freqs: int, out_act: int, recording: bool, *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                n_freqs: int, out_act: int, recording: bool, scratch: Optional[Tuple[Any, str]], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.size(-1)).to(torch.float32).contiguous()
         aux2 = None if aux is None else aux.reshape(-1, aux.size(-1)).to(torch.float32).contiguous()
@@ -84,7 +84,9 @@ class _FusedMLP(Function):
             wsfn.restype = C.c_int64
             ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))
         if ws_bytes:
-            ws = torch.empty(ws_bytes // 4, device=dev)
+            # harness: a capacity-based arena (arena.Arena) instead of the caching allocator -- the training loop runs each
+            # forward's backward before the next forward of the module, so one buffer per module is enough
+            ws = scratch[0].get(scratch[1], (ws_bytes // 4,), dev) if scratch is not None else torch.empty(ws_bytes // 4, device=dev)
             L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
         else:
             L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
@@ -114,7 +116,7 @@ class _FusedMLP(Function):
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
-        return (gx_out, None, None, None, None, None, None, *grads)
+        return (gx_out, None, None, None, None, None, None, None, *grads)
 
 
 def _linear_params(net: torch.nn.Sequential) -> List[torch.Tensor]:
@@ -155,7 +157,9 @@ class MLP(torch.nn.Module):
 
     def fused(self, x: torch.Tensor, aux: Optional[torch.Tensor] = None, encoding: int = L.ENC_NONE, n_freqs: int = 0,
               out_act: int = L.ACT_NONE, freqs: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, torch.is_grad_enabled(), *self.params())
+        # `scratch` = (arena.Arena, buffer name), set by the training harness (run.Trainer); None: allocate per call
+        return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, torch.is_grad_enabled(), self.__dict__.get("scratch"),
+                               *self.params())
 
     def forward(self, x: torch.Tensor):
         return self.fused(x)

@@ -103,7 +103,15 @@ class Trainer:
         self._flat, self._flat_used, self._flat_ids = Trainer._flat_small_grads(params, device) if world_size > 1 else (None, 0, set())
         self.renderer.accumulate_into_grad = True       # fused path adds into these buffers directly
         self.renderer.reuse_buffers = True              # and keeps its scratch in a capacity-based arena
+        # ... as do the field's own MLP stacks (Vanilla 256 x 10: 10 KB of activation workspace per sample = 11 GB per step;
+        # Cobafa 128 x 6), sized once from the dynamic batch's target so that no step ever meets hipMalloc
+        from .arena import Arena
+        from .models import MLP
+        self.scratch = Arena()
+        for i, m in enumerate(mod for mod in self.renderer.feature_module.modules() if isinstance(mod, MLP)):
+            m.__dict__["scratch"] = (self.scratch, f"mlp_ws{i}")
         self._arena: Dict[str, torch.Tensor] = {}
+        self._arena_grown = 0
         # torch.optim.Adam's update (run.py:186), one kernel pass per tensor, gradients zeroed in the same pass
         self.optimizer = FusedAdam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
@@ -140,6 +148,7 @@ class Trainer:
         if t is None or t.numel() < numel:
             t = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=self.device)
             self._arena[name] = t
+            self._arena_grown += 1
         return t[:numel].view(*shape)
 
     # ------------------------------------------------------------------ a8: dynamic batch

@@ -157,7 +157,8 @@ int tn_posenc_fwd(const float *x, int64_t n, int n_channels, const float *freqs,
  * One launch evaluates  act_out( W_L ... relu(W_1 relu(W_0 enc(x) + b_0) + b_1) ... + b_L ).
  * Weights are torch nn.Linear layout [out,in] row-major.
  * ------------------------------------------------------------------------------------------ */
-enum { TN_ACT_NONE = 0, TN_ACT_EXP_M1 = 1 /* exp(y-1), models.py:74 */, TN_ACT_SIGMOID = 2 };
+enum { TN_ACT_NONE = 0, TN_ACT_EXP_M1 = 1 /* exp(y-1), models.py:74 */, TN_ACT_SIGMOID = 2,
+       TN_ACT_EXP = 3 /* tn_basis_dot_* only: exp(y) with the clamped backward of models.py:42-53 */ };
 enum { TN_ENC_NONE = 0,
        TN_ENC_POSENC = 1,       /* input = PE_F(x[:, :3])                      (models.py:67)    */
        TN_ENC_DIR_CAT = 2,      /* input = cat[PE_F(dirs), dirs, x]            (models.py:87)    */

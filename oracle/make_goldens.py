@@ -359,6 +359,45 @@ def main():
          packed=packed, info=info, rendered=out, target=target, loss=loss, freqs=freqs15,
          **{"sd." + k: v for k, v in sd_np(rendc).items()}, **{"grad." + n: p.grad for n, p in rendc.named_parameters()})
 
+    # ---- G16: config 5 again with a MODERATE medium: some rays terminate (w == 0 tails, core.py:243-249) but the fp32 suffix
+    # sums of cuda.cu:49-56 stay well conditioned (< 1e-4 of every gradient tensor), so that the Cobafa sigma path -- coefficient
+    # and basis grid gradients through terminated rays -- is pinned as tightly as every other row (G15's dense medium lets the
+    # reference's own backward drift by 4e-2 on the sigma head).  Own seed: the sections above are unchanged.
+    torch.manual_seed(16)
+    freqs16 = [2.0, 3.5, 8.0]
+    cf = models.CobafaFeatureField(basis_res=[8, 10, 12], coef_res=8, freqs=freqs16, channels=[8, 8, 4], mlp_hidden_dim=128)
+    od = models.VanillaOpacityDecoder(128); cd = models.VanillaColorDecoder(8, 128, 64, 3)
+    with torch.no_grad():
+        od.net.net[2].bias.add_(3.0)
+    rendm = core.NerfRenderer(cf, od, cd, None)
+    rendm.eval()
+    R, S = 48, 40
+    o = torch.rand(R, 3) * 0.6 - 0.3
+    d = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+    g = core.OccupancyGrid(24, 1.3 / S)
+    kk = torch.randint(0, 30, (24, 24, 24))
+    g.grid.copy_(torch.tensor(decay) ** kk.float())
+    cut = 5      # far samples (large steps of the unbounded marcher) are culled by the grid
+    keep = torch.zeros(24, 24, 24, dtype=torch.bool)
+    keep[cut:24 - cut, cut:24 - cut, cut:24 - cut] = True
+    g.grid.mul_(keep.float())
+    g.mean = g.grid.mean().item()
+    mu = core.RayMarcherUnbounded(S, 0.1, 1e5, 1.3)
+    rpm = core.RayProvider(g, core.ContractionMip360(float("inf")), mu)
+    packed, info = rpm(o, d, training=False)
+    sig = od(cf(packed[:, :3])).ravel()
+    w = core.NerfWeights.apply(sig, packed[:, 6], info, 1e-4)
+    out = rendm(packed, info)
+    target = torch.rand(R, 3)
+    loss = torch.nn.functional.mse_loss(out, target)
+    loss.backward()
+    ends = info[:, 0] + info[:, 1]
+    n_term = int(sum(1 for r_ in range(R) if info[r_, 1] > 0 and w[ends[r_] - 1] == 0))
+    save("G16_config5_moderate", rays_o=o, rays_d=d, n_samples=S, near=0.1, uniform_range=1.3,
+         grid=g.grid, threshold=g.threshold, packed=packed, info=info, weights=w, n_masked=int((w == 0).sum()), n_terminated_rays=n_term,
+         rendered=out, target=target, loss=loss, freqs=freqs16,
+         **{"sd." + k: v for k, v in sd_np(rendm).items()}, **{"grad." + n: p.grad for n, p in rendm.named_parameters()})
+
     with open(os.path.join(out_dir, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by oracle/make_goldens.py from the reference imported at %s\n" % args.ref)
         f.write("torch %s, numpy %s, 1 CPU thread, _cuda replaced by oracle/weights_ref.c\n" % (torch.__version__, np.__version__))

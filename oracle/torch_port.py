@@ -265,24 +265,26 @@ def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
 def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d: np.ndarray, rgbs: np.ndarray, *,
                        method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
                        bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10, scene_type: str = "aabb",
-                       scene_scale: float = 1.0, cobafa_freqs=None):
+                       scene_scale: float = 1.0, cobafa_freqs=None, occ_updates: int = 0, grid0=None, grids_out=None):
     """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
     shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
-    including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts)."""
+    including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts).
+    Test knobs (defaults = the reference): ``occ_updates`` overrides the refresh period 16 * 4096 / B (run.py:103), ``grid0``
+    the all-ones initial grid (core.py:108), ``grids_out`` (a list) receives (step, grid, mean) after every refresh."""
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v.clone())
           for k, v in sd0.items()}
     params = [v for v in sd.values() if v.requires_grad]
     bs_ratio = 4096 / batch_size
     steps = int(2048 * bs_ratio)
-    occ_updates = int(16 * bs_ratio)
+    occ_updates = occ_updates or int(16 * bs_ratio)
     opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[steps // 2, steps * 3 // 4, steps * 5 // 6, steps * 9 // 10], gamma=0.33)
     aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
     # run.py:154-162: aabb scenes march the box, unbounded ones the Mip-NeRF-360 table with the inf-norm contraction
     step_size = float(orc.aabb_step_size(aabb, n_samples)) if scene_type == "aabb" else scene_scale / n_samples
     decay = 0.01 ** (1 / 16)
-    grid = np.ones((occupancy_res,) * 3, np.float32)
-    mean = 1.0
+    grid = np.ones((occupancy_res,) * 3, np.float32) if grid0 is None else np.array(grid0, np.float32, copy=True)
+    mean = float(orc.torch_like_mean(grid))
     bg_t = None if bg is None else torch.tensor(bg, dtype=torch.float32)
     vf = vanilla_freqs if method == "vanilla" else 0
     cf = tuple(cobafa_freqs) if method == "cobafa" else None
@@ -316,6 +318,8 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
         if step % occ_updates == 0:
             jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
             grid, mean = orc.occupancy_update(grid, sigma_np, step_size, 0.01, decay, mean, jit)
+            if grids_out is not None:
+                grids_out.append((step, grid.copy(), mean))
         out = render(sd, torch.from_numpy(packed), torch.from_numpy(info), bg_t, vanilla_freqs=vf, cobafa_freqs=cf)
         loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
         if method == "kplanes":

@@ -35,16 +35,24 @@ def _matches(got, ref, keys, rel) -> bool:
 
 
 def assert_grads_match_up_to_relu_ties(got: Dict[str, np.ndarray], compute_ref: Callable[[], Dict[str, np.ndarray]], rel,
-                                       eps: float = 2e-6, max_flips: int = 256, weights_conditioning: bool = False) -> int:
+                                       eps: float = 2e-6, max_flips: int = 256, weights_conditioning: bool = False,
+                                       golden: Dict[str, np.ndarray] = None, cond_cap: float = None) -> int:
     """``compute_ref()`` evaluates the reference gradients through oracle/torch_port.mlp (on any device) and returns
     {name: array}.  |got - ref| <= rel * max|ref| per tensor (``rel``: one number or {name: number}) for some assignment of the tie units (|pre| <= eps * sum |terms|;
     the rounding error of an fp32 dot product of K <= 307 terms is ~sqrt(K) * 6e-8 = 1e-6 of that sum).  Returns the number of
-    tie units that had to be flipped."""
+    tie units that had to be flipped.
+    ``golden`` {name: gradient captured from the reference itself}: when no tie unit had to be flipped, `got` is ALSO compared
+    with it directly, same tolerance -- the reference stays the oracle, the port only supplies the tie bookkeeping.
+    ``cond_cap``: upper bound on any conditioning-derived tolerance (a fixture whose reference gradients are looser than this
+    pins nothing and must be replaced)."""
     if weights_conditioning:
         # render-level fixtures: the reference's fp32 weights backward (cuda.cu:49-56) is itself only this close to an exact
         # evaluation of its formula (oracle/torch_port.weights_conditioning); no other fp32 order can be held to less
         cond = tp.weights_conditioning(compute_ref)
         rel = {k: max(rel[k] if isinstance(rel, dict) else rel, 4.0 * c) for k, c in cond.items()}
+    if cond_cap is not None:
+        worst = max(rel.values()) if isinstance(rel, dict) else rel
+        assert worst <= cond_cap, f"tolerance {worst:.1e} exceeds the cap {cond_cap:.1e}: " + str({k: f"{v:.1e}" for k, v in rel.items() if v > cond_cap} if isinstance(rel, dict) else rel)
     with tp.ReluControl(eps) as ctrl:
         base = compute_ref()
     keys = sorted(base)
@@ -55,6 +63,9 @@ def assert_grads_match_up_to_relu_ties(got: Dict[str, np.ndarray], compute_ref: 
     def score(ref):          # worst violation in units of the tolerance; <= 1 passes
         return max(float(np.abs(np.asarray(got[k], np.float64) - np.asarray(ref[k], np.float64)).max()) / tol(k, base) for k in keys)
     if score(base) <= 1.0:
+        if golden is not None:
+            _check(got, golden, keys, {k: tol(k, base) / max(float(np.abs(np.asarray(golden[k])).max()), 1e-30) for k in keys},
+                   "directly against the reference's golden gradients")
         return 0
     def dist2(ref):          # squared distance in units of the tolerances: every correct flip lowers it, whatever the others do
         return sum(float((((np.asarray(got[k], np.float64) - np.asarray(ref[k], np.float64)) / tol(k, base)) ** 2).sum()) for k in keys)

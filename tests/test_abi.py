@@ -117,3 +117,17 @@ def test_workspace_buckets():
     rng = random.Random(0)
     sizes = {_bucket(int(1.03e6 * (1 + 0.02 * rng.gauss(0, 1)))) for _ in range(5000)}
     assert len(sizes) <= 3
+
+
+def test_bench_launcher_parent_is_gpu_free():
+    """the launcher branch of bench.py runs before `import torch` and counts GPUs from the KFD topology files"""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    tree = ast.parse(src)
+    fn = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    for name in ("launch_ranks", "visible_gpus"):
+        used = {n.id for n in ast.walk(fn[name]) if isinstance(n, ast.Name)}
+        assert "torch" not in used, name
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and any(a.name.split(".")[0] == "torch" for a in n.names) for n in tree.body)

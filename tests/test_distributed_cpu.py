@@ -72,11 +72,12 @@ def _worker(rank, world, port, q, flat=True):
     gate = torch.tensor([0.0 if rank == 0 else 0.7])
     Trainer.all_reduce_grads(stub, gate)                  # ... which are awaited here, everything else is reduced now
     assert not stub._early and float(gate) > 0
-    # a second exchange with every rank's step empty: the gate stays 0.  (Each rank holds the sum S already: 0.5 S + 0.5 S = S,
-    # exactly, so the gradients compared below are unchanged; this time the plane goes through the non-early branch.)
+    # a second exchange with every rank's step empty: the gate stays 0.  (Each rank holds the sum S already: world x (S / world)
+    # = S, exactly for a power-of-two world, so the gradients compared below are unchanged; this time the plane goes through the
+    # non-early branch.)
     gate0 = torch.zeros(1)
     for p_ in m.parameters():
-        p_.grad.mul_(0.5)
+        p_.grad.mul_(1.0 / world)
     Trainer.all_reduce_grads(stub, gate0)
     assert float(gate0) == 0.0
     q.put((rank, float(loss.detach()), {k: p.grad.detach().contiguous().numpy().copy() for k, p in m.named_parameters()}))
@@ -84,13 +85,15 @@ def _worker(rank, world, port, q, flat=True):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-@pytest.mark.parametrize("flat", [True, False])
-def test_two_rank_gradient_exchange_equals_single_process(flat):
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("flat,world", [(True, 2), (False, 2), (True, 4)])
+def test_gradient_exchange_equals_single_process(flat, world):
+    """2 and 4 gloo ranks (the 8-GPU job's exchange code with more than one peer: flat bucket + gate slot, live-row plane
+    slices, early handles) against one process on the union of the ranks' rays"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, flat)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, flat)) for r in range(world)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
     for p in procs: p.join(timeout=30)
@@ -98,7 +101,7 @@ def test_two_rank_gradient_exchange_equals_single_process(flat):
     # single-process reference: concatenate both ranks' rays, plain mean
     m = _make_model()
     ins, tgts = [], []
-    for rank in range(2):
+    for rank in range(world):
         n = 5 + 4 * rank
         g = torch.Generator().manual_seed(100 + rank)
         ins.append(torch.rand(n, 96, generator=g)); tgts.append(torch.rand(n, 3, generator=g))
@@ -108,7 +111,7 @@ def test_two_rank_gradient_exchange_equals_single_process(flat):
     loss.backward()
     with torch.no_grad():
         m.plane.grad[:, :, :10] = 0; m.plane.grad[:, :, 100:] = 0
-    assert abs(res[0][1] + res[1][1] - float(loss)) < 1e-6          # local losses sum to the global mean
+    assert abs(sum(r[1] for r in res) - float(loss)) < 1e-6          # local losses sum to the global mean
     for k, p in m.named_parameters():
-        for rank in range(2):                                        # every rank holds the full-batch gradient
+        for rank in range(world):                                       # every rank holds the full-batch gradient
             torch.testing.assert_close(torch.from_numpy(res[rank][2][k]), p.grad.contiguous(), rtol=1e-5, atol=1e-7)

@@ -2,6 +2,7 @@
 G13 explicit K-Planes decoders (models.py:183-205), G14 NerfRenderer over VanillaFeatureMLP(10, 256, 8) with 40 % of the samples
 masked (core.py:243-249), G15 BASELINE config 5 composed (Cobafa field + RayMarcherUnbounded + ContractionMip360(inf))."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -48,8 +49,9 @@ def test_port_vanilla_renderer_matches_reference():
     assert len(grads) == sum(1 for k in g if k.startswith("grad."))
 
 
-def test_config5_sampler_and_port_match_reference():
-    g = load_golden("G15_config5_cobafa_unbounded")
+@pytest.mark.parametrize("name", ["G15_config5_cobafa_unbounded", "G16_config5_moderate"])
+def test_config5_sampler_and_port_match_reference(name):
+    g = load_golden(name)
     # sampler: unbounded marcher + inf-norm Mip-NeRF-360 contraction + occupancy test, bit-exact ints and coordinates
     packed, info = orc.ray_provider(g["rays_o"], g["rays_d"], marcher="unbounded", contraction="mip360", grid=g["grid"],
                                     threshold=float(g["threshold"]), n_samples=int(g["n_samples"]), near=float(g["near"]),

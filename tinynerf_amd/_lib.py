@@ -19,7 +19,7 @@ TN_KPLANES_MAX_SCALES = 4
 
 MARCH_AABB, MARCH_UNBOUNDED = 0, 1
 CONTRACT_AABB, CONTRACT_MIP360_INF, CONTRACT_MIP360_L2 = 0, 1, 2
-ACT_NONE, ACT_EXP_M1, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_EXP_M1, ACT_SIGMOID, ACT_EXP = 0, 1, 2, 3
 ENC_NONE, ENC_POSENC, ENC_DIR_CAT, ENC_AUX_CAT = 0, 1, 2, 3
 
 

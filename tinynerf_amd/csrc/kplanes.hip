@@ -109,6 +109,7 @@ template <int ACT>
 __device__ __forceinline__ float bd_act(float v)
 {
     if (ACT == TN_ACT_EXP_M1) return expf(v - 1.0f);
+    if (ACT == TN_ACT_EXP) return expf(v);
     if (ACT == TN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
 }
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void basis_dot_bwd_kernel(const float *__restr
             acc = tn::wave_sum(acc);
             const float g = g_out[i * K + k];
             if (ACT == TN_ACT_EXP_M1) gv[k] = g * expf(fminf(fmaxf(acc - 1.0f, -15.0f), 15.0f));
+            else if (ACT == TN_ACT_EXP) gv[k] = g * expf(fminf(fmaxf(acc, -15.0f), 15.0f));
             else if (ACT == TN_ACT_SIGMOID) { const float y = 1.0f / (1.0f + expf(-acc)); gv[k] = g * y * (1.0f - y); }
             else gv[k] = g;
         }
@@ -217,6 +219,7 @@ extern "C" int tn_basis_dot_fwd(const float *f, const float *basis, int64_t n, i
     switch (activation) {
     case TN_ACT_EXP_M1: basis_dot_fwd_kernel<TN_ACT_EXP_M1><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
     case TN_ACT_SIGMOID: basis_dot_fwd_kernel<TN_ACT_SIGMOID><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
+    case TN_ACT_EXP: basis_dot_fwd_kernel<TN_ACT_EXP><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
     case TN_ACT_NONE: basis_dot_fwd_kernel<TN_ACT_NONE><<<grid, block, 0, s>>>(f, basis, n, channels, n_out, out); break;
     default: return tn::fail(TN_E_CONFIG, "tn_basis_dot_fwd: unknown activation");
     }
@@ -234,6 +237,7 @@ extern "C" int tn_basis_dot_bwd(const float *f, const float *basis, const float 
     switch (activation) {
     case TN_ACT_EXP_M1: basis_dot_bwd_kernel<TN_ACT_EXP_M1><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
     case TN_ACT_SIGMOID: basis_dot_bwd_kernel<TN_ACT_SIGMOID><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
+    case TN_ACT_EXP: basis_dot_bwd_kernel<TN_ACT_EXP><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
     case TN_ACT_NONE: basis_dot_bwd_kernel<TN_ACT_NONE><<<grid, block, 0, s>>>(f, basis, grad_out, n, channels, n_out, grad_f, grad_basis, accumulate_f); break;
     default: return tn::fail(TN_E_CONFIG, "tn_basis_dot_bwd: unknown activation");
     }

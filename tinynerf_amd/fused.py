@@ -20,7 +20,7 @@ from torch.autograd import Function
 
 from . import _lib as L
 from .arena import Arena
-from .models import _hwc, _kplanes_desc, _mlp_desc
+from .models import _empty_rows, _hwc, _kplanes_desc, _mlp_desc
 
 
 PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)
@@ -125,8 +125,9 @@ class _RenderKPlanes(Function):
                C.c_int64(n), C.c_int64(R))
         # core.py:246-254: when EVERY sample is masked (w == 0 everywhere) the reference renders the background from constants
         # that carry no graph, i.e. no parameter receives a gradient from the image loss; here the upstream gradient is gated
-        # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer replaces it by the maximum over all ranks -- the
-        # single-GPU step on the union of the ranks' rays is only "empty" when every rank's is -- before the backward runs)
+        # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer all-reduces it in place right after this forward
+        # (run.Trainer.step_on_batch) -- the single-GPU step on the union of the ranks' rays is only "empty" when every
+        # rank's is -- so the backward below already reads the all-rank value)
         ctx.gate = weights.amax().reshape(1) if train else None
         if stats is not None:
             stats["gate"] = ctx.gate
@@ -337,7 +338,7 @@ class _RenderHeads(Function):
         g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
-        g_feat = torch.empty((n, F), device=dev)             # handed to autograd (the field's backward): not an arena view
+        g_feat = _empty_rows(n, F, dev)                      # handed to autograd (the field's backward): not an arena view
         nr, ns = len(rgb_p) // 2, len(sig_p) // 2
         gw_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[0::2]])
         gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])

@@ -58,6 +58,12 @@ def _bucket(n: int) -> int:
     return (n + g - 1) // g * g
 
 
+def _empty_rows(n: int, cols: int, dev: torch.device) -> torch.Tensor:
+    """[n, cols] fp32 carved from a bucketed allocation: per-sample tensors of the wide stacks are ~1 GB each and N changes every
+    step -- an exact-size request is a new block size for the caching allocator nearly every time (hipMalloc inside the step)"""
+    return torch.empty((_bucket(n), cols), device=dev)[:n]
+
+
 class _FusedMLP(Function):
     """y = act(MLP(enc(x, aux))) in one launch; in training the forward also writes the activation workspace the backward
     consumes (tn_mlp_fwd_stash), otherwise the backward recomputes the hidden activations."""
@@ -74,7 +80,7 @@ class _FusedMLP(Function):
         dev = L.require_cuda(x2, aux2, *ps)
         n = x2.size(0)
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
-        y = torch.empty((n, ps[-1].numel()), device=dev)
+        y = _empty_rows(n, ps[-1].numel(), dev)
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
         # `recording` = torch.is_grad_enabled() at the call site: inside torch.no_grad() (infer(), the occupancy refresh)
@@ -108,7 +114,7 @@ class _FusedMLP(Function):
         gw = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[0::2]])
         gb = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[1::2]])
         want_gx = ctx.needs_input_grad[0] and encoding != L.ENC_POSENC
-        gx = torch.empty_like(x2) if want_gx else None
+        gx = _empty_rows(n, x2.size(1), dev) if want_gx else None
         wsfn = L.lib().tn_mlp_bwd_workspace_bytes
         wsfn.restype = C.c_int64
         ws_bytes = int(wsfn(C.byref(desc), C.c_int64(_bucket(n))))
@@ -217,17 +223,17 @@ class _BasisDot(Function):
 
 class TruncatedExponential(Function):  # pylint: disable=abstract-method
     """exp with a clamped backward (models.py:42-53): forward exp(x), backward g * exp(clamp(x, -15, 15)).  Inside the heads it
-    is fused into the MLP kernel (TN_ACT_EXP_M1); on its own it is the element-wise case of tn_basis_dot_* (act(v) = exp(v - 1)
-    evaluated at v = x + 1)."""
+    is fused into the MLP kernel (TN_ACT_EXP_M1); on its own it is the element-wise case of tn_basis_dot_* (C = K = 1, f = 1,
+    TN_ACT_EXP: x reaches expf() unmodified, as in torch.exp)."""
 
     @staticmethod
     def forward(ctx, x):  # pylint: disable=arguments-differ
         x = x.float().contiguous()
         dev = L.require_cuda(x)
-        v = (x + 1.0).reshape(-1, 1)
-        one = torch.ones_like(v)
+        v = x.reshape(-1, 1)
+        one = torch.ones((1, 1), device=dev).expand(v.size(0), 1).contiguous() if v.size(0) else v
         out = torch.empty_like(v)
-        L.call("tn_basis_dot_fwd", dev, L.ptr(one), L.ptr(v), C.c_int64(v.size(0)), C.c_int32(1), C.c_int32(1), C.c_int32(L.ACT_EXP_M1), L.ptr(out))
+        L.call("tn_basis_dot_fwd", dev, L.ptr(one), L.ptr(v), C.c_int64(v.size(0)), C.c_int32(1), C.c_int32(1), C.c_int32(L.ACT_EXP), L.ptr(out))
         ctx.save_for_backward(one, v)
         ctx.x_shape = x.shape
         return out.reshape(x.shape)
@@ -238,7 +244,7 @@ class TruncatedExponential(Function):  # pylint: disable=abstract-method
         g = g.float().contiguous().reshape(-1, 1)
         g_one, g_v = torch.empty_like(one), torch.empty_like(v)
         L.call("tn_basis_dot_bwd", v.device, L.ptr(one), L.ptr(v), L.ptr(g), C.c_int64(v.size(0)), C.c_int32(1), C.c_int32(1),
-               C.c_int32(L.ACT_EXP_M1), L.ptr(g_one), L.ptr(g_v), C.c_int32(0))
+               C.c_int32(L.ACT_EXP), L.ptr(g_one), L.ptr(g_v), C.c_int32(0))
         return g_v.reshape(ctx.x_shape)
 
 

@@ -18,7 +18,8 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.zero_grad_in_step = zero_grad_in_step
-        self._gated_count = {}
+        self._gated_count = {}       # device -> int32 [1]: updates that were not gated away (the bias-correction count)
+        self._gated_params = {}      # device -> the parameters that share that count
 
     @torch.no_grad()
     def step(self, closure=None, plane_reg=None, gate=None):
@@ -71,6 +72,7 @@ class FusedAdam(torch.optim.Optimizer):
                         if self._gated_count.get(dev) is None:      # device-side count of the updates that were not gated away
                             first = min(self.state[p]["step"] for p, _, _, _ in tensors) - 1
                             self._gated_count[dev] = torch.full((1,), first, dtype=torch.int32, device=dev)
+                        self._gated_params[dev] = [p for p, _, _, _ in tensors]
                         L.call("tn_adam_multi_gated", dev, items, C.c_int32(len(tensors)), *common[:5], L.ptr(self._gated_count[dev]),
                                L.ptr(gate), common[6])
                     continue
@@ -92,3 +94,24 @@ class FusedAdam(torch.optim.Optimizer):
                     new, st["shadow"] = st["shadow"], p.data
                     p.data = new
         return loss
+
+    def sync_step_counts(self) -> None:
+        """Gated mode keeps the real update count on the device (a skipped "Empty iteration" must not advance the bias
+        correction, and deciding that on the host would be a read-back per step); ``state[p]["step"]`` counts calls.  This
+        writes the device count back into the state (one 4-byte read-back), so that checkpoints, resumes and inspections see the
+        count Adam actually uses."""
+        for dev, cnt in self._gated_count.items():
+            if cnt is None:
+                continue
+            c = int(cnt.item())
+            for p in self._gated_params.get(dev, []):
+                if p in self.state:
+                    self.state[p]["step"] = c
+
+    def state_dict(self):
+        self.sync_step_counts()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._gated_count, self._gated_params = {}, {}       # re-derived from the loaded step counts at the next gated step

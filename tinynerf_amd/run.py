@@ -119,10 +119,11 @@ class Trainer:
             gamma=0.33)
         self.train_step = 0
         self._cursor = 0                 # deterministic mode: position in the ray table
-        self._perm: Optional[torch.Tensor] = None      # random mode: the current shuffled epoch(s) of ray indices ...
-        self._perm_pos = 0                             # ... and the position of the next loader batch in it
+        self._perm: Optional[torch.Tensor] = None      # random mode: the current shuffled epoch of ray indices (int32) ...
+        self._perm_pos = 0                             # ... the position of the next loader batch in it ...
+        self._carry = torch.empty(0, dtype=torch.int32, device=device)     # ... and the unread tail of the previous epoch
         self._k_guess = 8
-        # per-rank ray stream: same generator family, different seed -> disjoint draws
+        # per-rank ray stream over the rank's own ray table (see _epoch_block): same generator family, different seed
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
         self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
@@ -155,16 +156,32 @@ class Trainer:
     def _epoch_block(self, m: int) -> torch.Tensor:
         """The next ``m`` ray indices of the shuffled stream: the reference's ``DataLoader(shuffle=True)`` (run.py:116-122) walks a
         fresh permutation of all rays per epoch -- every ray once per epoch, no replacement -- in loader batches of B; here the
-        permutation lives on the device (``torch.randperm`` from the trainer's own generator) and a step consumes the k batches
-        its dynamic batch took (``_perm_pos`` advances by R in build_batch; a block that is redrawn larger starts at the same place)."""
-        if self._perm is None or self._perm_pos + m > self._perm.numel():
-            chunks = [] if self._perm is None else [self._perm[self._perm_pos:]]
-            have = sum(c.numel() for c in chunks)
-            while have < m:
-                chunks.append(torch.randperm(self.rays_o.size(0), device=self.device, generator=self._gen))
-                have += chunks[-1].numel()
-            self._perm, self._perm_pos = torch.cat(chunks), 0
-        return self._perm[self._perm_pos:self._perm_pos + m]
+        permutation lives on the device (int32 ``torch.randperm`` from the trainer's own generator) and a step consumes the k
+        batches its dynamic batch took (``_advance`` in build_batch; a block that is redrawn larger starts at the same place).
+        The stream is  carry ++ perm[pos:] : at an epoch boundary only the few unread indices of the old permutation are kept
+        (``_carry``), the new permutation is never concatenated or copied.  N > 1: every rank is handed its OWN share of the
+        rays (bench.py: its own views; the tests: ``rays[rank::world]``), so per-rank permutations of per-rank tables are
+        disjoint by construction and an epoch of the job visits every ray once.  Deviation: the reference's partial last
+        loader batch of an epoch (DataLoader without drop_last) is filled up from the next epoch instead."""
+        n_rays = self.rays_o.size(0)
+        while self._carry.numel() + (0 if self._perm is None else self._perm.numel() - self._perm_pos) < m:
+            if self._perm is not None:
+                self._carry = torch.cat([self._carry, self._perm[self._perm_pos:]])
+            self._perm = torch.randperm(n_rays, device=self.device, generator=self._gen, dtype=torch.int32)
+            self._perm_pos = 0
+        c = self._carry.numel()
+        if c == 0:
+            return self._perm[self._perm_pos:self._perm_pos + m]
+        return torch.cat([self._carry[:m], self._perm[self._perm_pos:self._perm_pos + max(0, m - c)]])
+
+    def _advance(self, r: int) -> None:
+        """consume the first ``r`` indices of the shuffled stream"""
+        c = self._carry.numel()
+        if r >= c:
+            self._carry = self._carry[:0]
+            self._perm_pos += r - c
+        else:
+            self._carry = self._carry[r:]
 
     @torch.no_grad()
     def _launch_plan(self, n_b: Optional[int] = None) -> None:
@@ -182,7 +199,7 @@ class Trainer:
         if cfg.deterministic:
             idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
         else:
-            idx = self._epoch_block(n_b * B)
+            idx = self._epoch_block(n_b * B).long()
         o, d = self.rays_o[idx], self.rays_d[idx]
         desc = self.ray_provider._desc(dev, not cfg.deterministic, None)
         desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
@@ -216,7 +233,7 @@ class Trainer:
         self._k_guess = k
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         if not self.cfg.deterministic:
-            self._perm_pos += R
+            self._advance(R)
         info = self._buf("info", (R, 2), torch.int32)
         total = self._buf("total", (1,), torch.int32)
         L.call("tn_sample_scan", dev, L.ptr(pend["counts"]), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
@@ -256,6 +273,16 @@ class Trainer:
             ray_count = torch.full((1,), float(info.size(0)), device=self.device)
             ray_count_done = torch.distributed.all_reduce(ray_count, async_op=True)
         rendered = self.renderer(packed, info)                                    # run.py:251
+        # "Empty iteration" (core.py:251-254): no sample of the step has w > 0 -> no parameter is reached by the image loss, and
+        # torch.optim.Adam skips the grad-is-None parameters (run.py:258-260); decided on the device through this scalar (the
+        # step's largest weight, the tensor the render node's backward reads).  N > 1: the step on the union of all ranks' rays
+        # is empty only when every rank's is, so the scalar is summed over ranks BEFORE the backward pass (a rank whose own batch
+        # is fully masked must still propagate d / d sigma and the background term); 4 bytes, in flight behind the sampler
+        # pass of the next step
+        gate = getattr(self.renderer, "_stats", {}).get("gate")
+        gate_done = None
+        if self.world > 1 and gate is not None:
+            gate_done = torch.distributed.all_reduce(gate, async_op=True)
         if self.prefetch if prefetch is None else prefetch:
             self._launch_plan()            # next step's sampler pass runs between this forward and backward
         # loss * grad_scale, scaled and never unscaled (run.py:259-260 quirk).  The MSE and its gradient are written out
@@ -264,13 +291,12 @@ class Trainer:
         R = rendered.size(0)
         acc = self._buf("loss_acc", (1 + 32 * 3,), torch.float64).zero_()          # [0]: sum of squares, [1:]: regulariser sums
         grad = self._buf("grad_rendered", (R, 3), torch.float32)
-        # "Empty iteration" (core.py:251-254): no sample of the step has w > 0 -> no parameter is reached by the image loss, and
-        # torch.optim.Adam skips the grad-is-None parameters (run.py:258-260); decided on the device through this scalar
-        gate = getattr(self.renderer, "_stats", {}).get("gate")
         if self.world == 1:
             inv, inv_dev = 1.0 / (3.0 * R), None
         else:                                                                     # MSE over ALL ranks' rays (see global_ray_count)
             ray_count_done.wait()
+            if gate_done is not None:
+                gate_done.wait()
             inv, inv_dev = 1.0, (1.0 / (3.0 * ray_count)).float()
         L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))

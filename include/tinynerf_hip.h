@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TN_ABI_VERSION 2
+#define TN_ABI_VERSION 3
 
 enum {
     TN_OK = 0,
@@ -172,6 +172,8 @@ enum { TN_ENC_NONE = 0,
 #define TN_MLP_WGRAD_ONLY 8     /* ... weight / bias gradients only, from a workspace a CHAIN_ONLY call completed.  The split
                                  * lets a caller start consuming grad_x (e.g. scatter it and launch a gradient all-reduce)
                                  * while the weight gradients are still being computed. */
+#define TN_MLP_GRAD_Y_ROWS 16   /* tn_mlp_bwd of a layer-by-layer configuration (tn_mlp_rows_view): d loss / d y already sits in the
+                                 * workspace as [feature][32-sample] rows (a consumer's grad_x_rows); grad_y is ignored */
 
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
@@ -192,7 +194,26 @@ typedef struct tn_mlp_desc {
     /* tn_mlp_fwd only: optional per-row gate [n] (the renderer passes the volume-rendering weights, core.py:246-251: the
      * colour head only matters where w > 0).  A 32-row tile whose gates are all 0 is not evaluated and yields 0. */
     const float *row_gate;
+    /* Row views (optional, all NULL / 0 by default): x and grad_x of tn_mlp_bwd as [feature][32-sample] rows per 32-sample
+     * tile -- the layout in which a wide stack's layer-by-layer kernels keep activations and gradients in their workspace
+     * (tn_mlp_rows_view), so that the heads behind a width-256 feature stack (reference models.py:59-89, core.py:239-249)
+     * exchange both with it without a row-major round trip:
+     *   x_rows       value of feature f of sample 32 t + j at x_rows[t * x_rows_tile_stride + 32 f + j] (samples >= n: 0).
+     *                tn_mlp_bwd (two-pass form, TN_MLP_STASHED) then takes the first layer's weight gradient over the x
+     *                columns from these rows; needs in_dim % 32 == 0.  x itself is still required.
+     *   grad_x_rows  tn_mlp_bwd writes (TN_MLP_ACCUM_GRAD_X: adds) d loss / d x there, same layout, INSTEAD of grad_x. */
+    const float *x_rows;
+    float *grad_x_rows;
+    int64_t x_rows_tile_stride;               /* floats */
+    int64_t grad_x_rows_tile_stride;
 } tn_mlp_desc;
+
+/* Row views into the workspace of tn_mlp_fwd_stash(desc, ..., n) for a layer-by-layer configuration without output
+ * activation (the Vanilla 256 x 10 and Cobafa 128 x 6 feature stacks): offsets in floats from the workspace base of
+ *   y_rows       y as [feature][32-sample] rows -- valid until this stack's tn_mlp_bwd runs;
+ *   grad_y_rows  where tn_mlp_bwd with TN_MLP_GRAD_Y_ROWS expects d loss / d y in that layout;
+ * and the tile stride (floats per 32 samples) of both.  TN_E_CONFIG when the configuration has no such views. */
+int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_rows, int64_t *grad_y_rows, int64_t *tile_stride);
 
 /* y [n, dims[n_layers]] = MLP(x [n,in_dim], aux [n,3] (dirs for TN_ENC_DIR_CAT, else NULL)).
  * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */

@@ -34,7 +34,7 @@ def test_header_declares_the_reference_boundary():
 def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.tn_abi_version() == 2
+    assert lib.tn_abi_version() == 3
 
 
 def test_struct_layouts_match_c(tmp_path):

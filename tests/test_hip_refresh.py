@@ -89,7 +89,9 @@ def test_training_parity_across_occupancy_refreshes(method):
         thr, thr_r = min(0.01, mean), min(0.01, mean_r)
         occ, occ_r = g > thr, gr > thr_r
         frac = float(occ_r.mean())
-        assert 0.15 < frac < 0.85, (step, frac)                                            # the refresh really carved the grid
+        # the first refresh carves the designed state (the optimizer may fill the grid again later: Cobafa's density grows
+        # everywhere within four steps of the recipe's lr 1e-2 -- the later refreshes then pin decay chains and all-ones cells)
+        assert frac > 0.15 and (step > 0 or frac < 0.85), (step, frac)
         flips = int((occ != occ_r).sum())
         flips_total += flips
         # G5's bound: cells whose alpha sits within rounding of the threshold may fall on either side (expf / MFMA summation

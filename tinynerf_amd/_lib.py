@@ -43,6 +43,7 @@ class MlpDesc(C.Structure):
         ("weights", C.c_void_p * TN_MLP_MAX_LAYERS), ("biases", C.c_void_p * TN_MLP_MAX_LAYERS),
         ("aux_index", C.c_void_p), ("aux_stride", C.c_int32), ("reserved", C.c_int32),
         ("row_gate", C.c_void_p),
+        ("x_rows", C.c_void_p), ("grad_x_rows", C.c_void_p), ("x_rows_tile_stride", C.c_int64), ("grad_x_rows_tile_stride", C.c_int64),
     ]
 
 
@@ -60,6 +61,7 @@ MLP_ACCUM_GRAD_X = 1
 MLP_STASHED = 2
 MLP_CHAIN_ONLY = 4
 MLP_WGRAD_ONLY = 8
+MLP_GRAD_Y_ROWS = 16
 
 
 class PlaneRegItem(C.Structure):

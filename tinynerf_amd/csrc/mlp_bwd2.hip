@@ -25,6 +25,8 @@
 extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
+extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, const float *x_rows, int64_t x_stride, int in_dim, float *gW,
+                                 int ldw, int col0, float *gB, int64_t n, void *stream);
 
 namespace {
 
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
 
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
-        if ((KP || gx != nullptr) && a.enc != TN_ENC_POSENC) {
+        if ((KP || gx != nullptr || a.gx_rows != nullptr) && a.enc != TN_ENC_POSENC) {
             f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
@@ -367,9 +369,14 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             if constexpr (PAIR) first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
             const int64_t rowc = row < n ? row : n - 1;
             f32x4 old[4], oldn[4];
+            // d loss / d x as [feature][32-sample] rows (tn_mlp_desc::grad_x_rows: the consumer is a wide stack's layer kernel):
+            // the D tile of a 32-column block IS 32 such rows, written like every workspace row
+            float *const gxr = a.gx_rows != nullptr ? a.gx_rows + tile * a.gx_rows_stride : nullptr;      // (wave-uniform)
             if constexpr (ACCUM) {
+                if (gxr == nullptr) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 8 * q + 4 * h);
+                }
             }
 #pragma clang loop unroll(disable)
             for (int kt = 0; kt < n_kt; ++kt) {
@@ -377,9 +384,14 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 if constexpr (ACCUM) {
+                    if (gxr != nullptr) tn::mlp::load_rows(gxr + kt * 32 * 32, acc, 0, j, h);     // the MFMAs below accumulate on top
+                }
+                if constexpr (ACCUM) {
+                    if (gxr == nullptr) {
                     const int ktn = kt + 1 < n_kt ? kt + 1 : kt;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * ktn + 8 * q + 4 * h);
+                    }
                 }
                 {
                     constexpr int NG = 4 * T;
@@ -415,6 +427,10 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 if constexpr (KP) {                 // (uniform branches: kt is a loop counter)
                     if (kt == 0) gacc[0] = acc; else if (kt == 1) gacc[1] = acc; else gacc[2] = acc;
                     if (gx == nullptr) continue;
+                }
+                if (gxr != nullptr) {               // rows of samples >= n carry zeros (their output gradient was zeroed)
+                    store_rows(gxr + kt * 32 * 32, acc, 0, j, h);
+                    continue;
                 }
                 if constexpr (ACCUM) {
                     if (valid) {
@@ -474,6 +490,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     int n_layers, in_dim, K0, K0_pad, enc, n_freqs, out_dim, Tk0, total_tiles;
+    int tk_skip;                // first-layer k tiles [0, tk_skip) are somebody else's (x columns taken from row views, mlp_wgrad_rows.hip)
     const int *aux_index;       // TN_ENC_AUX_CAT
     int aux_stride;
     float *gW[TN_MLP_MAX_LAYERS];
@@ -493,8 +510,9 @@ __device__ __forceinline__ int wg_col0(const WgradArgs &a, int q) {
 template <int H, int NH>
 __device__ __forceinline__ void decode_tile(const WgradArgs &a, int id, int &l, int &tn_, int &tk) {
     constexpr int T = H / 32;
-    const int n0 = T * a.Tk0;
-    if (id < n0) { l = 0; tn_ = id / a.Tk0; tk = id - tn_ * a.Tk0; return; }
+    const int tk0n = a.Tk0 - a.tk_skip;
+    const int n0 = T * tk0n;
+    if (id < n0) { l = 0; tn_ = id / tk0n; tk = a.tk_skip + id - tn_ * tk0n; return; }
     id -= n0;
     if (id < (NH - 1) * T * T) { l = 1 + id / (T * T); id -= (l - 1) * T * T; tn_ = id / T; tk = id - tn_ * T; return; }
     id -= (NH - 1) * T * T;
@@ -516,15 +534,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: tile ownership lives in SGPRs
     const int64_t n_tiles = (n + 31) >> 5;
     const int xs = x_slots(a.enc, a.in_dim);
+    const int xs_st = 32 * a.tk_skip >= xs ? 0 : xs;      // x columns that are this kernel's: staged sample-major (none when skipped)
     const int extra = extra_rows(a.enc, a.in_dim, a.K0_pad);
     const int R = stash_rows_w(H, NH, extra);             // rows staged per tile
     const int Rt = stash_rows(H, NH, extra);              // rows per tile in the workspace
     const int row_chunks = R * 8;                         // float4 chunks of the workspace tile
-    const int x_chunks = xs > 0 ? (32 * a.in_dim) / 4 : 0;   // float4 chunks of the x rows of the tile (contiguous)
+    const int x_chunks = xs_st > 0 ? (32 * a.in_dim) / 4 : 0;   // float4 chunks of the x rows of the tile (contiguous)
     const int aw = AUX ? a.K0_pad - a.in_dim : 0;         // aux-table columns (multiple of 8, <= 64)
     float *ldsR = lds;
     float *ldsX = lds + R * RS;
-    float *ldsA = ldsX + (xs > 0 ? 32 * a.in_dim : 0);
+    float *ldsA = ldsX + (xs_st > 0 ? 32 * a.in_dim : 0);
     f32x16 acc[MAXS];
     float dbacc[MAXS];
     int tl[MAXS], ttn[MAXS], ttk[MAXS];
@@ -555,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad_kernel(WgradArgs a, const f
             e = e < 0 ? 0 : (e > xlast ? xlast : e);
             const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
             const f32x4 *pr = src + (c < row_chunks ? c : 0);
-            pre[k] = *((c < row_chunks || xs == 0) ? pr : px);
+            pre[k] = *((c < row_chunks || xs_st == 0) ? pr : px);
         }
         if constexpr (AUX) {
             const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;
@@ -850,11 +869,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const 
 // ------------------------------------------------------------------------------------------------
 // chunk / LDS budget of the wgrad kernel for a descriptor (host)
 struct WgradPlan { int R, Rt, xs, aw, chunks; size_t lds; };
-WgradPlan wgrad_plan(int enc, int in_dim, int K0_pad, int H, int NH) {
+WgradPlan wgrad_plan(int enc, int in_dim, int K0_pad, int H, int NH, bool x_elsewhere = false) {
     WgradPlan p;
     const int extra = extra_rows(enc, in_dim, K0_pad);
     p.R = stash_rows_w(H, NH, extra); p.Rt = stash_rows(H, NH, extra);
-    p.xs = x_slots(enc, in_dim);
+    p.xs = x_elsewhere ? 0 : x_slots(enc, in_dim);         // x columns taken from row views: nothing of x is staged here
     p.aw = enc == TN_ENC_AUX_CAT ? K0_pad - in_dim : 0;
     p.chunks = p.R * 8 + (p.xs > 0 ? 8 * in_dim : 0);           // float4 chunks of workspace rows + x rows per tile
     p.lds = ((size_t)p.R * 36 + (p.xs > 0 ? 32 * (size_t)in_dim : 0) + 32 * (size_t)p.aw) * 4;
@@ -913,7 +932,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     constexpr int WPP = 8;                   // pair: both heads' G_0 live at grad_x: 207 VGPRs (9-12 waves are capped at 168 and spill 38)
     int wpb = stashed ? WPS : WPB;
     auto kern = stashed ? mlp_chain_kernel<H, NH, WPS, true> : mlp_chain_kernel<H, NH, WPB, false>;
-    if (stashed && a.accum_gx && gx != nullptr && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
+    if (stashed && a.accum_gx && (gx != nullptr || a.gx_rows != nullptr) && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
     PairArgs pr;
     pr.gy = nullptr; pr.stash = nullptr;
     if (pair) {
@@ -938,10 +957,23 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     w.n_layers = a.n_layers; w.in_dim = a.in_dim; w.K0 = a.K0; w.K0_pad = a.K0_pad; w.enc = a.enc; w.n_freqs = a.n_freqs;
     w.out_dim = a.out_dim;
     w.Tk0 = (a.K0_pad + 31) / 32;
-    w.total_tiles = T * w.Tk0 + (NH - 1) * T * T + T;
+    w.tk_skip = 0;
     for (int l = 0; l < a.n_layers; ++l) { w.gW[l] = gw[l]; w.gB[l] = gb[l]; w.K[l] = a.K[l]; w.N[l] = a.N[l]; }
     w.aux_index = a.aux_index; w.aux_stride = a.aux_stride;
-    const WgradPlan wp = wgrad_plan(a.enc, a.in_dim, a.K0_pad, H, NH);
+    // x as [feature][32-sample] rows (the workspace of the wide stack that produced it): the first layer's x columns -- all of
+    // its k tiles below in_dim / 32 and its bias gradient -- go to the layer-kernel form (mlp_wgrad_rows.hip); what is left
+    // here are the encoding columns, the hidden layers and the output layer
+    const bool x_rows = a.x_rows != nullptr && stashed && H == 64 && (a.in_dim & 31) == 0 && x_slots(a.enc, a.in_dim) == a.in_dim &&
+                        (a.in_dim == 128 || a.in_dim == 256);
+    if (x_rows) {
+        const int extra_r = extra_rows(a.enc, a.in_dim, a.K0_pad);
+        const int col0 = (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) ? a.K0 - a.in_dim : 0;      // torch order [PE(d), d, x]
+        if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)NH * H * 32, (int64_t)stash_rows(H, NH, extra_r) * 32, a.x_rows, a.x_rows_stride,
+                                       a.in_dim, gw[0], a.K0, col0, gb[0], n, s)) return rc;
+        w.tk_skip = a.in_dim / 32;
+    }
+    w.total_tiles = T * (w.Tk0 - w.tk_skip) + (NH - 1) * T * T + T;
+    const WgradPlan wp = wgrad_plan(a.enc, a.in_dim, a.K0_pad, H, NH, x_rows);
     const size_t wlds = wp.lds;
     if (wlds > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: workspace tile does not fit LDS");
     if (wp.xs > 0 && (a.in_dim & 3)) return tn::fail(TN_E_CONFIG, "mlp_bwd: in_dim must be a multiple of 4");

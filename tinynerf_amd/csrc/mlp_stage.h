@@ -21,6 +21,10 @@ struct MlpArgs {
     const int *aux_index;  // TN_ENC_AUX_CAT: x row -> aux table row (nullptr: identity)
     int aux_stride;
     const float *row_gate; // forward only: tiles whose gates are all 0 are skipped (output 0)
+    // row views (tn_mlp_desc::x_rows / grad_x_rows): x^T and d loss / d x as [feature][32-sample] rows per tile
+    const float *x_rows;
+    float *gx_rows;
+    int64_t x_rows_stride, gx_rows_stride;
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
@@ -132,6 +136,16 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
         *reinterpret_cast<__attribute__((address_space(1))) float *>(base + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = t[r];
 }
 
+// the same rows back into the D layout
+__device__ __forceinline__ void load_rows(const float *__restrict__ rows, f32x16 &t, int ob, int j, int h) {
+    const global_char *base = wave_uniform_global(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        t[r] = *reinterpret_cast<const __attribute__((address_space(1))) float *>(base + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
+}
+
 // Bit r = (t[r] > 0) for ReLU outputs (t >= 0, so "> 0" is "bit pattern != 0"; -0.0 cannot occur after fmaxf(x, 0)
 // ... it can: fmaxf(-0.0, 0) may return either zero, hence the shift that drops the sign bit).  Two VALU operations per
 // element (min, shift-or) instead of compare + select + or: VALU instructions are what the MFMA-heavy kernels run out of.
@@ -184,6 +198,12 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
     a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
     a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride; a.row_gate = d->row_gate;
+    a.x_rows = d->x_rows; a.gx_rows = d->grad_x_rows; a.x_rows_stride = d->x_rows_tile_stride; a.gx_rows_stride = d->grad_x_rows_tile_stride;
+    TN_REQUIRE((!a.x_rows && !a.gx_rows) || ((a.in_dim & 31) == 0 && a.enc != TN_ENC_POSENC), TN_E_CONFIG,
+               "mlp: x_rows / grad_x_rows need in_dim % 32 == 0 and an encoding that keeps x as input columns");
+    TN_REQUIRE((!a.x_rows || (((uintptr_t)a.x_rows & 15) == 0 && a.x_rows_stride >= 32 * (int64_t)a.in_dim && (a.x_rows_stride & 3) == 0)) &&
+                   (!a.gx_rows || (((uintptr_t)a.gx_rows & 15) == 0 && a.gx_rows_stride >= 32 * (int64_t)a.in_dim)), TN_E_ALIGN,
+               "mlp: x_rows / grad_x_rows must be 16-byte aligned with a tile stride >= 32 * in_dim floats");
     TN_REQUIRE(a.out_dim >= 1 && a.in_dim >= 1, TN_E_SIZE, "mlp: bad in/out width");
     switch (a.enc) {
     case TN_ENC_NONE: TN_REQUIRE(a.K0 == a.in_dim, TN_E_CONFIG, "mlp: dims[0] must equal in_dim"); break;

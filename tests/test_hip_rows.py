@@ -1,0 +1,86 @@
+"""Row views between a wide feature stack and the heads behind it (include/tinynerf_hip.h: tn_mlp_desc::x_rows / grad_x_rows,
+tn_mlp_rows_view, TN_MLP_GRAD_Y_ROWS) -- the harness plumbing for reference models.py:59-89 on run.py:131-134 (Vanilla,
+width 256) and run.py:141-150 (Cobafa, width 128): y^T stays in the stack's workspace as [feature][32-sample] rows, the heads'
+first-layer weight gradients read it there (mlp_wgrad_rows.hip) and their data-gradient chains write d loss / d y back in the
+same layout.  Oracle: the same kernels through the row-major tensors (the module-API path that the goldens G8 / G11 / G14 pin)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _renderer(method, seed):
+    from tinynerf_amd import core, models as m
+    torch.manual_seed(seed)
+    if method == "vanilla":
+        fm, dim = m.VanillaFeatureMLP(10, 256, 8), 256
+    else:
+        fm = m.CobafaFeatureField(basis_res=[8, 10, 12], coef_res=8, freqs=[2.0, 3.5, 8.0], channels=[8, 8, 4], mlp_hidden_dim=128)
+        fm.dropout.p = 0.0
+        dim = 128
+    r = core.NerfRenderer(fm, m.VanillaOpacityDecoder(dim), m.VanillaColorDecoder(8, dim, 64, 3), torch.ones(3)).to(DEV)
+    with torch.no_grad():
+        r.sigma_decoder.net.net[2].bias.add_(2.0)
+    return r
+
+
+def _batch(n_rays, per_ray, seed):
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(max(1, per_ray // 2), per_ray + 1, (n_rays,), generator=g)
+    counts[3] = 0                                                    # an empty ray
+    start = torch.cumsum(counts, 0) - counts
+    n = int(counts.sum())
+    packed = torch.rand(n, 7, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
+    packed[:, 3:6] = torch.repeat_interleave(d, counts, dim=0)
+    packed[:, 6] = 0.02 + 0.03 * torch.rand(n, generator=g)
+    info = torch.stack([start, counts], 1).to(torch.int32)
+    return packed.to(DEV), info.to(DEV), torch.rand(n_rays, 3, generator=g).to(DEV)
+
+
+@pytest.mark.parametrize("method,n_rays,per_ray", [("vanilla", 61, 40), ("vanilla", 700, 57), ("cobafa", 300, 33)])
+def test_row_views_equal_row_major_tensors(method, n_rays, per_ray):
+    from tinynerf_amd import models as m
+    from tinynerf_amd.arena import Arena
+    packed, info, target = _batch(n_rays, per_ray, 5)
+    assert packed.size(0) % 32 != 0 or method == "cobafa"            # ragged last tile
+    grads = {}
+    for rows in (False, True):
+        r = _renderer(method, 21)
+        r.fused = True
+        if rows:                                                     # what run.Trainer sets up
+            r.reuse_buffers = True
+            arena = Arena()
+            for i, mod in enumerate(mm for mm in r.feature_module.modules() if isinstance(mm, m.MLP)):
+                mod.__dict__["scratch"] = (arena, f"ws{i}", {})
+        out = r(packed, info)
+        torch.nn.functional.mse_loss(out, target).backward()
+        if rows:
+            links = [mm.__dict__["scratch"][2] for mm in r.feature_module.modules() if isinstance(mm, m.MLP)]
+            assert len(links) == 1 and links[0].get("n") == packed.size(0) and links[0]["delivered"] is False      # consumed by the stack's backward
+            assert links[0]["width"] == (256 if method == "vanilla" else 128)
+        grads[rows] = {k: p.grad.detach().cpu().numpy() for k, p in r.named_parameters()}
+        grads[rows]["__out"] = out.detach().cpu().numpy()
+    assert np.array_equal(grads[True]["__out"], grads[False]["__out"])        # the forward is the same launches
+    for k, ref in grads[False].items():
+        # same products, summed in another order (row tiles / atomics): 2e-5 of the largest element per tensor
+        np.testing.assert_allclose(grads[True][k], ref, rtol=0, atol=2e-5 * max(float(np.abs(ref).max()), 1e-30), err_msg=k)
+
+
+def test_rows_view_reports_only_layer_kernel_stacks():
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    fm = m.VanillaFeatureMLP(10, 256, 8).to(DEV)
+    desc = m._mlp_desc(fm.net.params(), 3, L.ENC_POSENC, 10, L.ACT_NONE, fm.encoding.freqs)
+    y, g, st = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    assert L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) == 0
+    rows_h, rows_e = 9 * 256, 64
+    assert y.value == (rows_h + rows_e) * 32 and g.value == y.value + 256 * 32 and st.value == (rows_h + rows_e + 512) * 32
+    fn = L.lib().tn_mlp_bwd_workspace_bytes
+    fn.restype = C.c_int64
+    assert fn(C.byref(desc), C.c_int64(1000)) == 32 * st.value * 4
+    od = m.VanillaOpacityDecoder(256).to(DEV)                         # a width-64 head has no row views
+    d2 = m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
+    assert L.lib().tn_mlp_rows_view(C.byref(d2), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) != 0

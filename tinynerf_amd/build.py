@@ -36,6 +36,7 @@ SOURCES = {
     "mlp.hip": FAST,
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_wgrad_rows.hip": FAST + ["-munsafe-fp-atomics"],
 }
 
 

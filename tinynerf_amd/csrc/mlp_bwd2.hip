@@ -360,7 +360,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
 
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
-        if ((KP || gx != nullptr || a.gx_rows != nullptr) && a.enc != TN_ENC_POSENC) {
+        if ((KP || gx != nullptr || (!KP && a.gx_rows != nullptr)) && a.enc != TN_ENC_POSENC) {
             f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             f32x4 old[4], oldn[4];
             // d loss / d x as [feature][32-sample] rows (tn_mlp_desc::grad_x_rows: the consumer is a wide stack's layer kernel):
             // the D tile of a 32-column block IS 32 such rows, written like every workspace row
-            float *const gxr = a.gx_rows != nullptr ? a.gx_rows + tile * a.gx_rows_stride : nullptr;      // (wave-uniform)
+            float *const gxr = (!KP && a.gx_rows != nullptr) ? a.gx_rows + tile * a.gx_rows_stride : nullptr;      // (wave-uniform)
             if constexpr (ACCUM) {
                 if (gxr == nullptr) {
 #pragma unroll

@@ -991,6 +991,9 @@ int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hip
     return tn::check_launch("fwd_lds_kernel");
 }
 
+// the layer-kernel training forward (run_fwd_only): one launch per layer, [feature][32-sample] rows between them
+__host__ inline bool layer_kernel_path(int H, int L, int out) { return H >= 128 && L >= 3 && out > 4 && out <= H; }
+
 template <int H>
 int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s)
 {
@@ -999,7 +1002,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
     const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
     if constexpr (H >= 128) {
         const int L = a.n_layers, out = a.out_dim;
-        if (L >= 3 && out > 4 && out <= H) {      // first layer, then one launch per layer with W in LDS
+        if (layer_kernel_path(H, L, out)) {       // first layer, then one launch per layer with W in LDS
             const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
             if (a.enc == TN_ENC_POSENC && a.K0_pad <= 64) {      // encoded inputs as rows, then the first layer like any other
                 enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, lay.total,
@@ -1031,13 +1034,18 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
 
 template <int H>
 int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *gy, int64_t n, float *const *gw,
-               float *const *gb, float *gx, float *stash, hipStream_t s, bool stashed = false)
+               float *const *gb, float *gx, float *stash, hipStream_t s, bool stashed = false, bool gy_rows = false)
 {
     const int L = a.n_layers;
     const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim);
     const int64_t n_tiles = (n + 31) / 32;
     constexpr int WPB = H <= 64 ? 8 : 4;
-    if (stashed) {        // activations and the last pre-activation are in the workspace already (tn_mlp_fwd_stash)
+    if (gy_rows) {
+        // TN_MLP_GRAD_Y_ROWS: the consumers of y (the heads' data-gradient chains) have written d loss / d y as rows into
+        // buffer B (tn_mlp_rows_view): nothing to transpose, the walk below starts from B and ping-pongs into A
+        TN_REQUIRE(stashed && a.out_act == TN_ACT_NONE && (a.out_dim & 31) == 0, TN_E_CONFIG,
+                   "tn_mlp_bwd: TN_MLP_GRAD_Y_ROWS needs TN_MLP_STASHED, no output activation and out_dim % 32 == 0");
+    } else if (stashed) {        // activations and the last pre-activation are in the workspace already (tn_mlp_fwd_stash)
         out_grad_kernel<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * 8)), dim3(256), 0, s>>>(gy, n, a.out_dim, a.out_act, lay.total,
                                                                                          lay.rowsH + lay.rowsE, stash);
         if (int rc = tn::check_launch("out_grad_kernel")) return rc;
@@ -1047,7 +1055,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if (int rc = tn::check_launch("fwd_stash_kernel")) return rc;
     }
     const int offE = lay.rowsH, offGA = lay.rowsH + lay.rowsE, offGB = offGA + lay.rowsG;
-    int cur = offGA, nxt = offGB;
+    int cur = gy_rows ? offGB : offGA, nxt = gy_rows ? offGA : offGB;
     for (int l = L - 1; l >= 0; --l) {
         WgradArgs w;
         w.gW = gw[l]; w.gB = gb[l]; w.N = a.N[l]; w.K = a.K[l]; w.K_pad = l == 0 ? a.K0_pad : a.K[l];
@@ -1129,18 +1137,37 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_
     MlpArgs a;
     int H = 0;
     if (int rc = plan(desc, a, H)) return rc;
-    TN_REQUIRE(x && grad_y && grad_weights && grad_biases && workspace, TN_E_NULL, "tn_mlp_bwd(layers): null pointer");
+    TN_REQUIRE(x && (grad_y || (desc->flags & TN_MLP_GRAD_Y_ROWS)) && grad_weights && grad_biases && workspace, TN_E_NULL,
+               "tn_mlp_bwd(layers): null pointer");
     TN_REQUIRE(a.enc != TN_ENC_DIR_CAT || aux, TN_E_NULL, "tn_mlp_bwd(layers): dir_cat needs aux");
     for (int l = 0; l < a.n_layers; ++l)
         TN_REQUIRE(grad_weights[l] && grad_biases[l], TN_E_NULL, "tn_mlp_bwd(layers): null gradient pointer");
     hipStream_t s = (hipStream_t)stream;
-    const bool stashed = (desc->flags & TN_MLP_STASHED) != 0;
+    const bool stashed = (desc->flags & TN_MLP_STASHED) != 0, gy_rows = (desc->flags & TN_MLP_GRAD_Y_ROWS) != 0;
     switch (H) {
-    case 32: return run_layers<32>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
-    case 64: return run_layers<64>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
-    case 128: return run_layers<128>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
-    default: return run_layers<256>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed);
+    case 32: return run_layers<32>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed, gy_rows);
+    case 64: return run_layers<64>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed, gy_rows);
+    case 128: return run_layers<128>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed, gy_rows);
+    default: return run_layers<256>(a, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, workspace, s, stashed, gy_rows);
     }
+}
+
+extern "C" int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_rows, int64_t *grad_y_rows, int64_t *tile_stride)
+{
+    TN_REQUIRE(desc && y_rows && grad_y_rows && tile_stride, TN_E_NULL, "tn_mlp_rows_view: null pointer");
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mlp_rows_view: negative n");
+    const int L = desc->n_layers;
+    TN_REQUIRE(L >= 2 && L <= TN_MLP_MAX_LAYERS, TN_E_CONFIG, "tn_mlp_rows_view: n_layers must be in [2, 12]");
+    const int H = desc->dims[1], out = desc->dims[L];
+    // the configurations whose training forward runs layer by layer and leaves y^T behind (run_fwd_only), see tn_mlp_fwd_stash
+    TN_REQUIRE(!two_pass_supported(desc) && tn_mlp_bwd_layers_workspace_bytes(desc, 32) > 0 && layer_kernel_path(H, L, out) &&
+                   (out & 31) == 0 && desc->out_activation == TN_ACT_NONE && desc->encoding != TN_ENC_AUX_CAT, TN_E_CONFIG,
+               "tn_mlp_rows_view: only wide stacks evaluated layer by layer (width 128 / 256, >= 3 layers, out % 32 == 0, no output activation) keep row views");
+    const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, out);
+    *y_rows = (int64_t)(lay.rowsH + lay.rowsE) * 32;                 // buffer A: the last layer's (pre-)activation = y
+    *grad_y_rows = (int64_t)(lay.rowsH + lay.rowsE + lay.rowsG) * 32;    // buffer B
+    *tile_stride = (int64_t)lay.total * 32;
+    return TN_OK;
 }
 
 // training forward of a stack the layer-by-layer form covers: y + activations + last pre-activation into the workspace

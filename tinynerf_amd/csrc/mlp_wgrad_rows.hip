@@ -166,7 +166,6 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const flo
     switch (in_dim) {
     case 256: return launch_rows<64, 256, 2, 1>(w, n, s);       // 2 x 8 tiles: wave = one k block, both row blocks
     case 128: return launch_rows<64, 128, 1, 1>(w, n, s);       // 2 x 4 tiles
-    case 64: return launch_rows<64, 64, 1, 1>(w, n, s) ;
-    default: return tn::fail(TN_E_CONFIG, "mlp_bwd: x_rows are implemented for in_dim 64, 128 and 256");
+    default: return tn::fail(TN_E_CONFIG, "mlp_bwd: x_rows are implemented for in_dim 128 and 256");
     }
 }

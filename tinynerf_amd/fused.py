@@ -253,10 +253,16 @@ class _RenderHeads(Function):
     @staticmethod
     def forward(ctx: Any, feat: torch.Tensor, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
                 freqs: torch.Tensor, n_freqs: int, n_sigma: int, accumulate: bool, arena: Optional[Arena], train: bool,
-                hint: Optional[dict], stats: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
+                hint: Optional[dict], stats: Optional[dict], link: Optional[dict], *params: torch.Tensor) -> torch.Tensor:  # type: ignore
         sig_p = [p.contiguous() for p in params[:n_sigma]]
         rgb_p = [p.contiguous() for p in params[n_sigma:]]
         feat = feat.contiguous()
+        # `link`: row views of the wide stack that produced `feat` (models._FusedMLP.forward, harness only): feat^T as
+        # [feature][32-sample] rows in that stack's workspace and the slot where it takes d loss / d feat in the same layout
+        if not (link and train and link.get("n") == feat.size(0) and link.get("y_ptr") == feat.data_ptr() and link.get("width") == feat.size(1)
+                and feat.size(1) in (128, 256)):
+            link = None
+        ctx.link = link
         dev = L.require_cuda(feat, packed, info, *sig_p, *rgb_p)
         n, R = packed.size(0), info.size(0)
         F = feat.size(1)
@@ -338,20 +344,30 @@ class _RenderHeads(Function):
         g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
-        g_feat = _empty_rows(n, F, dev)                      # handed to autograd (the field's backward): not an arena view
+        link = ctx.link
+        # with row views the heads write d loss / d feat straight into the feature stack's workspace (rows) and read feat^T from
+        # there for their first layers' weight gradients; autograd gets a placeholder of the right shape (no memory behind it)
+        g_feat = _empty_rows(n, F, dev) if link is None else None      # handed to autograd (the field's backward): not an arena view
         nr, ns = len(rgb_p) // 2, len(sig_p) // 2
         gw_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[0::2]])
         gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])
         gw_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[0::2]])
         gb_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[1::2]])
         rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED)
+        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | L.MLP_STASHED)     # g_feat += d sigma / d feat
+        if link is not None:
+            for d in (rdesc, sdesc):
+                d.x_rows, d.grad_x_rows = link["y_rows"], link["grad_rows"]
+                d.x_rows_tile_stride = d.grad_x_rows_tile_stride = link["stride"]
         L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw_r, gb_r, L.ptr(g_feat),
                L.ptr(ws_r), C.c_int64(rb))
-        sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | L.MLP_STASHED)     # g_feat += d sigma / d feat
         L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s, L.ptr(g_feat),
                L.ptr(ws_s), C.c_int64(sb))
+        if link is not None:
+            link["delivered"] = True
+            g_feat = torch.empty(1, device=dev).expand(n, F)
         grads = [None if in_place else g for (g, in_place) in bufs]
-        return (g_feat, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+        return (g_feat, None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def _vanilla_decoders(renderer) -> bool:
@@ -390,5 +406,12 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
                                     len(sig_p), accumulate_into_grad, arena, train, hint, stats, *planes, *sig_p, *rgb_p)
     feat = fm(packed[:, :3])
     train = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in (*sig_p, *rgb_p)))
+    link = None
+    if train and arena is not None:          # harness: the stack that produced `feat` may offer row views of its workspace
+        from .models import MLP
+        for mod in fm.modules():
+            sc = mod.__dict__.get("scratch") if isinstance(mod, MLP) else None
+            if sc is not None and len(sc) > 2 and sc[2].get("y_ptr") == feat.data_ptr():
+                link = sc[2]
     return _RenderHeads.apply(feat, packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(sig_p),
-                              accumulate_into_grad, arena, train, hint, stats, *sig_p, *rgb_p)
+                              accumulate_into_grad, arena, train, hint, stats, link, *sig_p, *rgb_p)

@@ -94,8 +94,21 @@ class _FusedMLP(Function):
             # forward's backward before the next forward of the module, so one buffer per module is enough
             ws = scratch[0].get(scratch[1], (ws_bytes // 4,), dev) if scratch is not None else torch.empty(ws_bytes // 4, device=dev)
             L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
+            link = scratch[2] if scratch is not None and len(scratch) > 2 else None
+            if link is not None:
+                # harness: wide stacks evaluated layer by layer keep y as [feature][32-sample] rows in their workspace and take
+                # d loss / d y in that layout (tn_mlp_rows_view): the render node behind this stack (fused._RenderHeads) reads
+                # / writes them there instead of going through row-major [n, 256] tensors
+                link.clear()
+                y_off, g_off, stride = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+                if L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(n), C.byref(y_off), C.byref(g_off), C.byref(stride)) == 0:
+                    link.update(ws=ws, y_rows=ws.data_ptr() + 4 * y_off.value, grad_rows=ws.data_ptr() + 4 * g_off.value,
+                                stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(), delivered=False)
+            ctx.link = link
         else:
             L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
+        if not hasattr(ctx, "link"):
+            ctx.link = None
         ctx.save_for_backward(x2, aux2, freqs, ws, *ps)
         ctx.cfg = (encoding, n_freqs, out_act)
         ctx.x_shape = x.shape
@@ -107,8 +120,13 @@ class _FusedMLP(Function):
         encoding, n_freqs, out_act = ctx.cfg
         dev = x2.device
         n = x2.size(0)
-        gy = grad_y.reshape(n, -1).to(torch.float32).contiguous()
-        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs, L.MLP_STASHED if ws_fwd is not None else 0)
+        # d loss / d y already deposited as rows in the workspace by the consumer (see forward): grad_y is a placeholder
+        delivered = ctx.link is not None and ctx.link.get("delivered") and ctx.link.get("ws") is ws_fwd
+        if delivered:
+            ctx.link["delivered"] = False
+        gy = None if delivered else grad_y.reshape(n, -1).to(torch.float32).contiguous()
+        desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs,
+                         (L.MLP_STASHED if ws_fwd is not None else 0) | (L.MLP_GRAD_Y_ROWS if delivered else 0))
         grads = [torch.zeros_like(p) for p in ps]
         n_layers = len(ps) // 2
         gw = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[0::2]])
@@ -163,7 +181,7 @@ class MLP(torch.nn.Module):
 
     def fused(self, x: torch.Tensor, aux: Optional[torch.Tensor] = None, encoding: int = L.ENC_NONE, n_freqs: int = 0,
               out_act: int = L.ACT_NONE, freqs: Optional[torch.Tensor] = None) -> torch.Tensor:
-        # `scratch` = (arena.Arena, buffer name), set by the training harness (run.Trainer); None: allocate per call
+        # `scratch` = (arena.Arena, buffer name, row-view link dict), set by the training harness (run.Trainer); None: allocate per call
         return _FusedMLP.apply(x, aux, freqs, encoding, n_freqs, out_act, torch.is_grad_enabled(), self.__dict__.get("scratch"),
                                *self.params())
 

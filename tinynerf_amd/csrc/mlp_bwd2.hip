@@ -25,8 +25,8 @@
 extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
-extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, const float *x_rows, int64_t x_stride, int in_dim, float *gW,
-                                 int ldw, int col0, float *gB, int64_t n, void *stream);
+extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows, int64_t a_stride, int na, float *gW,
+                                 int ldw, int col0, int kmax, float *gB, int64_t n, void *stream);
 
 namespace {
 
@@ -968,8 +968,8 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (x_rows) {
         const int extra_r = extra_rows(a.enc, a.in_dim, a.K0_pad);
         const int col0 = (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) ? a.K0 - a.in_dim : 0;      // torch order [PE(d), d, x]
-        if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)NH * H * 32, (int64_t)stash_rows(H, NH, extra_r) * 32, a.x_rows, a.x_rows_stride,
-                                       a.in_dim, gw[0], a.K0, col0, gb[0], n, s)) return rc;
+        if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)NH * H * 32, (int64_t)stash_rows(H, NH, extra_r) * 32, H, a.x_rows, a.x_rows_stride,
+                                       a.in_dim, gw[0], a.K0, col0, a.in_dim, gb[0], n, s)) return rc;
         w.tk_skip = a.in_dim / 32;
     }
     w.total_tiles = T * (w.Tk0 - w.tk_skip) + (NH - 1) * T * T + T;

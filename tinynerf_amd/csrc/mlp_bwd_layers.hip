@@ -13,6 +13,9 @@
 #include "mlp_stage.h"
 #include <algorithm>
 
+extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows, int64_t a_stride, int na, float *gW,
+                                 int ldw, int col0, int kmax, float *gB, int64_t n, void *stream);
+
 namespace {
 
 using tn::f32x16;
@@ -1067,6 +1070,16 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if constexpr (H == 256 || H == 128) {
             if (!w.first && w.N == H && w.K == H) {
                 if (int rc = launch_wgrad_lds<H, 2, H == 256 ? 4 : 1>(w, n, stash, s)) return rc;
+                staged = true;
+            }
+        }
+        if constexpr (H == 256) {
+            // first layer of the width-256 stack on positional-encoding inputs (<= 64 slots, all of them E rows of this workspace):
+            // the row-operand kernel of mlp_wgrad_rows.hip (LDS-direct tiles, 2 x 1 accumulator tiles per wave) instead of
+            // per-wave operand loads from L2
+            if (!staged && w.first && lay.xs == 0 && w.K_pad == 64 && w.N == H) {
+                if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)cur * 32, (int64_t)lay.total * 32, H, stash + (int64_t)offE * 32,
+                                               (int64_t)lay.total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
                 staged = true;
             }
         }

@@ -29,7 +29,7 @@ struct WgradRowsArgs {
     int64_t g_stride, a_stride; // floats
     float *gW;                  // [NG][ldw]: dW[n][col0 + k]
     float *gB;                  // [NG] or nullptr
-    int ldw, col0;
+    int ldw, col0, kmax;        // columns k >= kmax are padding (not written)
 };
 
 __device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = 32 * (tn0 + bn) + frow(r, h);
-                atomicAdd(&a.gW[(int64_t)nn * a.ldw + a.col0 + k], acc[bn][bk][r]);
+                if (k < a.kmax) atomicAdd(&a.gW[(int64_t)nn * a.ldw + a.col0 + k], acc[bn][bk][r]);
             }
         }
         if (tk0 == 0 && a.gB != nullptr) {
@@ -155,17 +155,19 @@ int launch_rows(const WgradRowsArgs &w, int64_t n, hipStream_t s)
 
 }  // namespace
 
-// internal entry point (mlp_bwd2.hip): first-layer weight gradient of a width-64 head over its `in_dim` x columns
-extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, const float *x_rows,
-                                                                      int64_t x_stride, int in_dim, float *gW, int ldw, int col0, float *gB,
-                                                                      int64_t n, void *stream)
+// internal entry point (mlp_bwd2.hip, mlp_bwd_layers.hip): dW[NG][col0 + k] += G[NG][s] A[NA][s]^T for k < kmax, db[NG] += sum_s G
+//   (64, 256) / (64, 128): first layer of a width-64 head over the x columns it reads from a 256- / 128-wide stack;
+//   (256, 64): first layer of the width-256 stack itself over its <= 64 positional-encoding slots (E rows of its workspace)
+extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows,
+                                                                      int64_t a_stride, int na, float *gW, int ldw, int col0, int kmax,
+                                                                      float *gB, int64_t n, void *stream)
 {
     WgradRowsArgs w;
-    w.g_rows = g_rows; w.a_rows = x_rows; w.g_stride = g_stride; w.a_stride = x_stride; w.gW = gW; w.gB = gB; w.ldw = ldw; w.col0 = col0;
+    w.g_rows = g_rows; w.a_rows = a_rows; w.g_stride = g_stride; w.a_stride = a_stride; w.gW = gW; w.gB = gB; w.ldw = ldw; w.col0 = col0;
+    w.kmax = kmax;
     hipStream_t s = (hipStream_t)stream;
-    switch (in_dim) {
-    case 256: return launch_rows<64, 256, 2, 1>(w, n, s);       // 2 x 8 tiles: wave = one k block, both row blocks
-    case 128: return launch_rows<64, 128, 1, 1>(w, n, s);       // 2 x 4 tiles
-    default: return tn::fail(TN_E_CONFIG, "mlp_bwd: x_rows are implemented for in_dim 128 and 256");
-    }
+    if (ng == 64 && na == 256) return launch_rows<64, 256, 2, 1>(w, n, s);       // 2 x 8 tiles: wave = one k block, both row blocks
+    if (ng == 64 && na == 128) return launch_rows<64, 128, 1, 1>(w, n, s);       // 2 x 4 tiles
+    if (ng == 256 && na == 64) return launch_rows<256, 64, 2, 1>(w, n, s);       // 8 x 2 tiles: wave = two row blocks, one k block
+    return tn::fail(TN_E_CONFIG, "mlp_bwd: row-operand weight gradient is built for 64 x 256, 64 x 128 and 256 x 64");
 }

@@ -219,6 +219,14 @@ int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_rows, int64_
  * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */
 int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
                float *pre_act, void *stream);
+/* Inference forward with scratch: wide stacks on positional-encoding inputs (the Vanilla feature MLP, models.py:59-68) run
+ * layer by layer through the weight-in-register kernels of the training forward, the activations ping-ponging between two
+ * [feature][32-sample] row buffers in `workspace` (tn_mlp_fwd_workspace_bytes(desc, n) bytes: 2.3 KB per sample at width
+ * 256; 0 = this configuration has no such form, use tn_mlp_fwd).  Same MFMA steps in the same order as the training
+ * forward: identical y.  Used by infer() (run.py:15-50) and the occupancy refresh (core.py:133-145). */
+int64_t tn_mlp_fwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
+int tn_mlp_fwd_ws(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, void *workspace,
+                  int64_t workspace_bytes, void *stream);
 /* Training forward: y as tn_mlp_fwd, plus the hidden activations, their ReLU bit masks and the last layer's
  * pre-activation into `workspace` (tn_mlp_bwd_workspace_bytes(desc, n) bytes) in the layout tn_mlp_bwd's
  * backward (two-pass or layer-by-layer form) uses; pass the same workspace to tn_mlp_bwd with TN_MLP_STASHED set.

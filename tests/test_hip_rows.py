@@ -84,3 +84,28 @@ def test_rows_view_reports_only_layer_kernel_stacks():
     od = m.VanillaOpacityDecoder(256).to(DEV)                         # a width-64 head has no row views
     d2 = m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
     assert L.lib().tn_mlp_rows_view(C.byref(d2), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) != 0
+
+
+@pytest.mark.parametrize("n", [1, 777, 40000])
+def test_inference_through_the_layer_kernels(n):
+    """tn_mlp_fwd_ws (wide stack, layer kernels, two ping-pong row buffers) == the training forward's y bit for bit (same MFMA
+    steps in the same order) and == the register-resident inference kernel tn_mlp_fwd to fp32 rounding."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    torch.manual_seed(3)
+    fm = m.VanillaFeatureMLP(10, 256, 8).to(DEV)
+    x = (torch.rand(n, 3, device=DEV) * 2 - 1).contiguous()
+    with torch.no_grad():
+        y_inf = fm(x)                                               # no grad: the workspace form (models._FusedMLP.forward)
+    y_train = fm(x.requires_grad_(False))                           # parameters require grad: training forward with stash
+    assert y_train.requires_grad
+    assert torch.equal(y_inf, y_train.detach())
+    desc = m._mlp_desc(fm.net.params(), 3, L.ENC_POSENC, 10, L.ACT_NONE, fm.encoding.freqs)
+    y_reg = torch.empty(n, 256, device=DEV)
+    L.call("tn_mlp_fwd", x.device, C.byref(desc), L.ptr(x), C.c_void_p(None), C.c_int64(n), L.ptr(y_reg), C.c_void_p(None))
+    np.testing.assert_allclose(y_inf.cpu().numpy(), y_reg.cpu().numpy(), rtol=0, atol=2e-6 * float(y_reg.abs().max()))
+    fn = L.lib().tn_mlp_fwd_workspace_bytes
+    fn.restype = C.c_int64
+    assert fn(C.byref(desc), C.c_int64(n)) == ((n + 31) // 32) * (2 * 256 + 64) * 128
+    od = m.VanillaOpacityDecoder(256).to(DEV)
+    assert fn(C.byref(m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)), C.c_int64(n)) == 0

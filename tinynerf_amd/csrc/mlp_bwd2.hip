@@ -994,14 +994,25 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
             }
         }
     }
-#define TN_WGRAD(MAXS_, NW_, NCH_)                                                                                         \
+#define TN_WGRAD_X(MAXS_, NW_, NCH_, AUX_)                                                                                 \
     do {                                                                                                                    \
-        auto wk = mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, false>;                                                        \
+        auto wk = mlp_wgrad_kernel<H, NH, MAXS_, NW_, NCH_, AUX_>;                                                         \
         hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);      \
         if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", wlds, hipGetErrorString(we)); return (int)we; } \
         wk<<<dim3((unsigned)wblocks), dim3(NW_ * 64), wlds, s>>>(w, x, aux, n, stash);                                      \
     } while (0)
-    if (a.enc == TN_ENC_AUX_CAT) return tn::fail(TN_E_CONFIG, "mlp_bwd: TN_ENC_AUX_CAT outside the paired weight-gradient tiling");
+#define TN_WGRAD(MAXS_, NW_, NCH_) TN_WGRAD_X(MAXS_, NW_, NCH_, false)
+    if (a.enc == TN_ENC_AUX_CAT) {
+        // per-ray table columns + hidden + output layers of a head whose x columns went to the row-operand kernel above (the
+        // colour head behind a 256- / 128-wide stack): the general tiling with the table rows staged per tile
+        if constexpr (NH == 4) {
+            if (x_rows && w.total_tiles <= 24 && chunks <= 7 * 768 && wp.aw <= 64) {
+                TN_WGRAD_X(2, 12, 7, true);
+                return tn::check_launch("mlp_wgrad_kernel(aux)");
+            }
+        }
+        return tn::fail(TN_E_CONFIG, "mlp_bwd: TN_ENC_AUX_CAT outside the paired weight-gradient tiling");
+    }
     if (w.total_tiles <= 8 && chunks <= 4 * 512) TN_WGRAD(1, 8, 4);
     else if (w.total_tiles <= 16 && chunks <= 4 * 1024) TN_WGRAD(1, 16, 4);
     else if (w.total_tiles <= 24 && chunks <= 7 * 768) TN_WGRAD(2, 12, 7);     // 12 waves x 2 tiles: 170-VGPR budget, no spills
@@ -1009,6 +1020,7 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     else if (w.total_tiles <= 48 && chunks <= 10 * 1024) TN_WGRAD(3, 16, 10);
     else return tn::fail(TN_E_CONFIG, "mlp_bwd: configuration outside the wgrad tiling");
 #undef TN_WGRAD
+#undef TN_WGRAD_X
     return tn::check_launch("mlp_wgrad_kernel");
 }
 

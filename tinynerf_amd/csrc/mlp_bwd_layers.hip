@@ -997,8 +997,13 @@ int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hip
 // the layer-kernel training forward (run_fwd_only): one launch per layer, [feature][32-sample] rows between them
 __host__ inline bool layer_kernel_path(int H, int L, int out) { return H >= 128 && L >= 3 && out > 4 && out <= H; }
 
+// `inference`: no backward follows, so the hidden activations need not survive: two ping-pong buffers of H rows each (plus the
+// encoded-input rows) instead of one buffer per layer -- (2 H + rowsE) * 128 B per 32 samples (2.3 KB per sample for the
+// Vanilla stack against 11.5 KB of training workspace).
+__host__ inline int infer_rows_total(int H, const Layout &lay) { return 2 * H + lay.rowsE; }
+
 template <int H>
-int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s)
+int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s, bool inference = false)
 {
     const int64_t n_tiles = (n + 31) / 32;
     constexpr int WPB = H <= 64 ? 8 : 4;
@@ -1007,23 +1012,27 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
         const int L = a.n_layers, out = a.out_dim;
         if (layer_kernel_path(H, L, out)) {       // first layer, then one launch per layer with W in LDS
             const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
+            const int total = inference ? infer_rows_total(H, lay) : lay.total;
+            const int offE = inference ? 2 * H : lay.rowsH;
+            auto off_in = [&](int l) { return inference ? ((l - 1) & 1) * H : (l - 1) * H; };
+            auto off_out = [&](int l) { return inference ? (l & 1) * H : (l + 1 < L ? l * H : lay.rowsH + lay.rowsE); };
             if (a.enc == TN_ENC_POSENC && a.K0_pad <= 64) {      // encoded inputs as rows, then the first layer like any other
-                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, lay.total,
-                                                                                                        lay.rowsH);
+                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE);
                 if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
                 FwdLayerArgs f;
-                f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = lay.total;
-                f.off_in = lay.rowsH; f.off_out = 0; f.out_act = a.out_act;
+                f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = total;
+                f.off_in = offE; f.off_out = 0; f.out_act = a.out_act;
                 if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
+                if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: the layer-by-layer inference forward needs positional-encoding inputs");
                 fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
                     a, x, aux, nullptr, n, stash, y);
                 if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
             }
             for (int l = 1; l < L; ++l) {
                 FwdLayerArgs f;
-                f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = lay.total;
-                f.off_in = (l - 1) * H; f.off_out = l + 1 < L ? l * H : lay.rowsH + lay.rowsE; f.out_act = a.out_act;
+                f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = total;
+                f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act;
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
                 const int rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;
@@ -1031,6 +1040,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
             return TN_OK;
         }
     }
+    if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: configuration without a layer-by-layer inference forward");
     fwd_stash_kernel<H, WPB, true><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, nullptr, n, stash, y);
     return tn::check_launch("fwd_stash_kernel(forward)");
 }
@@ -1181,6 +1191,37 @@ extern "C" int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_r
     *grad_y_rows = (int64_t)(lay.rowsH + lay.rowsE + lay.rowsG) * 32;    // buffer B
     *tile_stride = (int64_t)lay.total * 32;
     return TN_OK;
+}
+
+// inference forward of a wide stack on positional-encoding inputs through the layer kernels (88 % of the fp32 matrix rate where the
+// register-resident kernel with weights from L2 reaches 67-70 %): workspace = two ping-pong activation buffers + encoded inputs
+extern "C" int64_t tn_mlp_fwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n)
+{
+    if (!desc || n <= 0) return 0;
+    const int L = desc->n_layers;
+    if (L < 2 || L > TN_MLP_MAX_LAYERS) return 0;
+    const int H = desc->dims[1], out = desc->dims[L];
+    if ((H != 128 && H != 256) || !layer_kernel_path(H, L, out) || desc->encoding != TN_ENC_POSENC || ((desc->dims[0] + 7) & ~7) > 64) return 0;
+    for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
+    const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, out);
+    return ((n + 31) / 32) * (int64_t)infer_rows_total(H, lay) * 32 * (int64_t)sizeof(float);
+}
+
+extern "C" int tn_mlp_fwd_ws(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, void *workspace,
+                             int64_t workspace_bytes, void *stream)
+{
+    TN_REQUIRE(desc, TN_E_NULL, "tn_mlp_fwd_ws: null descriptor");
+    if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_mlp_fwd_ws: negative n");
+    const int64_t need = tn_mlp_fwd_workspace_bytes(desc, n);
+    TN_REQUIRE(need > 0, TN_E_CONFIG, "tn_mlp_fwd_ws: this configuration has no workspace form (tn_mlp_fwd_workspace_bytes == 0): use tn_mlp_fwd");
+    TN_REQUIRE(x && y && workspace && workspace_bytes >= need, TN_E_NULL, "tn_mlp_fwd_ws: null pointer or workspace too small");
+    TN_REQUIRE((((uintptr_t)workspace | (uintptr_t)y) & 15) == 0, TN_E_ALIGN, "tn_mlp_fwd_ws: workspace / y must be 16-byte aligned");
+    MlpArgs a;
+    int H = 0;
+    if (int rc = plan(desc, a, H)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 128) return run_fwd_only<128>(a, x, aux, n, y, (float *)workspace, s, true);
+    return run_fwd_only<256>(a, x, aux, n, y, (float *)workspace, s, true);
 }
 
 // training forward of a stack the layer-by-layer form covers: y + activations + last pre-activation into the workspace

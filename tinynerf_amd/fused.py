@@ -266,18 +266,24 @@ class _RenderHeads(Function):
         dev = L.require_cuda(feat, packed, info, *sig_p, *rgb_p)
         n, R = packed.size(0), info.size(0)
         F = feat.size(1)
-        # (the per-ray direction table of the K-Planes node needs the paired weight-gradient tiling, which is sized for 96
-        # features; here cat[PE(d), d] is evaluated per sample inside the colour head's kernels, TN_ENC_DIR_CAT)
-        if hint is not None and hint.get("key") == (packed.data_ptr(), n, R):
-            steps = hint["steps"]
-        else:
-            steps = _alloc(arena, "steps", (n,), dev)
-            steps.copy_(packed[:, 6])
-        table = _alloc(arena, "dirs", (n, 3), dev)
-        table.copy_(packed[:, 3:6])
-        ray_ids, stride = None, 0
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
-        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
+        if link is not None:
+            # cat[PE(d), d] (models.py:87) once per RAY as a table the kernels index through the ray id of every sample
+            # (TN_ENC_AUX_CAT, as in the K-Planes node): the colour head then takes the plain-column first layer.  Its weight
+            # gradient over a 256-wide x needs the row-operand kernel, hence only with row views
+            table, ray_ids, stride, steps = _ray_aux(packed, info, freqs, n_freqs, arena, hint)
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, 0, ray_ids, stride)
+        else:
+            # cat[PE(d), d] is evaluated per sample inside the colour head's kernels (TN_ENC_DIR_CAT)
+            if hint is not None and hint.get("key") == (packed.data_ptr(), n, R):
+                steps = hint["steps"]
+            else:
+                steps = _alloc(arena, "steps", (n,), dev)
+                steps.copy_(packed[:, 6])
+            table = _alloc(arena, "dirs", (n, 3), dev)
+            table.copy_(packed[:, 3:6])
+            ray_ids, stride = None, 0
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
         ws_s = ws_r = None
         sb = rb = 0
         if train:
@@ -353,7 +359,10 @@ class _RenderHeads(Function):
         gb_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[1::2]])
         gw_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[0::2]])
         gb_s = (C.c_void_p * ns)(*[g.data_ptr() for g in g_sig[1::2]])
-        rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED)
+        if link is not None:
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED, ray_ids, stride)
+        else:
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED)
         sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_ACCUM_GRAD_X | L.MLP_STASHED)     # g_feat += d sigma / d feat
         if link is not None:
             for d in (rdesc, sdesc):

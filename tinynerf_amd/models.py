@@ -106,7 +106,20 @@ class _FusedMLP(Function):
                                 stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(), delivered=False)
             ctx.link = link
         else:
-            L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
+            # inference (infer(), the occupancy refresh): wide stacks run through the layer kernels with two ping-pong row
+            # buffers as scratch (tn_mlp_fwd_ws), in chunks of <= 2^22 samples so that the scratch stays below 10 GB
+            fwd_ws = L.lib().tn_mlp_fwd_workspace_bytes
+            fwd_ws.restype = C.c_int64
+            chunk = 1 << 22
+            nbytes = int(fwd_ws(C.byref(desc), C.c_int64(min(n, chunk)))) if (n > 0 and aux2 is None) else 0
+            if nbytes:
+                wsi = torch.empty(nbytes // 4, device=dev)
+                for k in range(0, n, chunk):
+                    m_ = min(chunk, n - k)
+                    L.call("tn_mlp_fwd_ws", dev, C.byref(desc), L.ptr(x2[k:k + m_]), C.c_void_p(None), C.c_int64(m_), L.ptr(y[k:k + m_]),
+                           L.ptr(wsi), C.c_int64(nbytes))
+            else:
+                L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
         if not hasattr(ctx, "link"):
             ctx.link = None
         ctx.save_for_backward(x2, aux2, freqs, ws, *ps)

@@ -210,10 +210,12 @@ def test_inference_chunking_and_no_training_state(method):
     assert torch.equal(a, b)
     n_kept = int(tr.ray_provider(oo, dd, training=False)[0].size(0))
     assert n_kept > 10000
-    # packed samples, features, head outputs: under 3 KB per kept sample (+ 16 MiB of per-ray scratch); the training workspace
-    # of the Vanilla stack alone would be 10.5 KB per sample
+    # packed samples, features, head outputs: under 3 KB per kept sample (+ 16 MiB of per-ray scratch), plus -- Vanilla -- the two
+    # ping-pong row buffers of the layer-kernel inference forward (tn_mlp_fwd_ws: 2.3 KB per sample, at most 2^22 samples at a
+    # time); the training workspace of the Vanilla stack alone would be 11.5 KB per sample
     peak = torch.cuda.max_memory_allocated() - base
-    assert peak < n_kept * 3072 + (16 << 20), (peak / n_kept, n_kept)
+    per_sample = 3072 + (2432 if method == "vanilla" else 0)
+    assert peak < n_kept * per_sample + (16 << 20), (peak / n_kept, n_kept)
 
 
 def test_random_ray_stream_walks_shuffled_epochs():

@@ -35,7 +35,7 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
 }
 
 struct Layout {            // rows (of 32 floats) per 32-sample tile
-    int rowsH, rowsE, rowsG, total;
+    int rowsH, rowsE, rowsG, rowsM, total;
     int xs;                // first-layer slots that are plain x columns
 };
 __host__ __device__ inline Layout make_layout(int H, int n_layers, int enc, int in_dim, int K0_pad, int out_dim) {
@@ -45,7 +45,11 @@ __host__ __device__ inline Layout make_layout(int H, int n_layers, int enc, int 
     L.rowsE = enc == TN_ENC_NONE ? 0 : K0_pad - L.xs;
     const int outp = (out_dim + 31) & ~31;
     L.rowsG = H > outp ? H : outp;
-    L.total = L.rowsH + L.rowsE + 2 * L.rowsG;
+    // wide stacks (layer kernels): ReLU bit masks of every hidden activation, one dword per lane and 32-feature block = 2 rows
+    // per (activation, block), behind the two gradient buffers -- the data-gradient kernel reads ONE dword per lane where the
+    // float mask rows cost it 16 row loads per tile (each vector-memory instruction stalls the matrix pipe for ~40 cycles)
+    L.rowsM = H >= 128 ? 2 * (H / 32) * (n_layers - 1) : 0;
+    L.total = L.rowsH + L.rowsE + 2 * L.rowsG + L.rowsM;
     return L;
 }
 
@@ -216,6 +220,7 @@ struct DgradArgs {
     int N, K;             // rows / columns of W
     int rows_total;       // stash rows per tile
     int off_gin, off_gout, off_mask;    // row offsets inside a tile
+    int off_bits;                       // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
     int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
     int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
 };
@@ -396,6 +401,7 @@ struct FwdLayerArgs {
     int Kp;               // input rows present in the workspace (K for hidden layers, K0_pad for the encoded first layer)
     int rows_total, off_in, off_out;
     int out_act;
+    int off_bits;         // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
 };
 
 // T = 32-row blocks of the layer input: 2 for the positional-encoding first layer, whose encoded inputs (<= 64 slots)
@@ -461,8 +467,10 @@ __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64
                 }
             }
             tn::pin16(acc);
+            acc = tn::relu16(acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) outp[(32 * ot + frow(r, h)) * 32 + j] = fmaxf(acc[r], 0.0f);
+            for (int r = 0; r < 16; ++r) outp[(32 * ot + frow(r, h)) * 32 + j] = acc[r];
+            if (a.off_bits >= 0) reinterpret_cast<unsigned *>(st + (a.off_bits + 2 * ot) * 32)[lane] = relu_bits(acc);
         }
     }
 }
@@ -602,6 +610,10 @@ __global__ __launch_bounds__(512) void fwd_wreg_kernel(FwdLayerArgs a, int64_t n
         if (!LAST || 32 * ob < a.N) {
             if constexpr (!LAST) {
                 wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc);
+                if (a.off_bits >= 0) {                  // (wave-uniform) ReLU bits of this block for the data-gradient kernel
+                    unsigned *bits = reinterpret_cast<unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * ob));
+                    bits[lane] = relu_bits(acc);
+                }
             } else {
                 float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
                 const int64_t row = tile * 32 + j;
@@ -704,7 +716,9 @@ __global__ __launch_bounds__(512) void dgrad_wreg_kernel(DgradArgs a, int64_t n,
         if (it > 0) emit(tile_of(it - 1), res);
         const int64_t tile = tile_of(it);
         float m[16];
-        wreg_load_block(urow(stash, tile * a.rows_total + a.off_mask), kb, j, h, m);
+        unsigned mbits = 0;
+        if (a.off_bits >= 0) mbits = reinterpret_cast<const unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * kb))[lane];
+        else wreg_load_block(urow(stash, tile * a.rows_total + a.off_mask), kb, j, h, m);
         wreg_load_rows(urow(stash, tile_of(it + 2) * a.rows_total + a.off_gin), kb, j, h, stage);
         __builtin_amdgcn_sched_barrier(0);
         const float *bt = buf + cur * G::TILE + j * SW + 4 * h;
@@ -718,8 +732,13 @@ __global__ __launch_bounds__(512) void dgrad_wreg_kernel(DgradArgs a, int64_t n,
         wreg_first_pair(bt, 2 * T, b);
         wreg_mfma_run<2 * T, 4 * T, T>(acc, W, bt, b);
         tn::pin16(acc);
+        if (a.off_bits >= 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = m[r] > 0.0f ? acc[r] : 0.0f;
+            for (int r = 0; r < 16; ++r) res[r] = mask_keep(acc[r], mbits, r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = m[r] > 0.0f ? acc[r] : 0.0f;
+        }
         cur = nxt;
     }
     emit(tile_of(iters - 1), res);
@@ -1016,12 +1035,14 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
             const int offE = inference ? 2 * H : lay.rowsH;
             auto off_in = [&](int l) { return inference ? ((l - 1) & 1) * H : (l - 1) * H; };
             auto off_out = [&](int l) { return inference ? (l & 1) * H : (l + 1 < L ? l * H : lay.rowsH + lay.rowsE); };
+            const int offM = lay.rowsH + lay.rowsE + 2 * lay.rowsG;
+            auto off_bits = [&](int l) { return (inference || l + 1 >= L) ? -1 : offM + 2 * (H / 32) * l; };      // activation l = output of layer l
             if (a.enc == TN_ENC_POSENC && a.K0_pad <= 64) {      // encoded inputs as rows, then the first layer like any other
                 enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE);
                 if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
                 FwdLayerArgs f;
                 f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = total;
-                f.off_in = offE; f.off_out = 0; f.out_act = a.out_act;
+                f.off_in = offE; f.off_out = 0; f.out_act = a.out_act; f.off_bits = off_bits(0);
                 if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
                 if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: the layer-by-layer inference forward needs positional-encoding inputs");
@@ -1032,7 +1053,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
             for (int l = 1; l < L; ++l) {
                 FwdLayerArgs f;
                 f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = total;
-                f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act;
+                f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act; f.off_bits = off_bits(l);
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
                 const int rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;
@@ -1102,6 +1123,10 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         DgradArgs d;
         d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
         d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? (l - 1) * H : 0;
+        // ReLU bit rows exist for the activations the layer kernels of the training forward wrote (run_fwd_only): every hidden
+        // one, and the first layer's when it ran as fwd_lds_kernel (positional-encoding inputs)
+        const bool bits = stashed && layer_kernel_path(H, L, a.out_dim) && l >= 1 && (l >= 2 || (a.enc == TN_ENC_POSENC && a.K0_pad <= 64));
+        d.off_bits = bits ? lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * (l - 1) : -1;
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {

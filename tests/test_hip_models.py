@@ -740,7 +740,8 @@ def test_mlp_forward_row_gate_skips_dead_tiles_only():
 
 def test_fused_mlp_takes_the_stash_forward_only_while_recording(monkeypatch):
     """training: the forward writes the backward's activation workspace (tn_mlp_fwd_stash: nothing is recomputed); inside
-    torch.no_grad() (infer(), the occupancy refresh) the plain forward runs and no workspace is allocated.  (Inside
+    torch.no_grad() (infer(), the occupancy refresh) the inference forward runs (wide stacks: tn_mlp_fwd_ws, layer kernels with
+    two ping-pong row buffers; everything else: tn_mlp_fwd) and no training workspace is allocated.  (Inside
     Function.forward grad mode is always off and needs_input_grad always reports the parameters: the call site decides.)"""
     m = models()
     from tinynerf_amd import _lib as L
@@ -756,4 +757,9 @@ def test_fused_mlp_takes_the_stash_forward_only_while_recording(monkeypatch):
     del names[:]
     with torch.no_grad():
         y2 = net(x)
-    assert names == ["tn_mlp_fwd"] and torch.equal(y2, y.detach())
+    assert names == ["tn_mlp_fwd_ws"] and torch.equal(y2, y.detach())
+    del names[:]
+    od = m.VanillaOpacityDecoder(256).to(DEV)
+    with torch.no_grad():
+        od(y2)
+    assert names == ["tn_mlp_fwd"]

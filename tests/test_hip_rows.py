@@ -76,8 +76,8 @@ def test_rows_view_reports_only_layer_kernel_stacks():
     desc = m._mlp_desc(fm.net.params(), 3, L.ENC_POSENC, 10, L.ACT_NONE, fm.encoding.freqs)
     y, g, st = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     assert L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) == 0
-    rows_h, rows_e = 9 * 256, 64
-    assert y.value == (rows_h + rows_e) * 32 and g.value == y.value + 256 * 32 and st.value == (rows_h + rows_e + 512) * 32
+    rows_h, rows_e, rows_m = 9 * 256, 64, 2 * 8 * 9          # hidden activations, encoded inputs, ReLU bit rows (2 per block and activation)
+    assert y.value == (rows_h + rows_e) * 32 and g.value == y.value + 256 * 32 and st.value == (rows_h + rows_e + 512 + rows_m) * 32
     fn = L.lib().tn_mlp_bwd_workspace_bytes
     fn.restype = C.c_int64
     assert fn(C.byref(desc), C.c_int64(1000)) == 32 * st.value * 4

@@ -950,20 +950,13 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradArgs a, int64_t n, 
                 dbacc[bn] += s;
             }
         }
-        // The tile's ONE barrier (next tile landed + everybody done reading this one) sits in front of the LAST k block's MFMAs,
-        // whose operands are in registers by then: behind it nobody reads this buffer any more (so the next iteration may
-        // overwrite it), a wave that arrives early still has 16 BN MFMAs to issue, and the first LDS reads of the next tile
-        // are requested while those run -- at the end of the iteration the barrier, the DMA wait and an LDS round trip were
-        // all exposed at once on every wave of the workgroup.  (BK == 1: the tile is too short to hide the DMA in front of it.)
+        // (measured and not kept: the barrier in front of the LAST k block's MFMAs, whose operands are in registers by then, so
+        // that an early wave still has MFMAs to issue behind it -- 1.043 ms per layer against 1.015 with the barrier at the end)
 #pragma unroll
         for (int bk = 0; bk < BK; ++bk) {
             f32x4 av[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(buf + a_off[bk] + 4 * ((4 * h + e) ^ swz));
-            if (BK > 1 && bk == BK - 1) {
-                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));       // operands in registers before the barrier
-                __syncthreads();
-            }
 #pragma unroll
             for (int bn = 0; bn < BN; ++bn)
 #pragma unroll
@@ -971,7 +964,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradArgs a, int64_t n, 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc[bn][bk] = tn::mfma32(gv[bn][e][u], av[e][u], acc[bn][bk]);
         }
-        if (BK == 1) __syncthreads();                      // (drains this wave's LDS-direct loads: the next tile is in place)
+        __syncthreads();                                   // (drains this wave's LDS-direct loads: the next tile is in place)
         cur ^= 1;
     }
 #pragma unroll

@@ -175,6 +175,12 @@ enum { TN_ENC_NONE = 0,
 #define TN_MLP_GRAD_Y_ROWS 16   /* tn_mlp_bwd of a layer-by-layer configuration (tn_mlp_rows_view): d loss / d y already sits in the
                                  * workspace as [feature][32-sample] rows (a consumer's grad_x_rows); grad_y is ignored */
 
+#define TN_MLP_BF16X3 32        /* wide stacks evaluated layer by layer (width 128 / 256): matrix products on the bf16 matrix cores with
+                                 * EXACT three-way operand splits (x = hi + mid + lo in bf16, six of the nine partial products,
+                                 * fp32 accumulate: every product good to 2^-23, the error of an fp32 product's own rounding) instead
+                                 * of v_mfma_f32_32x32x2_f32 -- 2.67 x the matrix rate, results equal to fp32 rounding.  Ignored by
+                                 * configurations without such a form. */
+
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
     int32_t in_dim;                           /* width of x (before encoding)                 */

@@ -109,3 +109,41 @@ def test_inference_through_the_layer_kernels(n):
     assert fn(C.byref(desc), C.c_int64(n)) == ((n + 31) // 32) * (2 * 256 + 64) * 128
     od = m.VanillaOpacityDecoder(256).to(DEV)
     assert fn(C.byref(m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)), C.c_int64(n)) == 0
+
+
+@pytest.mark.parametrize("width,n", [(256, 5000), (256, 33), (128, 4099)])
+def test_bf16x3_layers_equal_fp32_mfma_layers(width, n, monkeypatch):
+    """TN_MLP_BF16X3 (mlp_b3_layers.hip: bf16 matrix cores, exact three-way operand splits, six partial products, fp32
+    accumulate) against the fp32-MFMA layer kernels on the same wide stack: forward and every gradient to fp32 rounding --
+    both are fp32-accurate evaluations of the same sums in different orders (forward 3e-6 of the largest output after ten
+    layers, gradients 2e-5 of each tensor's largest element, the bound the fp32 kernels are held to against the oracle)."""
+    from tinynerf_amd import models as m
+    torch.manual_seed(11)
+    net = m.MLP(60 if width == 256 else 36, width, 8 if width == 256 else 5, width).to(DEV)      # Vanilla: PE inputs; Cobafa: plain
+    if width == 256:
+        fm = m.VanillaFeatureMLP(10, 256, 8).to(DEV)
+        fwd = lambda x: fm(x)
+        params = list(fm.parameters())
+        x = (torch.rand(n, 3, device=DEV) * 2 - 1)
+    else:
+        fwd = lambda x: net(x)
+        params = list(net.parameters())
+        x = torch.rand(n, 36, device=DEV)
+    g = torch.randn(n, width, device=DEV)
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        monkeypatch.setattr(m, "MATMUL", mode)
+        for p in params:
+            p.grad = None
+        y = fwd(x)
+        y.backward(g)
+        with torch.no_grad():
+            yi = fwd(x)
+        assert torch.equal(yi, y.detach())                      # inference (tn_mlp_fwd_ws) == training forward in either mode
+        res[mode] = (y.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params])
+    y0, g0 = res["fp32"]
+    y1, g1 = res["bf16x3"]
+    assert not np.array_equal(y0, y1)                            # (the flag did select another kernel)
+    np.testing.assert_allclose(y1, y0, rtol=0, atol=3e-6 * float(np.abs(y0).max()))
+    for a_, b_ in zip(g1, g0):
+        np.testing.assert_allclose(a_, b_, rtol=0, atol=2e-5 * max(float(np.abs(b_).max()), 1e-30))

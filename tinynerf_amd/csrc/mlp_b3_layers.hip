@@ -1,0 +1,368 @@
+// Layers of the wide stacks (Vanilla feature MLP 256 x 10, reference models.py:59-68, run.py:131; Cobafa 128 x 6) on the bf16
+// matrix cores with exact three-way operand splits (b3_device.h) -- same workspace rows, same arguments and the same results to
+// fp32 rounding as the fp32-MFMA kernels of mlp_bwd_layers.hip, at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 32 x 32 x 16
+// block.
+//
+// Forward / data gradient (fwd_b3_kernel / dgrad_b3_kernel): as in the fp32 form a wave owns 32-row blocks of the layer's
+// output and keeps their weights -- all K columns -- in registers for the whole launch, now as three packed-bf16 A operands per
+// 16-wide k step (12 registers per step and block), split once when the kernel starts.  H = 256: FOUR waves per workgroup, two
+// blocks each (384 weight registers of the 512 a lone wave on a SIMD may use: with two waves per SIMD the 192 registers of one
+// block leave no room for anything else); H = 128: four waves per tile stream, one block each, two streams per workgroup.
+// The 32-sample input tile reaches the workgroup through LDS as three bf16 planes [sample][feature] (B operand of a k step =
+// one ds_read_b128 per term, shared by the wave's blocks):
+//   * a wave's rows of the NEXT tile arrive by LDS-direct loads (global_load_lds_dwordx4) in an fp32 staging area -- no
+//     staging registers -- requested in the middle of the current tile's k loop, as soon as the area is free;
+//   * in the first half of the k loop the wave converts its rows of the next tile, two value pairs per step: ds_read_b32 from
+//     the staging area, the exact split (b3::split2), three ds_write_b32 into the other tile buffer.  The conversion
+//     instructions sit between the MFMAs of a step and overlap with them; only the wave that loaded a row touches it;
+//   * one barrier per tile (two tile buffers): everybody has finished reading the current tile and writing the next.  It is a
+//     raw s_barrier behind a COUNTED s_waitcnt: the LDS-direct loads must have landed, the tile's own row stores (issued
+//     behind them, retired in order) need not -- __syncthreads() would drain them too (vmcnt(0)).
+// LDS: 2 x 3 planes x 32 x (H + 8) bf16 + 32 x H fp32 staging per stream + bias = 135 KB for H = 256.
+#include "mlp_layers.h"
+#include "b3_device.h"
+#include <algorithm>
+
+namespace {
+
+using namespace tn::layers;
+using namespace tn::mlp;
+using tn::b3::Op;
+using tn::b3::u32x4;
+using tn::f32x16;
+using tn::f32x4;
+
+__device__ __forceinline__ void glds16(const float *src, float *dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+template <int H> struct B3Geom {
+    static constexpr int T = H / 32;                // 32-row blocks of the layer's input and of its output
+    static constexpr int BPW = H / 128;             // blocks per wave: 2 for H = 256 (one wave per SIMD, 512 registers), 1 for H = 128
+    static constexpr int WPS = T / BPW;             // waves per tile stream (4)
+    static constexpr int STREAMS = H == 256 ? 1 : 2;
+    static constexpr int THREADS = STREAMS * WPS * 64;
+    static constexpr int KS = H / 16;               // k steps
+    static constexpr int CONV = KS / 2;             // steps that carry the conversion of the next tile (2 * BPW pairs each)
+    static constexpr int SB = H + 8;                // bf16 elements per LDS tile row: (H + 8) * 2 B = odd multiple of 16 B
+    static constexpr int PLANE = 32 * SB;           // bf16 elements per term plane
+    static constexpr int TILE_B = 3 * PLANE * 2;    // bytes per tile buffer
+    static constexpr int STAGE_B = 32 * H * 4;      // bytes of the fp32 staging area of a stream ([row][32 samples], lane-linear)
+    static constexpr int STREAM_B = 2 * TILE_B + STAGE_B;
+    static constexpr size_t lds_bytes = (size_t)STREAMS * STREAM_B + H * 4;
+};
+
+// weights of output rows 32 ob + i as A operands: step s, lane (i, h): W[row][16 s + 8 h + 0..7]
+template <int KS>
+__device__ __forceinline__ void load_weights_rows(const float *__restrict__ W, int ldw, int row, bool ok, int h, Op (&A)[KS]) {
+    const float *wr = W + (int64_t)(ok ? row : 0) * ldw + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wr + 16 * s), w1 = *reinterpret_cast<const f32x4 *>(wr + 16 * s + 4);
+        float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        if (!ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        }
+        A[s] = tn::b3::split8(v);
+    }
+}
+// ... of W^T: A[i = column 32 kb + i][k = row n]: step s, lane (i, h): W[16 s + 8 h + e][col]
+template <int KS>
+__device__ __forceinline__ void load_weights_cols(const float *__restrict__ W, int ldw, int col, int h, Op (&A)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W[(int64_t)(16 * s + 8 * h + e) * ldw + col];
+        A[s] = tn::b3::split8(v);
+    }
+}
+
+// B operand of step s for sample j: three ds_read_b128
+template <int SB>
+__device__ __forceinline__ Op read_b(const unsigned short *tile, int j, int h, int s) {
+    constexpr int PLANE = 32 * SB;
+    const unsigned short *p = tile + j * SB + 16 * s + 8 * h;
+    Op o;
+    o.hi = *reinterpret_cast<const u32x4 *>(p);
+    o.mid = *reinterpret_cast<const u32x4 *>(p + PLANE);
+    o.lo = *reinterpret_cast<const u32x4 *>(p + 2 * PLANE);
+    return o;
+}
+
+// LDS-direct request of `nrows` (multiple of 8) rows of a tile, starting at row r0 of `rows` ([row][32 samples]) -> stage
+// (lane-linear: one instruction = 8 rows x 128 B = 1 KB)
+template <int NROWS>
+__device__ __forceinline__ void request_rows(const float *rows, int r0, float *stage, int lane) {
+    const float *src = rows + r0 * 32 + 4 * lane;            // 16 B per lane
+#pragma unroll
+    for (int e = 0; e < NROWS / 8; ++e) glds16(src + e * 256, stage + e * 256);
+}
+
+// value pair p (0 .. 8 BPW - 1) of the wave's staged rows -> the three bf16 planes of a tile buffer.  The wave's 32 BPW rows x 32
+// samples are 16 BPW values per lane: lane (j, h) owns rows 32 b + 16 h + e (b < BPW, e < 16) of sample j; pair p = (b, e = 2 q,
+// 2 q + 1) with b = p / 8, q = p % 8.  Feature index of row r (within the wave's rows) = f0 + r.
+template <int SB>
+__device__ __forceinline__ void convert_pair(const float *sp, unsigned short *np, int p) {
+    constexpr int PLANE = 32 * SB;
+    const int b = p >> 3, q = p & 7;
+    const float v0 = sp[(32 * b + 2 * q) * 32], v1 = sp[(32 * b + 2 * q + 1) * 32];
+    unsigned hi, mid, lo;
+    tn::b3::split2(v0, v1, hi, mid, lo);
+    unsigned short *d = np + 32 * b + 2 * q;
+    *reinterpret_cast<unsigned *>(d) = hi;
+    *reinterpret_cast<unsigned *>(d + PLANE) = mid;
+    *reinterpret_cast<unsigned *>(d + 2 * PLANE) = lo;
+}
+
+// Everything of one tile stream that forward and data gradient share: geometry, prologue, the k loop with the conversion of the
+// next tile and the request of the one after it in the middle, the counted wait + barrier.
+template <int H>
+struct Stream {
+    using G = B3Geom<H>;
+    static constexpr int KS = G::KS, SB = G::SB, PLANE = G::PLANE, BPW = G::BPW;
+    int lane, j, h, wave, stream, wib;          // wib: wave in stream; it owns blocks BPW wib .. + BPW - 1
+    unsigned short *tiles;
+    float *stage;                               // this wave's 32 BPW rows of the staging area
+    int64_t n_tiles, stride, first, iters;
+
+    __device__ __forceinline__ void init(unsigned char *lds_raw, int64_t n) {
+        lane = tn::lane_id(); j = lane & 31; h = lane >> 5;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        stream = wave / G::WPS; wib = wave % G::WPS;
+        unsigned char *sbase = lds_raw + stream * G::STREAM_B;
+        tiles = reinterpret_cast<unsigned short *>(sbase);
+        stage = reinterpret_cast<float *>(sbase + 2 * G::TILE_B) + (32 * BPW * wib) * 32;
+        n_tiles = (n + 31) >> 5;
+        stride = (int64_t)gridDim.x * G::STREAMS;
+        first = (int64_t)blockIdx.x * G::STREAMS;
+        iters = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    }
+    __device__ __forceinline__ int64_t tile_of(int64_t it) const { const int64_t t = first + stream + it * stride; return t < n_tiles ? t : n_tiles - 1; }
+    __device__ __forceinline__ const float *sp() const { return stage + (16 * h) * 32 + j; }
+    __device__ __forceinline__ unsigned short *np(int buf) const { return tiles + buf * (3 * PLANE) + j * SB + 32 * BPW * wib + 16 * h; }
+    __device__ __forceinline__ void request(const float *stash, int64_t tile, int rows_total, int off) const {
+        request_rows<32 * BPW>(urow(stash, tile * rows_total + off), 32 * BPW * wib, stage, lane);
+    }
+    // tiles 0 (converted in one go) and 1 (requested); ends with a full barrier
+    __device__ __forceinline__ void prologue(const float *stash, int rows_total, int off) {
+        request(stash, tile_of(0), rows_total, off);
+        __syncthreads();                                     // (vmcnt(0): the wave's own rows have landed)
+#pragma unroll
+        for (int p = 0; p < 8 * BPW; ++p) convert_pair<SB>(sp(), np(0), p);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next request overwrites the area
+        request(stash, tile_of(1), rows_total, off);
+        __syncthreads();
+    }
+    // acc[b] += W_b x tile(cur) for the wave's blocks; converts the staged tile into buffer cur ^ 1 during the first CONV steps,
+    // then requests tile `it + 2`
+    __device__ __forceinline__ void k_loop(const Op (&A)[BPW][KS], f32x16 (&acc)[BPW], int cur, const float *stash, int64_t next2, int rows_total,
+                                           int off) const {
+        const unsigned short *tc = tiles + cur * (3 * PLANE);
+        const float *s_ = sp();
+        unsigned short *n_ = np(cur ^ 1);
+        constexpr int PPS = (8 * BPW) / G::CONV;             // pairs per conversion step
+        Op b = read_b<SB>(tc, j, h, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Op bn = b;
+            if (s + 1 < KS) bn = read_b<SB>(tc, j, h, s + 1);
+            if (s < G::CONV) {
+#pragma unroll
+                for (int u = 0; u < PPS; ++u) convert_pair<SB>(s_, n_, PPS * s + u);
+            }
+            if (s == G::CONV) {
+                // the conversion's reads of the staging area have been consumed (their values went through the split): the area is
+                // free for the tile after next, which then has the second half of the k loop to arrive
+                request(stash, next2, rows_total, off);
+            }
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma6(A[bq][s], b, acc[bq]);
+            b = bn;
+        }
+    }
+    // end of a tile: NSTORES vector-memory stores were issued behind the request of k_loop (retired in order: once at most
+    // NSTORES operations are outstanding the request has landed), LDS writes of the conversion retired, then the barrier
+    template <int NSTORES>
+    __device__ __forceinline__ void tile_barrier() const {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTORES) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+};
+
+template <int H, bool LAST>
+__global__ __launch_bounds__(B3Geom<H>::THREADS) void fwd_b3_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
+{
+    using G = B3Geom<H>;
+    constexpr int KS = G::KS, BPW = G::BPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Stream<H> st;
+    st.init(lds_raw, n);
+    float *bias_s = reinterpret_cast<float *>(lds_raw + G::STREAMS * G::STREAM_B);
+    for (int e = threadIdx.x; e < H; e += blockDim.x) bias_s[e] = e < a.N ? a.B[e] : 0.0f;
+    if (st.iters == 0) return;
+    const int j = st.j, h = st.h, lane = st.lane;
+    Op A[BPW][KS];
+#pragma unroll
+    for (int bq = 0; bq < BPW; ++bq) {
+        const int row = 32 * (BPW * st.wib + bq) + j;
+        load_weights_rows<KS>(a.W, a.K, row, row < a.N, h, A[bq]);
+    }
+    st.prologue(stash, a.rows_total, a.off_in);
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < st.iters; ++it) {
+        f32x16 acc[BPW];
+#pragma unroll
+        for (int bq = 0; bq < BPW; ++bq)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_s + 32 * (BPW * st.wib + bq) + 8 * q + 4 * h);
+                acc[bq][4 * q] = b4[0]; acc[bq][4 * q + 1] = b4[1]; acc[bq][4 * q + 2] = b4[2]; acc[bq][4 * q + 3] = b4[3];
+            }
+        st.k_loop(A, acc, cur, stash, st.tile_of(it + 2), a.rows_total, a.off_in);
+        const int64_t tile = st.tile_of(it);
+#pragma unroll
+        for (int bq = 0; bq < BPW; ++bq) {
+            const int ob = BPW * st.wib + bq;
+            tn::pin16(acc[bq]);
+            if constexpr (!LAST) {
+                acc[bq] = tn::relu16(acc[bq]);
+                wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc[bq]);
+            } else if (32 * ob < a.N) {
+                float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
+                const int64_t row = tile * 32 + j;
+                const bool valid = row < n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = 32 * ob + 8 * q + 4 * h;
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = valid && f + u < a.N;
+                        outp[(u + 8 * q) * 32] = ok ? acc[bq][4 * q + u] : 0.0f;
+                        v[u] = tn::apply_act(acc[bq][4 * q + u], a.out_act);
+                    }
+                    if (valid) {
+                        if ((a.N & 3) == 0) { if (f < a.N) *reinterpret_cast<f32x4 *>(y + row * a.N + f) = v; }
+                        else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (f + u < a.N) y[row * a.N + f + u] = v[u];
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (!LAST) {
+            if (a.off_bits >= 0) {                  // (wave-uniform) ReLU bits of the wave's blocks for the data-gradient kernel
+#pragma unroll
+                for (int bq = 0; bq < BPW; ++bq) {
+                    unsigned *bits = reinterpret_cast<unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * (BPW * st.wib + bq)));
+                    bits[lane] = relu_bits(acc[bq]);
+                }
+            }
+            st.template tile_barrier<16 * BPW>();   // (with the bit rows 17 BPW stores follow the request: the bound still covers it)
+        } else {
+            st.template tile_barrier<0>();          // (the last layer's y stores are conditional: count nothing)
+        }
+        cur ^= 1;
+    }
+}
+
+// data gradient twin: the wave's blocks are input-feature blocks kb (A = W^T rows), B = the incoming gradient tile
+template <int H>
+__global__ __launch_bounds__(B3Geom<H>::THREADS) void dgrad_b3_kernel(DgradArgs a, int64_t n, float *__restrict__ stash)
+{
+    using G = B3Geom<H>;
+    constexpr int KS = G::KS, BPW = G::BPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Stream<H> st;
+    st.init(lds_raw, n);
+    if (st.iters == 0) return;
+    const int j = st.j, h = st.h, lane = st.lane;
+    Op A[BPW][KS];
+#pragma unroll
+    for (int bq = 0; bq < BPW; ++bq) load_weights_cols<KS>(a.W, a.K, 32 * (BPW * st.wib + bq) + j, h, A[bq]);
+    st.prologue(stash, a.rows_total, a.off_gin);
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < st.iters; ++it) {
+        const int64_t tile = st.tile_of(it);
+        unsigned mbits[BPW];
+#pragma unroll
+        for (int bq = 0; bq < BPW; ++bq)
+            mbits[bq] = reinterpret_cast<const unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * (BPW * st.wib + bq)))[lane];
+        f32x16 acc[BPW];
+#pragma unroll
+        for (int bq = 0; bq < BPW; ++bq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bq][r] = 0.0f;
+        st.k_loop(A, acc, cur, stash, st.tile_of(it + 2), a.rows_total, a.off_gin);
+#pragma unroll
+        for (int bq = 0; bq < BPW; ++bq) {
+            tn::pin16(acc[bq]);
+            f32x16 res;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = mask_keep(acc[bq][r], mbits[bq], r);
+            wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), BPW * st.wib + bq, j, h, res);
+        }
+        st.template tile_barrier<16 * BPW>();
+        cur ^= 1;
+    }
+}
+
+template <int H, bool LAST>
+int launch_fwd(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    using G = B3Geom<H>;
+    auto kern = fwd_b3_kernel<H, LAST>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_fwd(bf16x3): cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(G::THREADS), G::lds_bytes, s>>>(f, n, stash, y);
+    return tn::check_launch("fwd_b3_kernel");
+}
+
+template <int H>
+int launch_dgrad(const DgradArgs &d, int64_t n, float *stash, hipStream_t s)
+{
+    using G = B3Geom<H>;
+    if (d.off_bits < 0) return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): the data gradient takes its ReLU masks as bit rows");
+    auto kern = dgrad_b3_kernel<H>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd(bf16x3): cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(G::THREADS), G::lds_bytes, s>>>(d, n, stash);
+    return tn::check_launch("dgrad_b3_kernel");
+}
+
+}  // namespace
+
+namespace tn {
+namespace layers {
+
+__attribute__((visibility("hidden"))) int launch_fwd_b3(int H, bool last, const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    if (H == 256) return last ? launch_fwd<256, true>(f, n, stash, y, s) : launch_fwd<256, false>(f, n, stash, y, s);
+    if (H == 128) return last ? launch_fwd<128, true>(f, n, stash, y, s) : launch_fwd<128, false>(f, n, stash, y, s);
+    return tn::fail(TN_E_CONFIG, "mlp_fwd(bf16x3): width 128 or 256");
+}
+
+__attribute__((visibility("hidden"))) int launch_dgrad_b3(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s)
+{
+    if (H == 256) return launch_dgrad<256>(d, n, stash, s);
+    if (H == 128) return launch_dgrad<128>(d, n, stash, s);
+    return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): width 128 or 256");
+}
+
+__attribute__((visibility("hidden"))) int launch_wgrad_b3(int, const WgradArgs &, int64_t, const float *, hipStream_t)
+{
+    return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): the weight gradient has no bf16x3 form yet");
+}
+
+}  // namespace layers
+}  // namespace tn

@@ -10,7 +10,7 @@
 // i.e. 2L+1 launches with all activations crossing HBM exactly once in each direction (the reference's
 // autograd does the same through cuBLAS with NHW-major activations and separate bias / ReLU kernels).
 // Weights are read from L2 (256x256 fp32 = 256 KiB per layer does not fit LDS next to anything else).
-#include "mlp_stage.h"
+#include "mlp_layers.h"
 #include <algorithm>
 
 extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows, int64_t a_stride, int na, float *gW,
@@ -21,13 +21,13 @@ namespace {
 using tn::f32x16;
 using tn::f32x4;
 using namespace tn::mlp;
+using namespace tn::layers;
 
 __device__ __forceinline__ float act_grad(float pre, int act) {
     if (act == TN_ACT_EXP_M1) return expf(fminf(fmaxf(pre - 1.0f, -15.0f), 15.0f));     // models.py:50-53
     if (act == TN_ACT_SIGMOID) { const float s = 1.0f / (1.0f + expf(-pre)); return s * (1.0f - s); }
     return 1.0f;
 }
-__device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }     // D-layout row of reg r
 
 __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
 #pragma unroll
@@ -215,15 +215,6 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__
 // ------------------------------------------------------------------------------------------------
 // data gradient of one layer:  Gout = relu'(Hmask) * (W^T Gin)      (FIRST: grad_x, no mask, row-major out)
 // ------------------------------------------------------------------------------------------------
-struct DgradArgs {
-    const float *W;       // [N][K] torch layout
-    int N, K;             // rows / columns of W
-    int rows_total;       // stash rows per tile
-    int off_gin, off_gout, off_mask;    // row offsets inside a tile
-    int off_bits;                       // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
-    int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
-    int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
-};
 
 template <int H, bool FIRST, int WPB>
 __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ gx)
@@ -395,14 +386,6 @@ __global__ __launch_bounds__(256) void enc_rows_kernel(MlpArgs a, const float *_
     }
 }
 
-struct FwdLayerArgs {
-    const float *W, *B;   // [N][K] torch layout, [N]
-    int N, K;
-    int Kp;               // input rows present in the workspace (K for hidden layers, K0_pad for the encoded first layer)
-    int rows_total, off_in, off_out;
-    int out_act;
-    int off_bits;         // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
-};
 
 // T = 32-row blocks of the layer input: 2 for the positional-encoding first layer, whose encoded inputs (<= 64 slots)
 // enc_rows_kernel has written as workspace rows (the rows the weight gradient reads anyway)
@@ -501,46 +484,6 @@ template <int H> struct WregGeom {
     static constexpr int TILE = 32 * SW;           // floats per tile buffer
     static constexpr size_t lds_bytes = (size_t)STREAMS * 3 * TILE * sizeof(float);
 };
-
-// Vector-memory instructions of these kernels use the SGPR-base form (wave-uniform 64-bit base + one 32-bit lane offset +
-// immediate): a 64-bit per-lane address costs the SIMD measurably more matrix-pipe time per instruction
-// (scripts/microbench/wreg_layer.hip: 84.8 -> 87.8 % busy for the same loads and stores).
-__device__ __forceinline__ const float *urow(const float *base, int64_t row) {          // wave-uniform row pointer
-    const int64_t o = row * 32;
-    return base + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
-}
-__device__ __forceinline__ float *urow(float *base, int64_t row) { return const_cast<float *>(urow(const_cast<const float *>(base), row)); }
-
-// the 32 rows [32 ob, 32 ob + 32) of a [row][32 samples] tile -> registers (lane (j, h): rows 32 ob + 16 h + 0..15, sample j)
-__device__ __forceinline__ void wreg_load_rows(const float *__restrict__ rows, int ob, int j, int h, float (&stage)[16]) {
-    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
-    unsigned off = (unsigned)(16 * h * 32 + j) * 4u;
-    asm volatile("" : "+v"(off));       // (keeps the zero-extension next to the access: base + zext(off) selects the SGPR-base form)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) stage[e] = *reinterpret_cast<const float *>(p + off + (unsigned)(e * 128));
-}
-// D-layout rows of block `ob` (lane (j, h), reg r: row 32 ob + frow(r, h), sample j) from / to [row][32 samples] rows
-__device__ __forceinline__ void wreg_store_block(float *__restrict__ rows, int ob, int j, int h, const f32x16 &v) {
-    char *p = reinterpret_cast<char *>(rows + 32 * ob * 32);
-    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
-    asm volatile("" : "+v"(off));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) *reinterpret_cast<float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = v[r];
-}
-__device__ __forceinline__ void wreg_load_block(const float *__restrict__ rows, int ob, int j, int h, float (&m)[16]) {
-    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
-    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
-    asm volatile("" : "+v"(off));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[r] = *reinterpret_cast<const float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
-}
-// ... -> LDS tile [sample j][feature]: four ds_write_b128
-__device__ __forceinline__ void wreg_write_rows(float *__restrict__ tile, int SW, int ob, int j, int h, const float (&stage)[16]) {
-    float *p = tile + j * SW + 32 * ob + 16 * h;
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-        *reinterpret_cast<f32x4 *>(p + 4 * v) = f32x4{stage[4 * v], stage[4 * v + 1], stage[4 * v + 2], stage[4 * v + 3]};
-}
 
 // MFMAs of reduction groups [G0, G1) (group g = 8 in-features: B operand = one ds_read_b128 at bt + 8 g) with the operands of
 // the next PAIR of groups requested before the current pair's eight MFMAs are issued (left alone, hipcc sinks each read to
@@ -773,12 +716,6 @@ int launch_dgrad_wreg(const DgradArgs &d, int64_t n, float *stash, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 // weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    float *gW, *gB;
-    int N, K, K_pad;
-    int rows_total, off_g, off_a, off_e;
-    int first, enc, in_dim, n_freqs, xs;
-};
 
 template <int MAXS>
 __global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const float *__restrict__ x, int64_t n,
@@ -1057,7 +994,9 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = total;
                 f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act; f.off_bits = off_bits(l);
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
-                const int rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
+                int rc;
+                if (a.b3) rc = launch_fwd_b3(H, l + 1 == L, f, n, stash, y, s);        // bf16 matrix cores, exact 3-way splits
+                else rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;
             }
             return TN_OK;
@@ -1135,7 +1074,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             bool done = false;
             if constexpr (H >= 128) {
                 if (a.K[l] == H && a.N[l] == H) {
-                    if (int rc = launch_dgrad_wreg<H>(d, n, stash, s)) return rc;
+                    if (a.b3 && d.off_bits >= 0) { if (int rc = launch_dgrad_b3(H, d, n, stash, s)) return rc; }
+                    else if (int rc = launch_dgrad_wreg<H>(d, n, stash, s)) return rc;
                     done = true;
                 } else if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS
                     constexpr int NKT = 4, WL = 8;

@@ -1,0 +1,90 @@
+// Shared pieces of the layer-by-layer kernels of the wide stacks (mlp_bwd_layers.hip: exact fp32 MFMA; mlp_b3_layers.hip: the
+// same layers on bf16 MFMA with exact three-way operand splits): argument structs, the [feature][32-sample] row helpers.
+#pragma once
+#include "mlp_stage.h"
+
+namespace tn {
+namespace layers {
+
+using tn::f32x16;
+using tn::f32x4;
+
+__device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }     // D-layout row of reg r
+
+// data gradient of one layer:  Gout = relu'(Hmask) * (W^T Gin)      (FIRST: grad_x, no mask, row-major out)
+struct DgradArgs {
+    const float *W;       // [N][K] torch layout
+    int N, K;             // rows / columns of W
+    int rows_total;       // stash rows per tile
+    int off_gin, off_gout, off_mask;    // row offsets inside a tile
+    int off_bits;                       // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
+    int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
+    int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
+};
+
+// forward of one layer on workspace rows
+struct FwdLayerArgs {
+    const float *W, *B;   // [N][K] torch layout, [N]
+    int N, K;
+    int Kp;               // input rows present in the workspace (K for hidden layers, K0_pad for the encoded first layer)
+    int rows_total, off_in, off_out;
+    int out_act;
+    int off_bits;         // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
+};
+
+// weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
+struct WgradArgs {
+    float *gW, *gB;
+    int N, K, K_pad;
+    int rows_total, off_g, off_a, off_e;
+    int first, enc, in_dim, n_freqs, xs;
+};
+
+// Vector-memory instructions of these kernels use the SGPR-base form (wave-uniform 64-bit base + one 32-bit lane offset +
+// immediate): a 64-bit per-lane address costs the SIMD measurably more matrix-pipe time per instruction
+// (scripts/microbench/wreg_layer.hip: 84.8 -> 87.8 % busy for the same loads and stores).
+__device__ __forceinline__ const float *urow(const float *base, int64_t row) {          // wave-uniform row pointer
+    const int64_t o = row * 32;
+    return base + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+}
+__device__ __forceinline__ float *urow(float *base, int64_t row) { return const_cast<float *>(urow(const_cast<const float *>(base), row)); }
+
+// the 32 rows [32 ob, 32 ob + 32) of a [row][32 samples] tile -> registers (lane (j, h): rows 32 ob + 16 h + 0..15, sample j)
+__device__ __forceinline__ void wreg_load_rows(const float *__restrict__ rows, int ob, int j, int h, float (&stage)[16]) {
+    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(16 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));       // (keeps the zero-extension next to the access: base + zext(off) selects the SGPR-base form)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) stage[e] = *reinterpret_cast<const float *>(p + off + (unsigned)(e * 128));
+}
+// D-layout rows of block `ob` (lane (j, h), reg r: row 32 ob + frow(r, h), sample j) from / to [row][32 samples] rows
+__device__ __forceinline__ void wreg_store_block(float *__restrict__ rows, int ob, int j, int h, const f32x16 &v) {
+    char *p = reinterpret_cast<char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = v[r];
+}
+__device__ __forceinline__ void wreg_load_block(const float *__restrict__ rows, int ob, int j, int h, float (&m)[16]) {
+    const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);
+    unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[r] = *reinterpret_cast<const float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
+}
+// ... -> LDS tile [sample j][feature]: four ds_write_b128
+__device__ __forceinline__ void wreg_write_rows(float *__restrict__ tile, int SW, int ob, int j, int h, const float (&stage)[16]) {
+    float *p = tile + j * SW + 32 * ob + 16 * h;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        *reinterpret_cast<f32x4 *>(p + 4 * v) = f32x4{stage[4 * v], stage[4 * v + 1], stage[4 * v + 2], stage[4 * v + 3]};
+}
+
+
+// ---- bf16x3 forms (mlp_b3_layers.hip); same arguments, same workspace layout, results equal to fp32 rounding ----
+int launch_fwd_b3(int H, bool last, const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s);
+int launch_dgrad_b3(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s);
+int launch_wgrad_b3(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
+
+}  // namespace layers
+}  // namespace tn

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 from typing import Any, Callable, List, Optional, Sequence, Tuple, cast
 
 import torch
@@ -23,6 +24,12 @@ from . import _lib as L
 # --------------------------------------------------------------------------------------------
 # fused MLP plumbing
 # --------------------------------------------------------------------------------------------
+# Matrix products of the wide stacks (Vanilla 256 x 10, Cobafa 128 x 6): "bf16x3" = bf16 matrix cores with exact three-way
+# operand splits (TN_MLP_BF16X3: results equal to fp32 rounding, 2.67 x the fp32 matrix rate), "fp32" = v_mfma_f32_32x32x2_f32.
+# TN_MATMUL=fp32 in the environment (or assigning "fp32" here) selects the plain fp32 instructions.
+MATMUL = "fp32" if os.environ.get("TN_MATMUL", "bf16x3").lower() == "fp32" else "bf16x3"
+
+
 def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,
               freqs: Optional[torch.Tensor], flags: int = 0, aux_index: Optional[torch.Tensor] = None, aux_stride: int = 0) -> L.MlpDesc:
     n_layers = len(params) // 2
@@ -34,7 +41,7 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
     d.encoding = encoding
     d.n_freqs = n_freqs
     d.out_activation = out_act
-    d.flags = flags
+    d.flags = flags | (L.MLP_BF16X3 if MATMUL == "bf16x3" else 0)
     d.aux_index = aux_index.data_ptr() if aux_index is not None else None
     d.aux_stride = aux_stride
     d.freqs = freqs.data_ptr() if freqs is not None else None

@@ -63,7 +63,8 @@ def test_row_views_equal_row_major_tensors(method, n_rays, per_ray):
             assert links[0]["width"] == (256 if method == "vanilla" else 128)
         grads[rows] = {k: p.grad.detach().cpu().numpy() for k, p in r.named_parameters()}
         grads[rows]["__out"] = out.detach().cpu().numpy()
-    assert np.array_equal(grads[True]["__out"], grads[False]["__out"])        # the forward is the same launches
+    # the same forward launches up to the colour head's direction encoding (per-ray table vs per-sample sin / cos)
+    np.testing.assert_allclose(grads[True]["__out"], grads[False]["__out"], rtol=0, atol=2e-6)
     for k, ref in grads[False].items():
         # same products, summed in another order (row tiles / atomics): 2e-5 of the largest element per tensor
         np.testing.assert_allclose(grads[True][k], ref, rtol=0, atol=2e-5 * max(float(np.abs(ref).max()), 1e-30), err_msg=k)
@@ -139,7 +140,10 @@ def test_bf16x3_layers_equal_fp32_mfma_layers(width, n, monkeypatch):
         y.backward(g)
         with torch.no_grad():
             yi = fwd(x)
-        assert torch.equal(yi, y.detach())                      # inference (tn_mlp_fwd_ws) == training forward in either mode
+        if width == 256:
+            assert torch.equal(yi, y.detach())                  # inference (tn_mlp_fwd_ws) == training forward in either mode
+        else:                                                   # (plain inputs: inference takes the register-resident fp32 kernel)
+            np.testing.assert_allclose(yi.cpu().numpy(), y.detach().cpu().numpy(), rtol=0, atol=3e-6 * float(y.abs().max()))
         res[mode] = (y.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params])
     y0, g0 = res["fp32"]
     y1, g1 = res["bf16x3"]

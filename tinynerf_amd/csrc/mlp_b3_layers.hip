@@ -23,6 +23,10 @@
 #include "b3_device.h"
 #include <algorithm>
 
+#ifndef TN_B3_ABLATE
+#define TN_B3_ABLATE 0      // timing experiments only (wrong results): 1 = no conversion, 2 = no LDS-direct requests, 4 = no stores
+#endif
+
 namespace {
 
 using namespace tn::layers;
@@ -156,30 +160,79 @@ struct Stream {
         __syncthreads();
     }
     // acc[b] += W_b x tile(cur) for the wave's blocks; converts the staged tile into buffer cur ^ 1 during the first CONV steps,
-    // then requests tile `it + 2`
+    // then requests tile `it + 2`.  Software-pipelined by hand and pinned with scheduling barriers (one wave per SIMD at H = 256:
+    // nobody else hides an LDS round trip; left alone, hipcc sinks every ds_read to just in front of its first use):
+    //   step s:  [ds_read: B operands of step s + 1, staged values of conversion slot s]  |  [MFMAs of step s, interleaved
+    //            over the wave's blocks so that consecutive MFMAs never share an accumulator, + split / ds_write of the values
+    //            read in step s - 1]
     __device__ __forceinline__ void k_loop(const Op (&A)[BPW][KS], f32x16 (&acc)[BPW], int cur, const float *stash, int64_t next2, int rows_total,
                                            int off) const {
         const unsigned short *tc = tiles + cur * (3 * PLANE);
         const float *s_ = sp();
         unsigned short *n_ = np(cur ^ 1);
-        constexpr int PPS = (8 * BPW) / G::CONV;             // pairs per conversion step
+        constexpr int CONV = G::CONV;
+        constexpr int PPS = (8 * BPW) / CONV;                // pairs per conversion step
         Op b = read_b<SB>(tc, j, h, 0);
+        float cv[2 * PPS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             Op bn = b;
             if (s + 1 < KS) bn = read_b<SB>(tc, j, h, s + 1);
-            if (s < G::CONV) {
+            float cn[2 * PPS];
+            if (s < CONV && !(TN_B3_ABLATE & 1)) {
 #pragma unroll
-                for (int u = 0; u < PPS; ++u) convert_pair<SB>(s_, n_, PPS * s + u);
+                for (int u = 0; u < PPS; ++u) {
+                    const int p = PPS * s + u, bq = p >> 3, q = p & 7;
+                    cn[2 * u] = s_[(32 * bq + 2 * q) * 32];
+                    cn[2 * u + 1] = s_[(32 * bq + 2 * q + 1) * 32];
+                }
             }
-            if (s == G::CONV) {
-                // the conversion's reads of the staging area have been consumed (their values went through the split): the area is
-                // free for the tile after next, which then has the second half of the k loop to arrive
-                request(stash, next2, rows_total, off);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == CONV + 1) {
+                // every staged value has been read AND consumed (split in step CONV): the area is free for the tile after next,
+                // which then has the rest of the k loop to arrive
+                if (!(TN_B3_ABLATE & 2)) request(stash, next2, rows_total, off);
             }
+            // six partial products, small terms first, blocks interleaved (consecutive MFMAs never share an accumulator).  The
+            // split / ds_write of the values read one step ago is cut into PPS pieces that are pinned BETWEEN the terms: an
+            // in-order wave issues them in the shadow of the MFMA that is executing; clustered behind the MFMAs (hipcc's
+            // choice, whatever sched_group_barrier asks for) they run while the matrix pipe drains
+            const bool conv = s >= 1 && s <= CONV && !(TN_B3_ABLATE & 1);
+            auto piece = [&](int u) {
+                if (!conv || u >= PPS) return;
+                const int p = PPS * (s - 1) + u, bq = p >> 3, q = p & 7;
+                unsigned hi, mid, lo;
+                tn::b3::split2(cv[2 * u], cv[2 * u + 1], hi, mid, lo);
+                unsigned short *d = n_ + 32 * bq + 2 * q;
+                *reinterpret_cast<unsigned *>(d) = hi;
+                *reinterpret_cast<unsigned *>(d + PLANE) = mid;
+                *reinterpret_cast<unsigned *>(d + 2 * PLANE) = lo;
+                __builtin_amdgcn_sched_barrier(0);
+            };
 #pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma6(A[bq][s], b, acc[bq]);
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].lo, b.hi, acc[bq]);
+            __builtin_amdgcn_sched_barrier(0);
+            piece(0);
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.lo, acc[bq]);
+            __builtin_amdgcn_sched_barrier(0);
+            piece(1);
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].mid, b.mid, acc[bq]);
+            __builtin_amdgcn_sched_barrier(0);
+            piece(2);
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].mid, b.hi, acc[bq]);
+            __builtin_amdgcn_sched_barrier(0);
+            piece(3);
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.mid, acc[bq]);
+#pragma unroll
+            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.hi, acc[bq]);
+            __builtin_amdgcn_sched_barrier(0);
             b = bn;
+#pragma unroll
+            for (int u = 0; u < 2 * PPS; ++u) cv[u] = cn[u];
         }
     }
     // end of a tile: NSTORES vector-memory stores were issued behind the request of k_loop (retired in order: once at most
@@ -230,7 +283,7 @@ __global__ __launch_bounds__(B3Geom<H>::THREADS) void fwd_b3_kernel(FwdLayerArgs
             tn::pin16(acc[bq]);
             if constexpr (!LAST) {
                 acc[bq] = tn::relu16(acc[bq]);
-                wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc[bq]);
+                if (!(TN_B3_ABLATE & 4) || acc[bq][0] == 123.f) wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc[bq]);
             } else if (32 * ob < a.N) {
                 float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
                 const int64_t row = tile * 32 + j;
@@ -306,11 +359,193 @@ __global__ __launch_bounds__(B3Geom<H>::THREADS) void dgrad_b3_kernel(DgradArgs 
             f32x16 res;
 #pragma unroll
             for (int r = 0; r < 16; ++r) res[r] = mask_keep(acc[bq][r], mbits[bq], r);
-            wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), BPW * st.wib + bq, j, h, res);
+            if (!(TN_B3_ABLATE & 4) || res[0] == 123.f) wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), BPW * st.wib + bq, j, h, res);
         }
         st.template tile_barrier<16 * BPW>();
         cur ^= 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][k] += sum_s G[n][s] A[k][s],  db[n] += sum_s G[n][s]   (N == K == H)
+//
+// The reduction index is the SAMPLE: a 32-sample tile is two 16-wide k steps.  Four waves per workgroup (H = 256: one per SIMD,
+// 512 registers), a wave owns BN x BK output tiles of 32 x 32 for the whole launch (4 x 4 for H = 256: 256 accumulator
+// registers -- the whole accumulator file -- and 24 ds_read_b128 for 96 MFMAs per k step).  Both operands are rows
+// [feature][32 samples] of the workspace; a k step needs their 16-sample halves as bf16 triplets [row][16 samples] in LDS
+// (operand of lane (i, h) = samples 8 h .. 8 h + 7 of row i: one ds_read_b128 per term).  Pipeline over HALF tiles, two LDS
+// buffers, one barrier per half tile:
+//     while the MFMAs of half tile t run from buffer t & 1, every thread splits the 2 H x 16 values of half tile t + 1 it holds
+//     in registers (8 x 4 consecutive samples of a row, loaded while half tile t - 1 was being multiplied) and writes them to
+//     the other buffer; then it requests half tile t + 2.
+// The bias gradient is summed on the way by the threads that convert G rows (a thread meets the same rows in every tile).
+// ------------------------------------------------------------------------------------------------
+template <int H, int BN, int BK>
+__global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
+{
+    constexpr int NR = 2 * H;                          // rows per half tile: G rows [0, H), A rows [H, 2 H)
+    constexpr int RS = 24;                             // bf16 elements per LDS row: 16 samples + 8 pad = 48 B (3 x 16 B: odd)
+    constexpr int PLANE = NR * RS;                     // bf16 elements per term plane
+    constexpr int BUF = 3 * PLANE;                     // ... per buffer
+    constexpr int NCH = (NR * 4) / 256;                // 16-byte chunks (4 samples of a row) per thread and half tile
+    constexpr int WK = (H / 32) / BK;                  // waves along k
+    static_assert((H / 32 / BN) * WK == 4 && NCH * 256 == NR * 4, "four waves own all tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(lds_raw);
+    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int tn0 = (wave / WK) * BN, tk0 = (wave % WK) * BK;
+    f32x16 acc[BN][BK];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bn][bk][r] = 0.0f;
+    // this thread's chunks of a half tile: chunk id = threadIdx.x + 256 c -> row id / 4, samples 4 (id % 4) .. + 3 of the half
+    const int qd = threadIdx.x & 3;
+    int src_off[NCH], dst_off[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int row = (threadIdx.x + 256 * c) >> 2;
+        src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
+        dst_off[c] = row * RS + 4 * qd;
+    }
+    float dbacc[NCH / 2];
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) dbacc[c] = 0.0f;
+    const int64_t n_half = 2 * n_tiles;                           // half tile t: tile t / 2, samples 16 (t & 1) .. + 15
+    const int64_t stride = gridDim.x;                             // tiles are dealt round-robin to the workgroups
+    auto half_src = [&](int64_t it) {                             // `it`-th half tile of this workgroup
+        int64_t tile = blockIdx.x + (it >> 1) * stride;
+        tile = tile < n_tiles ? tile : n_tiles - 1;
+        return stash + tile * (int64_t)a.rows_total * 32 + 16 * (it & 1);
+    };
+    const int64_t my_tiles = (int64_t)blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + stride - 1) / stride : 0;
+    const int64_t iters = 2 * my_tiles;
+    if (iters == 0) return;
+    (void)n_half;
+    f32x4 st[NCH];
+    auto load_half = [&](int64_t it) {
+        const float *src = half_src(it);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) st[c] = *reinterpret_cast<const f32x4 *>(src + src_off[c]);
+    };
+    auto convert_chunk = [&](int c, unsigned short *buf, bool count_bias) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        tn::b3::split2(st[c][0], st[c][1], h0, m0, l0);
+        tn::b3::split2(st[c][2], st[c][3], h1, m1, l1);
+        unsigned short *d = buf + dst_off[c];
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l0, l1);
+        if (count_bias && c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
+    };
+    // prologue: half tile 0 converted, half tile 1 in registers
+    load_half(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) convert_chunk(c, lds, true);
+    load_half(1);
+    __syncthreads();
+    int g_off[BN], a_off[BK];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn) g_off[bn] = (32 * (tn0 + bn) + i) * RS + 8 * h;
+#pragma unroll
+    for (int bk = 0; bk < BK; ++bk) a_off[bk] = (H + 32 * (tk0 + bk) + i) * RS + 8 * h;
+    auto read_op = [&](const unsigned short *buf, int off) {
+        Op o;
+        o.hi = *reinterpret_cast<const u32x4 *>(buf + off);
+        o.mid = *reinterpret_cast<const u32x4 *>(buf + off + PLANE);
+        o.lo = *reinterpret_cast<const u32x4 *>(buf + off + 2 * PLANE);
+        return o;
+    };
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < iters; ++it) {
+        const unsigned short *bc = lds + cur * BUF;
+        unsigned short *bnx = lds + (cur ^ 1) * BUF;
+        const bool more = it + 1 < iters;                         // (wave-uniform) half tile it + 1 exists: it sits in `st`
+        Op gop[BN];
+#pragma unroll
+        for (int bn = 0; bn < BN; ++bn) gop[bn] = read_op(bc, g_off[bn]);
+        Op aop = read_op(bc, a_off[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            Op anx = aop;
+            if (bk + 1 < BK) anx = read_op(bc, a_off[bk + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // six partial products per output tile, small terms first, tiles interleaved; the conversion of the next half tile
+            // is cut into NCH / BK pieces pinned between them
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].lo, aop.hi, acc[bn][bk]);
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.lo, acc[bn][bk]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int c = bk * (NCH / BK); c < bk * (NCH / BK) + (NCH / BK) / 2; ++c) convert_chunk(c, bnx, true);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].mid, aop.mid, acc[bn][bk]);
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].mid, aop.hi, acc[bn][bk]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int c = bk * (NCH / BK) + (NCH / BK) / 2; c < (bk + 1) * (NCH / BK); ++c) convert_chunk(c, bnx, true);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.mid, acc[bn][bk]);
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.hi, acc[bn][bk]);
+            __builtin_amdgcn_sched_barrier(0);
+            aop = anx;
+        }
+        if (it + 2 < iters) load_half(it + 2);                    // in flight during the next half tile's MFMAs
+        __syncthreads();                                          // next half converted by everybody, this one read by everybody
+        cur ^= 1;
+    }
+    // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
+    // (all MFMA results are complete before the first accumulator read whichever way the loop was left: see tn::pin16 for the
+    // hipcc wait-state bug; pinning 256 accumulator registers in VGPRs at once is not an option here)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            const int k = 32 * (tk0 + bk) + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * (tn0 + bn) + frow(r, h);
+                atomicAdd(&a.gW[(int64_t)nn * a.K + k], acc[bn][bk][r]);
+            }
+        }
+    // bias gradient: the four threads of a row (quarters of the 16 samples) are neighbours
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) {
+        float sgm = dbacc[c];
+        sgm += __shfl_xor(sgm, 1, 64);
+        sgm += __shfl_xor(sgm, 2, 64);
+        const int row = (threadIdx.x + 256 * c) >> 2;
+        if (qd == 0) atomicAdd(&a.gB[row], sgm);
+    }
+}
+
+template <int H, int BN, int BK>
+int launch_wgrad(const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
+{
+    constexpr size_t lds_bytes = (size_t)2 * 3 * (2 * H) * 24 * 2;
+    auto kern = wgrad_b3_kernel<H, BN, BK>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd(bf16x3): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int per_cu = lds_bytes * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1;
+    kern<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * per_cu)), dim3(256), lds_bytes, s>>>(w, n, stash);
+    return tn::check_launch("wgrad_b3_kernel");
 }
 
 template <int H, bool LAST>
@@ -359,9 +594,12 @@ __attribute__((visibility("hidden"))) int launch_dgrad_b3(int H, const DgradArgs
     return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): width 128 or 256");
 }
 
-__attribute__((visibility("hidden"))) int launch_wgrad_b3(int, const WgradArgs &, int64_t, const float *, hipStream_t)
+__attribute__((visibility("hidden"))) int launch_wgrad_b3(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
 {
-    return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): the weight gradient has no bf16x3 form yet");
+    if (w.first || w.N != H || w.K != H) return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): square hidden layers only");
+    if (H == 256) return launch_wgrad<256, 4, 4>(w, n, stash, s);
+    if (H == 128) return launch_wgrad<128, 2, 2>(w, n, stash, s);
+    return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): width 128 or 256");
 }
 
 }  // namespace layers

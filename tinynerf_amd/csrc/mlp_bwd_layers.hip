@@ -1041,7 +1041,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         bool staged = false;
         if constexpr (H == 256 || H == 128) {
             if (!w.first && w.N == H && w.K == H) {
-                if (int rc = launch_wgrad_lds<H, 2, H == 256 ? 4 : 1>(w, n, stash, s)) return rc;
+                if (a.b3) { if (int rc = launch_wgrad_b3(H, w, n, stash, s)) return rc; }
+                else if (int rc = launch_wgrad_lds<H, 2, H == 256 ? 4 : 1>(w, n, stash, s)) return rc;
                 staged = true;
             }
         }

@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the exact 3-way split: six bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
 # counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
@@ -226,12 +228,17 @@ def alloc_counters():
             "segments": int(st.get("segment.all.current", 0)), "reserved_gb": st.get("reserved_bytes.all.current", 0) / 2 ** 30}
 
 
-def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows):
+def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=None):
     """One of the reference's other model configurations on the headline's workload: warm up until the scratch arenas and the
     allocator have stopped growing, then `n_windows` windows of `steps` steps (synchronize on both sides); min / median over
     the windows, every step's time from HIP events on the launch stream, and the allocator's counters over the timed region
     (device_allocs_in_windows must be 0: a fresh hipMalloc in a step is a stall, not kernel time)."""
+    from tinynerf_amd import models as tn_models
     from tinynerf_amd.run import TrainConfig, Trainer
+    prev_mode = tn_models.MATMUL
+    if matmul is not None:
+        tn_models.MATMUL = matmul
+    mode = tn_models.MATMUL
     c2 = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
     t2 = Trainer(c2, o, d, rgbs, torch.ones(3, device=dev), dev)
     t2.occupancy_grid.grid.copy_(tr_main.occupancy_grid.grid)
@@ -272,9 +279,21 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows):
     # width-256 / 128 stacks: algorithmic FLOP of the whole model (forward + data gradient + weight gradient) over the step
     flop = model_flop_per_sample(t2.renderer)
     if flop:
-        out["mfma_frac"] = flop * out["samples_per_s"] / 1e12 / PEAK_FP32_MFMA_TFLOPS
+        tf = flop * out["samples_per_s"] / 1e12
         out["flop_per_sample_step"] = flop
+        out["tflops_fp32_equivalent"] = tf
+        out["matmul"] = mode
+        if mode == "bf16x3":
+            # wide-stack layers on the bf16 matrix cores with exact 3-way operand splits (TN_MLP_BF16X3): fp32-accurate products
+            # at six bf16 MFMAs each; the width-64 heads stay on the fp32 MFMA
+            out["mfma_frac"] = tf / PEAK_BF16X3_TFLOPS
+            out["mfma_peak"] = {"tflops": PEAK_BF16X3_TFLOPS, "what": "dense bf16 MFMA peak / 6 products per fp32 product (bf16x3)"}
+            out["vs_fp32_mfma_peak"] = tf / PEAK_FP32_MFMA_TFLOPS
+        else:
+            out["mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
+            out["mfma_peak"] = {"tflops": PEAK_FP32_MFMA_TFLOPS, "what": "fp32 MFMA peak"}
     del t2
+    tn_models.MATMUL = prev_mode
     return out
 
 
@@ -444,11 +463,11 @@ def main():
     others = None
     if rank == 0 and world == 1 and not args.no_stages:
         others = {}
-        for method in ("vanilla", "cobafa"):
+        for key, method, matmul in (("vanilla", "vanilla", None), ("cobafa", "cobafa", None), ("vanilla_fp32_mfma", "vanilla", "fp32")):
             try:
-                others[method] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows)
+                others[key] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows, matmul)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
-                others[method] = {"error": repr(e)}
+                others[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
 
     if rank == 0:

@@ -22,6 +22,7 @@
 #include "mlp_layers.h"
 #include "b3_device.h"
 #include <algorithm>
+#include <type_traits>
 
 #ifndef TN_B3_ABLATE
 #define TN_B3_ABLATE 0      // timing experiments only (wrong results): 1 = no conversion, 2 = no LDS-direct requests, 4 = no stores
@@ -47,7 +48,8 @@ template <int H> struct B3Geom {
     static constexpr int STREAMS = H == 256 ? 1 : 2;
     static constexpr int THREADS = STREAMS * WPS * 64;
     static constexpr int KS = H / 16;               // k steps
-    static constexpr int CONV = KS / 2;             // steps that carry the conversion of the next tile (2 * BPW pairs each)
+    static constexpr int CONV = KS / 2;             // steps that carry the conversion of the next tile (2 * BPW pairs each): the sooner
+                                                    // the staging area is free, the longer the request of the tile after next has to land
     static constexpr int SB = H + 8;                // bf16 elements per LDS tile row: (H + 8) * 2 B = odd multiple of 16 B
     static constexpr int PLANE = 32 * SB;           // bf16 elements per term plane
     static constexpr int TILE_B = 3 * PLANE * 2;    // bytes per tile buffer
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
     for (int c = 0; c < NCH; ++c) {
         const int row = (threadIdx.x + 256 * c) >> 2;
         src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
+        if (TN_B3_ABLATE & 64) src_off[c] = a.off_g * 32 + (threadIdx.x + 256 * c) * 4;      // (timing experiment: contiguous)
         dst_off[c] = row * RS + 4 * qd;
     }
     float dbacc[NCH / 2];
@@ -426,13 +429,22 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
     const int64_t iters = 2 * my_tiles;
     if (iters == 0) return;
     (void)n_half;
+    // The half tile in flight lives in ONE register set: chunk c of half tile k + 1 is requested right behind the conversion of
+    // chunk c of half tile k (its registers are free at that moment) and consumed one half tile later -- a whole iteration
+    // (~3000 matrix-pipe cycles) for every load, and at each conversion exactly NCH - 1 younger loads are outstanding, so the
+    // wait is a constant vmcnt(NCH - 1).  (Two sets swapped per iteration made hipcc's waitcnt pass drain the queue at the top
+    // of every half tile; a 64-bit address per lane makes it build the address in the load's destination registers: the
+    // loads take the SGPR-base form, wave-uniform base + the thread's 32-bit byte offset.)
     f32x4 st[NCH];
-    auto load_half = [&](int64_t it) {
-        const float *src = half_src(it);
+    unsigned src_boff[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) st[c] = *reinterpret_cast<const f32x4 *>(src + src_off[c]);
+    for (int c = 0; c < NCH; ++c) src_boff[c] = (unsigned)src_off[c] * 4u;
+    auto load_chunk = [&](const global_char *base, int c) {
+        unsigned off = src_boff[c];
+        asm volatile("" : "+v"(off));                          // (keeps the zero-extension at the access: SGPR-base form)
+        st[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(base + off);
     };
-    auto convert_chunk = [&](int c, unsigned short *buf, bool count_bias) {
+    auto convert_chunk = [&](int c, unsigned short *buf) {
         unsigned h0, m0, l0, h1, m1, l1;
         tn::b3::split2(st[c][0], st[c][1], h0, m0, l0);
         tn::b3::split2(st[c][2], st[c][3], h1, m1, l1);
@@ -440,13 +452,49 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
         *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
         *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(m0, m1);
         *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l0, l1);
-        if (count_bias && c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
+        if (c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
+    };
+    // The same conversion cut into 12 micro-steps of 2-4 instructions per chunk (split of the first value pair: 0-4, of the second:
+    // 5-9, LDS writes + bias sum + request of the chunk's successor: 10-11).  One wave per SIMD: an instruction overlaps with the
+    // matrix pipe only while an MFMA is EXECUTING, i.e. in the ~28 cycles behind each MFMA's issue -- a block of twenty VALU
+    // instructions behind eight MFMAs (what hipcc schedules) runs while the pipe is idle.  The k loop below pins one micro-step
+    // behind every MFMA.
+    unsigned cu[8];          // conversion state carried between micro-steps
+    float cf[4];
+    auto micro = [&](int c, int m, unsigned short *buf, const global_char *nb) {
+        const unsigned MSK = 0xffff0000u;
+        const int e = m >= 5 ? 2 : 0;                        // value pair (e, e + 1) of the chunk
+        const int mm = m >= 5 ? m - 5 : m;
+        if (m < 10) {
+            if (mm == 0) { cu[0] = __float_as_uint(st[c][e]) & MSK; cu[1] = __float_as_uint(st[c][e + 1]) & MSK; }
+            else if (mm == 1) { cf[0] = st[c][e] - __uint_as_float(cu[0]); cf[1] = st[c][e + 1] - __uint_as_float(cu[1]); }
+            else if (mm == 2) { cu[2] = __float_as_uint(cf[0]) & MSK; cu[3] = __float_as_uint(cf[1]) & MSK; }
+            else if (mm == 3) { cf[2] = cf[0] - __uint_as_float(cu[2]); cf[3] = cf[1] - __uint_as_float(cu[3]); }
+            else {              // packed pairs: hi -> cu[4 + e/2 .. ], mid, lo
+                const int q = e >> 1;
+                cu[0 + 0] = __builtin_amdgcn_perm(cu[1], cu[0], 0x07060302u);
+                cu[2] = __builtin_amdgcn_perm(cu[3], cu[2], 0x07060302u);
+                cu[1] = __builtin_amdgcn_perm(__float_as_uint(cf[3]), __float_as_uint(cf[2]), 0x07060302u);
+                if (q == 0) { cu[4] = cu[0]; cu[5] = cu[2]; cu[6] = cu[1]; }      // keep the first pair's (hi, mid, lo) for the 8-byte writes
+            }
+        } else if (m == 10) {
+            unsigned short *d = buf + dst_off[c];
+            *reinterpret_cast<uint2 *>(d) = make_uint2(cu[4], cu[0]);
+            *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(cu[5], cu[2]);
+            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(cu[6], cu[1]);
+        } else {
+            if (c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
+            load_chunk(nb, c);
+        }
     };
     // prologue: half tile 0 converted, half tile 1 in registers
-    load_half(0);
+    {
+        const global_char *b0 = wave_uniform_global(half_src(0)), *b1 = wave_uniform_global(half_src(1));
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) convert_chunk(c, lds, true);
-    load_half(1);
+        for (int c = 0; c < NCH; ++c) load_chunk(b0, c);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { convert_chunk(c, lds); load_chunk(b1, c); }
+    }
     __syncthreads();
     int g_off[BN], a_off[BK];
 #pragma unroll
@@ -460,12 +508,15 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
         o.lo = *reinterpret_cast<const u32x4 *>(buf + off + 2 * PLANE);
         return o;
     };
-    int cur = 0;
-#pragma clang loop unroll(disable)
-    for (int64_t it = 0; it < iters; ++it) {
+    // one half tile: MFMAs from buffer `cur`; (CONVERT) chunk by chunk, the next half (in `st`) is converted into the other buffer
+    // and the half after that requested into the registers just freed.  The last half tile of the workgroup has nothing to
+    // convert: it runs as a second instance of the body behind the loop, so that inside the loop conversion and requests are
+    // unconditional (a branch around them makes hipcc's counted vmcnt waits collapse to vmcnt(0)).
+    auto half_step = [&](int64_t it, int cur, auto convert_tag) {
+        constexpr bool CONVERT = decltype(convert_tag)::value;
         const unsigned short *bc = lds + cur * BUF;
         unsigned short *bnx = lds + (cur ^ 1) * BUF;
-        const bool more = it + 1 < iters;                         // (wave-uniform) half tile it + 1 exists: it sits in `st`
+        const global_char *nb = wave_uniform_global(half_src(it + 2 < iters ? it + 2 : it));     // (clamped: loaded, never used)
         Op gop[BN];
 #pragma unroll
         for (int bn = 0; bn < BN; ++bn) gop[bn] = read_op(bc, g_off[bn]);
@@ -476,39 +527,45 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
             Op anx = aop;
             if (bk + 1 < BK) anx = read_op(bc, a_off[bk + 1]);
             __builtin_amdgcn_sched_barrier(0);
-            // six partial products per output tile, small terms first, tiles interleaved; the conversion of the next half tile
-            // is cut into NCH / BK pieces pinned between them
+            // six partial products per output tile, small terms first, tiles interleaved; one conversion micro-step (two for the
+            // narrow stack) pinned behind every MFMA
+            constexpr int NM = BN * BK * 6, MS = NCH * 12, PER = MS / NM;
+            static_assert(PER * NM == MS, "micro-steps divide evenly over the MFMAs");
+            auto term = [&](int t, const u32x4 &(*ga)(const Op &), const u32x4 &(*ab)(const Op &)) {
 #pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].lo, aop.hi, acc[bn][bk]);
+                for (int bn = 0; bn < BN; ++bn) {
+                    acc[bn][bk] = tn::b3::mfma16(ga(gop[bn]), ab(aop), acc[bn][bk]);
+                    if constexpr (CONVERT && !(TN_B3_ABLATE & 8)) {
 #pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.lo, acc[bn][bk]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-#pragma unroll
-                for (int c = bk * (NCH / BK); c < bk * (NCH / BK) + (NCH / BK) / 2; ++c) convert_chunk(c, bnx, true);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].mid, aop.mid, acc[bn][bk]);
-#pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].mid, aop.hi, acc[bn][bk]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-#pragma unroll
-                for (int c = bk * (NCH / BK) + (NCH / BK) / 2; c < (bk + 1) * (NCH / BK); ++c) convert_chunk(c, bnx, true);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.mid, acc[bn][bk]);
-#pragma unroll
-            for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma16(gop[bn].hi, aop.hi, acc[bn][bk]);
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int u = 0; u < PER; ++u) {
+                            const int m = ((bk * 6 + t) * BN + bn) * PER + u;
+                            micro(m / 12, m % 12, bnx, nb);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            term(0, [](const Op &o) -> const u32x4 & { return o.lo; }, [](const Op &o) -> const u32x4 & { return o.hi; });
+            term(1, [](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.lo; });
+            term(2, [](const Op &o) -> const u32x4 & { return o.mid; }, [](const Op &o) -> const u32x4 & { return o.mid; });
+            term(3, [](const Op &o) -> const u32x4 & { return o.mid; }, [](const Op &o) -> const u32x4 & { return o.hi; });
+            term(4, [](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.mid; });
+            term(5, [](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.hi; });
             aop = anx;
         }
-        if (it + 2 < iters) load_half(it + 2);                    // in flight during the next half tile's MFMAs
-        __syncthreads();                                          // next half converted by everybody, this one read by everybody
+        // next half converted by everybody, this one read by everybody: LDS traffic retired, then a RAW barrier -- __syncthreads()
+        // carries vmcnt(0) and would wait for the loads just requested
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it + 1 < iters; ++it) {
+        half_step(it, cur, std::true_type{});
         cur ^= 1;
     }
+    half_step(iters - 1, cur, std::false_type{});
     // ---- flush: full-line atomics (lanes = consecutive columns of one weight row) ----
     // (all MFMA results are complete before the first accumulator read whichever way the loop was left: see tn::pin16 for the
     // hipcc wait-state bug; pinning 256 accumulator registers in VGPRs at once is not an option here)

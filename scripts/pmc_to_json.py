@@ -56,10 +56,12 @@ if chain:
 kb = find("kplanes_bwd_kernel")
 if kb:
     lanes["tn_kplanes_bwd"] = kb["WRITE_SIZE_KB"] * 1024 / 4.0
-# bytes per training step: every kernel seen at least once per step on average (torch glue included)
+# bytes per training step: every launch of the run (torch glue and the occupancy refresh of the first step included) ...
 per_step = sum(v["bytes"] * v["launches_seen"] for v in per.values()) / steps
+# ... and the steady state: kernels that ran in every step (the refresh every 64 steps and one-off set-up kernels left out)
+per_step_steady = sum(v["bytes"] * v["launches_seen"] for v in per.values() if v["launches_seen"] >= steps) / steps
 json.dump({"note": __doc__.strip().replace("\n", " "),
            "command": "scripts/pmc.sh <tag> --steps 3 --warmup 1 --no-stages (one rocprofv3 --pmc pass per counter), then this script",
-           "steps_seen": steps, "samples_per_step": samples, "bytes_per_step": per_step, "per_entry": entry,
+           "steps_seen": steps, "samples_per_step": samples, "bytes_per_step": per_step_steady, "bytes_per_step_all_launches": per_step, "per_entry": entry,
            "lane_atomics_per_entry": lanes, "per_kernel": per}, open(dst, "w"), indent=1)
-print(json.dumps({"per_entry": entry, "lane_atomics_per_entry": lanes, "bytes_per_step": per_step}, indent=1))
+print(json.dumps({"per_entry": entry, "lane_atomics_per_entry": lanes, "bytes_per_step": per_step_steady, "bytes_per_step_all_launches": per_step}, indent=1))

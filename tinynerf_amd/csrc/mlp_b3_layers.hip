@@ -196,41 +196,51 @@ struct Stream {
                 if (!(TN_B3_ABLATE & 2)) request(stash, next2, rows_total, off);
             }
             // six partial products, small terms first, blocks interleaved (consecutive MFMAs never share an accumulator).  The
-            // split / ds_write of the values read one step ago is cut into PPS pieces that are pinned BETWEEN the terms: an
-            // in-order wave issues them in the shadow of the MFMA that is executing; clustered behind the MFMAs (hipcc's
-            // choice, whatever sched_group_barrier asks for) they run while the matrix pipe drains
+            // split / ds_write of the values read one step ago is cut into micro-steps of 2-3 instructions, one (two for
+            // H = 128) pinned behind every MFMA: with one wave per SIMD an instruction overlaps with the matrix pipe only while
+            // an MFMA is executing, i.e. in the ~28 cycles behind each MFMA's issue; clustered behind the MFMAs (hipcc's
+            // choice, whatever sched_group_barrier asks for) the conversion runs while the pipe is idle
             const bool conv = s >= 1 && s <= CONV && !(TN_B3_ABLATE & 1);
-            auto piece = [&](int u) {
-                if (!conv || u >= PPS) return;
-                const int p = PPS * (s - 1) + u, bq = p >> 3, q = p & 7;
-                unsigned hi, mid, lo;
-                tn::b3::split2(cv[2 * u], cv[2 * u + 1], hi, mid, lo);
-                unsigned short *d = n_ + 32 * bq + 2 * q;
-                *reinterpret_cast<unsigned *>(d) = hi;
-                *reinterpret_cast<unsigned *>(d + PLANE) = mid;
-                *reinterpret_cast<unsigned *>(d + 2 * PLANE) = lo;
-                __builtin_amdgcn_sched_barrier(0);
+            constexpr int NMS = 6 * PPS, NMF = 6 * BPW, PER = (NMS + NMF - 1) / NMF;      // micro-steps / MFMAs per step
+            unsigned cu[4];
+            float cf[4];
+            auto micro = [&](int m) {
+                if (!conv || m >= NMS) return;
+                const int u = m / 6, mm = m % 6;
+                const unsigned MSK = 0xffff0000u;
+                if (mm == 0) { cu[0] = __float_as_uint(cv[2 * u]) & MSK; cu[1] = __float_as_uint(cv[2 * u + 1]) & MSK; }
+                else if (mm == 1) { cf[0] = cv[2 * u] - __uint_as_float(cu[0]); cf[1] = cv[2 * u + 1] - __uint_as_float(cu[1]); }
+                else if (mm == 2) { cu[2] = __float_as_uint(cf[0]) & MSK; cu[3] = __float_as_uint(cf[1]) & MSK; }
+                else if (mm == 3) { cf[2] = cf[0] - __uint_as_float(cu[2]); cf[3] = cf[1] - __uint_as_float(cu[3]); }
+                else if (mm == 4) {
+                    cu[0] = __builtin_amdgcn_perm(cu[1], cu[0], 0x07060302u);
+                    cu[2] = __builtin_amdgcn_perm(cu[3], cu[2], 0x07060302u);
+                    cu[1] = __builtin_amdgcn_perm(__float_as_uint(cf[3]), __float_as_uint(cf[2]), 0x07060302u);
+                } else {
+                    const int p = PPS * (s - 1) + u, bq = p >> 3, q = p & 7;
+                    unsigned short *d = n_ + 32 * bq + 2 * q;
+                    *reinterpret_cast<unsigned *>(d) = cu[0];
+                    *reinterpret_cast<unsigned *>(d + PLANE) = cu[2];
+                    *reinterpret_cast<unsigned *>(d + 2 * PLANE) = cu[1];
+                }
             };
+            int g = 0;
+            auto term = [&](const u32x4 &(*wa)(const Op &), const u32x4 &(*xb)(const Op &)) {
 #pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].lo, b.hi, acc[bq]);
-            __builtin_amdgcn_sched_barrier(0);
-            piece(0);
+                for (int bq = 0; bq < BPW; ++bq) {
+                    acc[bq] = tn::b3::mfma16(wa(A[bq][s]), xb(b), acc[bq]);
 #pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.lo, acc[bq]);
-            __builtin_amdgcn_sched_barrier(0);
-            piece(1);
-#pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].mid, b.mid, acc[bq]);
-            __builtin_amdgcn_sched_barrier(0);
-            piece(2);
-#pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].mid, b.hi, acc[bq]);
-            __builtin_amdgcn_sched_barrier(0);
-            piece(3);
-#pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.mid, acc[bq]);
-#pragma unroll
-            for (int bq = 0; bq < BPW; ++bq) acc[bq] = tn::b3::mfma16(A[bq][s].hi, b.hi, acc[bq]);
+                    for (int e = 0; e < PER; ++e) micro(g * PER + e);
+                    ++g;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            term([](const Op &o) -> const u32x4 & { return o.lo; }, [](const Op &o) -> const u32x4 & { return o.hi; });
+            term([](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.lo; });
+            term([](const Op &o) -> const u32x4 & { return o.mid; }, [](const Op &o) -> const u32x4 & { return o.mid; });
+            term([](const Op &o) -> const u32x4 & { return o.mid; }, [](const Op &o) -> const u32x4 & { return o.hi; });
+            term([](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.mid; });
+            term([](const Op &o) -> const u32x4 & { return o.hi; }, [](const Op &o) -> const u32x4 & { return o.hi; });
             __builtin_amdgcn_sched_barrier(0);
             b = bn;
 #pragma unroll

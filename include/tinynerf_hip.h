@@ -137,6 +137,11 @@ int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32_t *base_of
  * plan[3] = 1 if the rule tripped within the supplied rays (else every supplied batch is used). */
 int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
                   void *stream);
+/* tn_batch_plan and tn_sample_scan(counts, n_rays, NULL, info, NULL) over ALL candidate rays as one multi-workgroup launch
+ * (the training step's form: the harness uses the first plan[2] rows of info once the plan is on the host, so that nothing but
+ * tn_sample_pack is left behind the step's read-back; reference run.py:215-244 + core.py:179-181). */
+int tn_batch_plan_scan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
+                       int32_t *info, void *stream);
 /* pass 3: packed[start_r - base + j] = (contracted xyz, ray dir, step) for the j-th set bit
  * (core.py:182-186).  ray_ids / steps (optional) receive the ray index and the step size (column 6) of every packed
  * sample as contiguous arrays (what the weights kernels and the per-ray colour-head table index). */

@@ -261,6 +261,118 @@ __global__ __launch_bounds__(1024) void sample_scan_kernel(
     if (threadIdx.x == 0 && total) total[0] = carry_s;
 }
 
+// Multi-workgroup form of the scan: workgroup b owns rays [4096 b, 4096 (b + 1)) and reads the counts below its range itself
+// (b 16-byte loads per thread out of L2) instead of waiting for a carry -- no inter-workgroup traffic, no flags, one launch;
+// integer sums, so the result does not depend on the order.  counts must be 16-byte aligned (the launcher checks).
+__global__ __launch_bounds__(1024) void sample_scan_mb_kernel(
+    const int32_t *__restrict__ counts, int64_t n_rays, const int32_t *__restrict__ base_offset,
+    int32_t *__restrict__ info, int32_t *__restrict__ total)
+{
+    __shared__ int32_t wave_tot[16], pre_tot[16];
+    const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * 4096;
+    int32_t pre = 0;
+    const int4 *c4 = reinterpret_cast<const int4 *>(counts);
+    for (int64_t q = threadIdx.x; q < (lo >> 2); q += 1024) { const int4 v = c4[q]; pre += (v.x + v.y) + (v.z + v.w); }
+    const int64_t r0 = lo + 4 * (int64_t)threadIdx.x;
+    int32_t c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (r0 + u < n_rays) ? counts[r0 + u] : 0;
+    const int32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+    int32_t v = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (lane == 63) wave_tot[wave] = v;
+    if (lane == 0) pre_tot[wave] = pre;
+    __syncthreads();
+    int32_t below = 0, wave_off = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { below += pre_tot[w]; wave_off += w < wave ? wave_tot[w] : 0; }
+    int32_t run = (base_offset ? base_offset[0] : 0) + below + wave_off + v - mine;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (r0 + u < n_rays) { info[2 * (r0 + u)] = run; info[2 * (r0 + u) + 1] = c[u]; }
+        run += c[u];
+    }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) total[0] = below + wave_off + v;
+}
+
+// Dynamic-batch rule AND the scan of every candidate ray in one launch (tn_batch_plan_scan): workgroup b owns loader batch b.
+// Its waves first reduce the batches below b (wave w: batches w, w + 16, ...; the counts are L2-resident, written by the mask
+// pass just before), so every workgroup knows its own start without waiting for another one; then it scans its own rays.  The
+// last workgroup holds every batch sum and evaluates the sequential rule on one lane.  <= MAX_PLAN_BATCHES workgroups: the
+// redundant reads grow with the square of the batch count (48 batches of 1024 rays: 4.7 MB out of L2 in total).
+constexpr int MAX_PLAN_BATCHES = 256;
+__global__ __launch_bounds__(1024) void batch_plan_scan_kernel(const int32_t *__restrict__ counts, int64_t n_rays, int32_t batch_size,
+                                                               int64_t target, int32_t *__restrict__ plan, int32_t *__restrict__ info)
+{
+    __shared__ int32_t sums[MAX_PLAN_BATCHES];
+    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t carry_s;
+    const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, n_batches = gridDim.x;
+    for (int j = wave; j < b; j += 16) {
+        int32_t s = 0;
+        const int64_t lo = (int64_t)j * batch_size, hi = lo + batch_size;             // j < b: a full batch
+        for (int64_t r = lo + lane; r < hi; r += 64) s += counts[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) sums[j] = s;
+    }
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    int32_t below = 0;
+    for (int j = 0; j < b; ++j) below += sums[j];                                     // LDS broadcast reads
+    const int64_t lo = (int64_t)b * batch_size;
+    const int64_t hi = lo + batch_size < n_rays ? lo + batch_size : n_rays;
+    for (int64_t tile = lo; tile < hi; tile += 4096) {
+        const int64_t r0 = tile + 4 * (int64_t)threadIdx.x;
+        int32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (r0 + u < hi) ? counts[r0 + u] : 0;
+        const int32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+        int32_t v = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) wave_tot[wave] = v;
+        __syncthreads();
+        int32_t wave_off = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) wave_off += w < wave ? wave_tot[w] : 0;
+        const int32_t carry = carry_s;
+        int32_t run = below + carry + wave_off + v - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u < hi) { info[2 * (r0 + u)] = run; info[2 * (r0 + u) + 1] = c[u]; }
+            run += c[u];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + v;
+        __syncthreads();
+    }
+    if (b == n_batches - 1 && threadIdx.x == 0) {
+        sums[b] = carry_s;
+        int64_t cur = 0;
+        int k = 0, tripped = 0;
+        while (k < n_batches) {
+            cur += sums[k];
+            ++k;
+            const int64_t projected = (int64_t)((double)cur * (1.0 + 1.0 / (double)k));     // run.py:240
+            if (projected >= target) { tripped = 1; break; }
+        }
+        const int64_t R = (int64_t)k * batch_size < n_rays ? (int64_t)k * batch_size : n_rays;
+        plan[0] = k; plan[1] = (int32_t)cur; plan[2] = (int32_t)R; plan[3] = tripped;
+    }
+}
+
 // reference run.py:215-244 -- the dynamic-batch projection rule evaluated on the device: per-loader-batch sums
 // by wave reductions, then the (inherently sequential, <= 4096 steps) rule on one lane.
 __global__ __launch_bounds__(1024) void batch_plan_kernel(const int32_t *__restrict__ counts, int64_t n_rays,
@@ -496,6 +608,11 @@ extern "C" int tn_sample_scan(const int32_t *counts, int64_t n_rays, const int32
 {
     TN_REQUIRE(n_rays >= 0, TN_E_SIZE, "tn_sample_scan: negative n_rays");
     TN_REQUIRE(n_rays == 0 || (counts && info), TN_E_NULL, "tn_sample_scan: null pointer");
+    if (n_rays > 4096 && n_rays <= ((int64_t)1 << 21) && (reinterpret_cast<uintptr_t>(counts) & 15) == 0) {
+        hipLaunchKernelGGL(sample_scan_mb_kernel, dim3((unsigned)((n_rays + 4095) / 4096)), dim3(1024), 0, (hipStream_t)stream, counts, n_rays,
+                           base_offset, info, total);
+        return tn::check_launch("sample_scan_mb_kernel");
+    }
     hipLaunchKernelGGL(sample_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, base_offset, info, total);
     return tn::check_launch("sample_scan_kernel");
 }
@@ -508,6 +625,21 @@ extern "C" int tn_batch_plan(const int32_t *counts, int64_t n_rays, int32_t batc
     TN_REQUIRE(plan && (n_rays == 0 || counts), TN_E_NULL, "tn_batch_plan: null pointer");
     batch_plan_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(counts, n_rays, batch_size, target, plan);
     return tn::check_launch("batch_plan_kernel");
+}
+
+extern "C" int tn_batch_plan_scan(const int32_t *counts, int64_t n_rays, int32_t batch_size, int64_t target, int32_t *plan,
+                                  int32_t *info, void *stream)
+{
+    TN_REQUIRE(n_rays >= 0 && batch_size > 0 && target >= 0, TN_E_SIZE, "tn_batch_plan_scan: bad size");
+    const int64_t n_batches = (n_rays + batch_size - 1) / batch_size;
+    TN_REQUIRE(n_batches <= 4096, TN_E_SIZE, "tn_batch_plan_scan: more than 4096 loader batches");
+    TN_REQUIRE(plan && (n_rays == 0 || (counts && info)), TN_E_NULL, "tn_batch_plan_scan: null pointer");
+    if (n_batches >= 1 && n_batches <= MAX_PLAN_BATCHES) {
+        batch_plan_scan_kernel<<<dim3((unsigned)n_batches), dim3(1024), 0, (hipStream_t)stream>>>(counts, n_rays, batch_size, target, plan, info);
+        return tn::check_launch("batch_plan_scan_kernel");
+    }
+    if (int rc = tn_batch_plan(counts, n_rays, batch_size, target, plan, stream)) return rc;
+    return n_rays ? tn_sample_scan(counts, n_rays, nullptr, info, nullptr, stream) : TN_OK;
 }
 
 extern "C" int tn_sample_pack(const tn_sampler_desc *desc, const float *rays_o, const float *rays_d, int64_t n_rays,

@@ -372,6 +372,51 @@ def test_batch_plan_vs_oracle_random(seed):
     L.call("tn_batch_plan", torch.device(DEV), L.ptr(c_dev), C.c_int64(n_b * B), C.c_int32(B), C.c_int64(target), L.ptr(plan))
     k, n, R, tripped = plan.tolist()
     assert (k, n, R, tripped) == (k_ref, n_ref, k_ref * B, tripped_ref)
+    # the training step's form: the rule and the scan of every candidate ray in one multi-workgroup launch
+    plan2 = torch.zeros(4, dtype=torch.int32, device=DEV)
+    info = torch.full((n_b * B, 2), -1, dtype=torch.int32, device=DEV)
+    L.call("tn_batch_plan_scan", torch.device(DEV), L.ptr(c_dev), C.c_int64(n_b * B), C.c_int32(B), C.c_int64(target), L.ptr(plan2), L.ptr(info))
+    assert plan2.tolist() == [k, n, R, tripped]
+    flat = counts.reshape(-1).astype(np.int64)
+    np.testing.assert_array_equal(info.cpu().numpy(), np.stack([np.cumsum(flat) - flat, flat], -1).astype(np.int32))
+
+
+@pytest.mark.parametrize("n_rays,B", [(1, 1), (4097, 1024), (50_000, 1024), (49_999, 5000), (300 * 64, 64), (260 * 16 + 3, 16)])
+def test_batch_plan_scan_shapes(n_rays, B):
+    """ragged last batch, batches larger than one 4096-ray sweep, and the > 256-batch fallback to the two single launches"""
+    from tinynerf_amd import _lib as L
+    rng = np.random.default_rng(n_rays)
+    counts = (rng.integers(0, 200, n_rays) * (rng.random(n_rays) < 0.4)).astype(np.int32)
+    target = int(counts.sum() * 0.6) + 1
+    c_dev = cu(counts, torch.int32)
+    plan, plan2 = torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV)
+    info = torch.full((n_rays, 2), -1, dtype=torch.int32, device=DEV)
+    L.call("tn_batch_plan", torch.device(DEV), L.ptr(c_dev), C.c_int64(n_rays), C.c_int32(B), C.c_int64(target), L.ptr(plan))
+    L.call("tn_batch_plan_scan", torch.device(DEV), L.ptr(c_dev), C.c_int64(n_rays), C.c_int32(B), C.c_int64(target), L.ptr(plan2), L.ptr(info))
+    assert plan.tolist() == plan2.tolist()
+    flat = counts.astype(np.int64)
+    np.testing.assert_array_equal(info.cpu().numpy(), np.stack([np.cumsum(flat) - flat, flat], -1).astype(np.int32))
+
+
+@pytest.mark.parametrize("n_rays", [4096, 4097, 12_345, 640_000, (1 << 21) + 5])
+def test_sample_scan_multi_workgroup(n_rays):
+    """core.py:179-181 at image size: the multi-workgroup scan (4096 < R <= 2^21, aligned counts), its single-workgroup form on
+    either side of that range and on an unaligned view, all against numpy, with and without the base offset of run.py:231"""
+    from tinynerf_amd import _lib as L
+    rng = np.random.default_rng(n_rays)
+    counts = (rng.integers(0, 900, n_rays + 1) * (rng.random(n_rays + 1) < 0.3)).astype(np.int32)
+    c_all = cu(counts, torch.int32)
+    base = torch.tensor([12345], dtype=torch.int32, device=DEV)
+    for off in (0, 1):
+        c_dev = c_all[off:off + n_rays]
+        ref = counts[off:off + n_rays].astype(np.int64)
+        for b in (None, base):
+            info = torch.full((n_rays, 2), -1, dtype=torch.int32, device=DEV)
+            total = torch.zeros(1, dtype=torch.int32, device=DEV)
+            L.call("tn_sample_scan", torch.device(DEV), L.ptr(c_dev), C.c_int64(n_rays), L.ptr(b) if b is not None else C.c_void_p(None), L.ptr(info),
+                   L.ptr(total))
+            np.testing.assert_array_equal(info.cpu().numpy(), np.stack([np.cumsum(ref) - ref + (12345 if b is not None else 0), ref], -1).astype(np.int32))
+            assert int(total.item()) == int(ref.sum())
 
 
 # ------------------------------------------------------------------------------------------------ INTEGRATION.md section 1

@@ -138,6 +138,7 @@ class Trainer:
         if world_size > 1 and isinstance(self.renderer.feature_module, KPlanesFeatureField):
             self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
         self._plan_host: Optional[torch.Tensor] = None
+        self._info_turn = 0
         self.prefetch = True
 
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -207,14 +208,20 @@ class Trainer:
         maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
         counts = self._buf("counts", (R_all,), torch.int32)
         plan = self._buf("plan", (4,), torch.int32)
+        # (offset, count) of EVERY candidate ray, in the same launch as the rule (the scan of a prefix does not depend on where the
+        # rule cuts): behind the read-back only the pack is left.  Two buffers in turn: this runs during the previous step, whose
+        # backward pass still reads its own info.
+        self._info_turn ^= 1
+        info = self._buf(f"info{self._info_turn}", (R_all, 2), torch.int32)
         L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
-        L.call("tn_batch_plan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan))
+        L.call("tn_batch_plan_scan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan),
+               L.ptr(info))
         if self._plan_host is None:
             self._plan_host = torch.empty(4, dtype=torch.int32, pin_memory=True)
             self._plan_event = torch.cuda.Event()
         self._plan_host.copy_(plan, non_blocking=True)
         self._plan_event.record(torch.cuda.current_stream(dev))
-        self._pending = dict(n_b=n_b, idx=idx, o=o, d=d, desc=desc, maskbits=maskbits, counts=counts)
+        self._pending = dict(n_b=n_b, idx=idx, o=o, d=d, desc=desc, maskbits=maskbits, counts=counts, info=info)
 
     @torch.no_grad()
     def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
@@ -234,9 +241,7 @@ class Trainer:
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         if not self.cfg.deterministic:
             self._advance(R)
-        info = self._buf("info", (R, 2), torch.int32)
-        total = self._buf("total", (1,), torch.int32)
-        L.call("tn_sample_scan", dev, L.ptr(pend["counts"]), C.c_int64(R), C.c_void_p(None), L.ptr(info), L.ptr(total))
+        info = pend["info"][:R]
         packed = self._buf("packed", (n, 7), torch.float32)
         ray_ids = self._buf("ray_ids", (n,), torch.int32)
         steps = self._buf("steps", (n,), torch.float32)

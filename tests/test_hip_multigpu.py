@@ -230,7 +230,9 @@ def test_ranks_equal_one_rank_on_the_union(method, world, smooth):
                     # elements carry 1e-4 of the largest element as order noise, and from the second step on Adam (eps 1e-15)
                     # turns that noise into full-size updates of the elements it hits; the tensor as a whole must agree to
                     # 2e-5 on the first step and to 5e-3 afterwards
-                    assert float(np.linalg.norm((got - ref).astype(np.float64))) <= (2e-5 if first else 5e-3) * float(np.linalg.norm(ref.astype(np.float64))), (k, step)
+                    # (smooth steps after the first: the parameters themselves differ by the first step's order noise -- seen up to 2.8e-5)
+                    norm_tol = 2e-5 if step == 0 else (1e-4 if smooth else 5e-3)
+                    assert float(np.linalg.norm((got - ref).astype(np.float64))) <= norm_tol * float(np.linalg.norm(ref.astype(np.float64))), (k, step)
                     np.testing.assert_allclose(got, ref, rtol=0, atol=(5e-3 if first else 5e-2) * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
                 else:
                     np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-12), err_msg=k)

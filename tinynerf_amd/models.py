@@ -129,6 +129,8 @@ class _FusedMLP(Function):
                 L.call("tn_mlp_fwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), C.c_void_p(None))
         if not hasattr(ctx, "link"):
             ctx.link = None
+        # harness (scratch[3]): weight gradients are added straight into param.grad where it exists (the optimizer pass zeroes it)
+        ctx.param_refs = params if (scratch is not None and len(scratch) > 3 and scratch[3]) else None
         ctx.save_for_backward(x2, aux2, freqs, ws, *ps)
         ctx.cfg = (encoding, n_freqs, out_act)
         ctx.x_shape = x.shape
@@ -147,7 +149,9 @@ class _FusedMLP(Function):
         gy = None if delivered else grad_y.reshape(n, -1).to(torch.float32).contiguous()
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs,
                          (L.MLP_STASHED if ws_fwd is not None else 0) | (L.MLP_GRAD_Y_ROWS if delivered else 0))
-        grads = [torch.zeros_like(p) for p in ps]
+        refs = ctx.param_refs if ctx.param_refs is not None else [None] * len(ps)
+        in_place = [r is not None and r.grad is not None and r.grad.stride() == p.stride() and r.grad.dtype == p.dtype for r, p in zip(refs, ps)]
+        grads = [r.grad if ip else torch.zeros_like(p) for r, p, ip in zip(refs, ps, in_place)]
         n_layers = len(ps) // 2
         gw = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[0::2]])
         gb = (C.c_void_p * n_layers)(*[g.data_ptr() for g in grads[1::2]])
@@ -160,7 +164,7 @@ class _FusedMLP(Function):
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
-        return (gx_out, None, None, None, None, None, None, None, *grads)
+        return (gx_out, None, None, None, None, None, None, None, *[None if ip else g for g, ip in zip(grads, in_place)])
 
 
 def _linear_params(net: torch.nn.Sequential) -> List[torch.Tensor]:
@@ -612,7 +616,9 @@ def _cobafa_desc(coef: torch.Tensor, basis: Sequence[torch.Tensor], freqs: Seque
 
 class _CobafaFeatures(Function):
     @staticmethod
-    def forward(ctx: Any, x: torch.Tensor, freqs: Tuple[float, ...], coef: torch.Tensor, *basis: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def forward(ctx: Any, x: torch.Tensor, freqs: Tuple[float, ...], accumulate: bool, coef: torch.Tensor, *basis: torch.Tensor) -> torch.Tensor:  # type: ignore
+        # accumulate (harness switch, run.Trainer): the scatter adds straight into grid.grad where it exists
+        ctx.param_refs = (coef, *basis) if accumulate else None
         x = x.contiguous()
         dev = L.require_cuda(x)
         if not all(g.is_cuda for g in (coef, *basis)):
@@ -628,12 +634,17 @@ class _CobafaFeatures(Function):
     def backward(ctx: Any, g: torch.Tensor):  # type: ignore
         x, coef, *basis = ctx.saved_tensors
         desc, keep = _cobafa_desc(coef, basis, ctx.freqs)
-        g_coef = torch.zeros_like(coef, memory_format=torch.channels_last_3d)
-        g_basis = [torch.zeros_like(b, memory_format=torch.channels_last_3d) for b in basis]
+        refs = ctx.param_refs if ctx.param_refs is not None else [None] * (1 + len(basis))
+        out = []
+        for r, p in zip(refs, (coef, *basis)):
+            ip = (r is not None and r.requires_grad and r.grad is not None and r.grad.stride() == p.stride()
+                  and p.is_contiguous(memory_format=torch.channels_last_3d))
+            out.append((r.grad if ip else torch.zeros_like(p, memory_format=torch.channels_last_3d), ip))
+        g_coef, g_basis = out[0][0], [o[0] for o in out[1:]]
         gb = (C.c_void_p * len(basis))(*[_dhwc(t).data_ptr() for t in g_basis])
         L.call("tn_cobafa_bwd", x.device, C.byref(desc), L.ptr(x), C.c_int64(x.size(0)), L.ptr(g.contiguous()),
                L.ptr(_dhwc(g_coef)), gb)
-        return (None, None, g_coef, *g_basis)
+        return (None, None, None, *[None if ip else t for t, ip in out])
 
 
 class SawtoothEncoding(torch.nn.Module):
@@ -662,7 +673,7 @@ class CobafaGrid(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         one = torch.ones((1, 1, 1, 1, 1), device=x.device)
-        out = _CobafaFeatures.apply(x.reshape(-1, 3), (0.0,), one, self.grid)
+        out = _CobafaFeatures.apply(x.reshape(-1, 3), (0.0,), False, one, self.grid)
         return out.view(*x.size()[:-1], self.feature_dim)
 
 
@@ -683,7 +694,8 @@ class CobafaFeatureField(torch.nn.Module):
         self.feature_dim = mlp_hidden_dim
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
-        return _CobafaFeatures.apply(x.reshape(-1, 3), self.freqs, self.coef_grid.grid, *[b.grid for b in self.basis_grids])
+        return _CobafaFeatures.apply(x.reshape(-1, 3), self.freqs, bool(self.__dict__.get("accumulate_into_grad")), self.coef_grid.grid,
+                                     *[b.grid for b in self.basis_grids])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.mlp(self.dropout(self.features(x)))

@@ -109,7 +109,9 @@ class Trainer:
         from .models import MLP
         self.scratch = Arena()
         for i, m in enumerate(mod for mod in self.renderer.feature_module.modules() if isinstance(mod, MLP)):
-            m.__dict__["scratch"] = (self.scratch, f"mlp_ws{i}", {})
+            m.__dict__["scratch"] = (self.scratch, f"mlp_ws{i}", {}, True)
+        if isinstance(self.renderer.feature_module, CobafaFeatureField):
+            self.renderer.feature_module.__dict__["accumulate_into_grad"] = True
         self._arena: Dict[str, torch.Tensor] = {}
         self._arena_grown = 0
         # torch.optim.Adam's update (run.py:186), one kernel pass per tensor, gradients zeroed in the same pass

@@ -296,6 +296,24 @@ __global__ __launch_bounds__(B3Geom<H>::THREADS) void fwd_b3_kernel(FwdLayerArgs
             if constexpr (!LAST) {
                 acc[bq] = tn::relu16(acc[bq]);
                 if (!(TN_B3_ABLATE & 4) || acc[bq][0] == 123.f) wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc[bq]);
+            } else if (a.N == H) {
+                // full-width output (the feature stacks: y = 256 / 128 features): pre-activation rows through the SGPR-base stores,
+                // y as four 16-byte stores per block -- a fixed number of vector-memory operations behind the k loop's request,
+                // so that the tile ends with a counted wait instead of draining them
+                const int64_t row = tile * 32 + j;
+                const bool valid = row < n;
+                f32x16 pre;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pre[r] = valid ? acc[bq][r] : 0.0f;
+                wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, pre);
+                float *yr = y + (valid ? row : 0) * H + 32 * ob + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = tn::apply_act(acc[bq][4 * q + u], a.out_act);
+                    if (valid) *reinterpret_cast<f32x4 *>(yr + 8 * q) = v;
+                }
             } else if (32 * ob < a.N) {
                 float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
                 const int64_t row = tile * 32 + j;
@@ -330,7 +348,8 @@ __global__ __launch_bounds__(B3Geom<H>::THREADS) void fwd_b3_kernel(FwdLayerArgs
             }
             st.template tile_barrier<16 * BPW>();   // (with the bit rows 17 BPW stores follow the request: the bound still covers it)
         } else {
-            st.template tile_barrier<0>();          // (the last layer's y stores are conditional: count nothing)
+            if (a.N == H) st.template tile_barrier<20 * BPW>();   // (a tile always holds a valid sample: the y stores are issued)
+            else st.template tile_barrier<0>();                   // (narrow outputs: conditional stores, count nothing)
         }
         cur ^= 1;
     }

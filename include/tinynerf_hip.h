@@ -219,6 +219,16 @@ typedef struct tn_mlp_desc {
     int64_t grad_x_rows_tile_stride;
 } tn_mlp_desc;
 
+/* One plain Linear (reference src/models.py:183-191: KPlanesExplicitOpacityDecoder.net = torch.nn.Linear(96, 96), the only
+ * Linear on the reference's path outside an MLP stack): y [n, out] = x [n, in] weight^T + bias (bias may be NULL), weight
+ * [out, in] row-major as torch.nn.Linear holds it, 1 <= in, out <= 128, fp32 MFMA. */
+int tn_linear_fwd(const float *x, const float *weight, const float *bias, int64_t n, int32_t in_features,
+                  int32_t out_features, float *y, void *stream);
+/* ... and its backward: grad_x [n, in] = grad_y weight (written; NULL: skipped), grad_weight [out, in] += grad_y^T x and
+ * grad_bias [out] += column sums of grad_y (both ACCUMULATED, as autograd does into .grad; NULL: skipped). */
+int tn_linear_bwd(const float *x, const float *weight, const float *grad_y, int64_t n, int32_t in_features,
+                  int32_t out_features, float *grad_x, float *grad_weight, float *grad_bias, void *stream);
+
 /* Row views into the workspace of tn_mlp_fwd_stash(desc, ..., n) for a layer-by-layer configuration without output
  * activation (the Vanilla 256 x 10 and Cobafa 128 x 6 feature stacks): offsets in floats from the workspace base of
  *   y_rows       y as [feature][32-sample] rows -- valid until this stack's tn_mlp_bwd runs;

@@ -763,3 +763,46 @@ def test_fused_mlp_takes_the_stash_forward_only_while_recording(monkeypatch):
     with torch.no_grad():
         od(y2)
     assert names == ["tn_mlp_fwd"]
+
+
+# ------------------------------------------------------------------ the one plain Linear of the path (models.py:186)
+@pytest.mark.parametrize("n,fin,fout,bias", [(1000, 96, 96, True), (33, 96, 96, True), (4097, 32, 64, False), (777, 50, 7, True),
+                                              (64, 1, 1, True), (100_000, 96, 96, True), (500, 128, 128, True), (0, 96, 96, True)])
+def test_linear_fwd_bwd_vs_torch(n, fin, fout, bias):
+    """tn_linear_fwd / tn_linear_bwd against torch.nn.functional.linear in fp64 on the host: ragged n, widths that are not
+    multiples of 32 (zero padding inside the kernel), no bias, the 128 x 128 limit, the empty batch."""
+    m = models()
+    g = torch.Generator().manual_seed(n + fin)
+    x = torch.randn(n, fin, generator=g)
+    w = torch.randn(fout, fin, generator=g) / fin ** 0.5
+    b = torch.randn(fout, generator=g) if bias else None
+    go = torch.randn(n, fout, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = None if b is None else b.double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(go.double())
+    xt, wt = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    bt = None if b is None else cu(b).requires_grad_(True)
+    y = m.linear(xt, wt, bt)
+    assert y.shape == (n, fout)
+    y.backward(cu(go))
+
+    def close(got, ref, k):       # fp32 accumulation over k terms
+        ref = ref.detach().float().numpy()
+        assert got.shape == ref.shape
+        if ref.size == 0:
+            return
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=0, atol=4e-7 * max(k, 8) ** 0.5 * max(float(np.abs(ref).max()), 1e-30) + 1e-30)
+    close(y, yr, fin)
+    close(xt.grad, xr.grad, fout)
+    close(wt.grad, wr.grad, max(n, 1))
+    if b is not None:
+        close(bt.grad, br.grad, max(n, 1))
+
+
+def test_linear_rejects_wide_layers_and_cpu_tensors():
+    m = models()
+    with pytest.raises(RuntimeError):
+        m.linear(torch.zeros(4, 300, device=DEV), torch.zeros(8, 300, device=DEV))
+    with pytest.raises(RuntimeError):
+        m.linear(torch.zeros(4, 8), torch.zeros(8, 8))

@@ -552,9 +552,49 @@ class KPlanesFeatureField(torch.nn.Module):
         return (sums * coef).sum().to(torch.float32)
 
 
+class _Linear(Function):
+    """y = x W^T + b on the fp32 MFMA (tn_linear_fwd / tn_linear_bwd, csrc/linear.hip) -- torch.nn.functional.linear for
+    the one plain Linear of the reference's path (models.py:186)."""
+
+    @staticmethod
+    def forward(ctx: Any, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:  # type: ignore
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.size(-1)).to(torch.float32).contiguous()
+        w = weight.to(torch.float32).contiguous()
+        b = None if bias is None else bias.to(torch.float32).contiguous()
+        dev = L.require_cuda(x2, w, b)
+        if x2.size(1) != w.size(1):
+            raise ValueError(f"linear: x has {x2.size(1)} features, weight expects {w.size(1)}")
+        y = torch.empty((x2.size(0), w.size(0)), device=dev)
+        L.call("tn_linear_fwd", dev, L.ptr(x2), L.ptr(w), L.ptr(b), C.c_int64(x2.size(0)), C.c_int32(w.size(1)), C.c_int32(w.size(0)), L.ptr(y))
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y.reshape(*lead, w.size(0))
+
+    @staticmethod
+    def backward(ctx: Any, grad_y: torch.Tensor):  # type: ignore
+        x2, w = ctx.saved_tensors
+        dev = x2.device
+        gy = grad_y.reshape(-1, w.size(0)).to(torch.float32).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        gb = torch.zeros(w.size(0), device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if gw is None and gb is not None:       # (the kernel reduces the bias beside the weights)
+            gw = torch.zeros_like(w)
+        L.call("tn_linear_bwd", dev, L.ptr(x2), L.ptr(w), L.ptr(gy), C.c_int64(x2.size(0)), C.c_int32(w.size(1)), C.c_int32(w.size(0)),
+               L.ptr(gx), L.ptr(gw), L.ptr(gb))
+        return (None if gx is None else gx.reshape(ctx.x_shape), gw if ctx.needs_input_grad[1] else None, gb)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _Linear.apply(x, weight, bias)
+
+
 class KPlanesExplicitOpacityDecoder(torch.nn.Module):
-    """sigma = exp(<f, W f + b> - 1) (models.py:183-191).  The Linear is a plain library GEMM (rocBLAS through torch); the
-    per-sample dot product and the truncated exponential are one HIP launch (tn_basis_dot_fwd, backward with the clamp)."""
+    """sigma = exp(<f, W f + b> - 1) (models.py:183-191).  The Linear is tn_linear_fwd / _bwd (fp32 MFMA, csrc/linear.hip; the
+    module keeps a torch.nn.Linear for its parameters and state_dict keys); the per-sample dot product and the truncated
+    exponential are one more launch (tn_basis_dot_fwd, backward with the clamp)."""
 
     def __init__(self, feature_dim):
         super().__init__()
@@ -562,7 +602,7 @@ class KPlanesExplicitOpacityDecoder(torch.nn.Module):
         self.activation = lambda x: truncated_exp(x - 1.)
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        return _BasisDot.apply(features, self.net(features), 1, L.ACT_EXP_M1)
+        return _BasisDot.apply(features, linear(features, self.net.weight, self.net.bias), 1, L.ACT_EXP_M1)
 
 
 class KPlanesExplicitColorDecoder(torch.nn.Module):

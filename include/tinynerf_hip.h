@@ -50,6 +50,10 @@ int tn_abi_version(void);
  * ------------------------------------------------------------------------------------------ */
 int tn_weights_fwd(const float *sigmas, const float *steps, const int32_t *info, float threshold,
                    float *weights, int64_t n_samples, int64_t n_rays, void *stream);
+/* tn_weights_fwd that also raises gate[0] to 1.0 when any weight is > 0 (never lowers it: the caller zeroes it).  The
+ * harness' device-side form of the reference's "Empty iteration" test (core.py:251-254: `(weights > 0).any()`). */
+int tn_weights_fwd_gate(const float *sigmas, const float *steps, const int32_t *info, float threshold,
+                        float *weights, float *gate, int64_t n_samples, int64_t n_rays, void *stream);
 int tn_weights_bwd(const float *sigmas, const float *steps, const int32_t *info,
                    const float *weights, const float *grad_weights, float *grad_sigmas,
                    int64_t n_samples, int64_t n_rays, void *stream);
@@ -404,6 +408,14 @@ int tn_ray_aux(const float *packed, const int32_t *info, int64_t n_rays, int32_t
  * sumsq[0] += sum (rendered - target)^2 (fp64, caller zeroes) over n = 3 * rays elements, one pass. */
 int tn_mse_grad(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, float *grad,
                 double *sumsq, void *stream);
+/* tn_mse_grad with the "Empty iteration" gate applied at the source: grad = 0 when !(gate[0] > 0) (core.py:251-254: the
+ * image loss then reaches no parameter); sumsq as in tn_mse_grad. */
+int tn_mse_grad_gated(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev,
+                      const float *gate, float *grad, double *sumsq, void *stream);
+/* The harness' batch draw (run.py:225-229, the DataLoader's index_select): rows idx[i] of the [N, 3] ray tables -> out_* [n, 3]
+ * in one launch; rgbs / out_rgb may be NULL. */
+int tn_gather_rays(const float *rays_o, const float *rays_d, const float *rgbs, const int32_t *idx, int64_t n,
+                   float *out_o, float *out_d, float *out_rgb, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * optimizer step of the harness                        (reference run.py:186,258-260: torch.optim.Adam)

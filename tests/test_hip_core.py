@@ -308,3 +308,40 @@ def test_coarse_reject_leaves_the_mask_unchanged(scene):
             outs.append(prov(o, d, training=True, jitter=jit))
         assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
         assert 0 < outs[0][0].size(0) < 700 * 96
+
+
+# ------------------------------------------------------------------ harness helpers of round 3 (run.Trainer)
+def test_weights_fwd_gate_flag_and_gated_mse_and_ray_gather():
+    """tn_weights_fwd_gate = tn_weights_fwd + a flag raised when any weight is > 0 (never lowered); tn_mse_grad_gated = tn_mse_grad
+    with grad = 0 under a closed gate; tn_gather_rays = three index_selects."""
+    from tinynerf_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    info, n = ragged(rng, 300, 70, 0.1)
+    it = cu(info, torch.int32)
+    steps = torch.full((n,), 0.01, device=DEV)
+    for scale, expect in ((5.0, 1.0), (0.0, 0.0)):                 # sigma = 0 everywhere: every weight is 0, the flag stays down
+        sig = torch.rand(n, device=DEV) * scale
+        w_ref = torch.empty(n, device=DEV); w = torch.empty(n, device=DEV)
+        gate = torch.zeros(1, device=DEV)
+        L.call("tn_weights_fwd", torch.device(DEV), L.ptr(sig), L.ptr(steps), L.ptr(it), C.c_float(1e-4), L.ptr(w_ref), C.c_int64(n), C.c_int64(info.shape[0]))
+        L.call("tn_weights_fwd_gate", torch.device(DEV), L.ptr(sig), L.ptr(steps), L.ptr(it), C.c_float(1e-4), L.ptr(w), L.ptr(gate), C.c_int64(n),
+               C.c_int64(info.shape[0]))
+        assert torch.equal(w, w_ref) and float(gate.item()) == expect
+        assert bool((w_ref > 0).any()) == bool(expect)
+        # gated loss gradient
+        r, t = torch.rand(1000, 3, device=DEV), torch.rand(1000, 3, device=DEV)
+        g0, g1 = torch.empty_like(r), torch.empty_like(r)
+        a0, a1 = torch.zeros(1, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.float64, device=DEV)
+        L.call("tn_mse_grad", torch.device(DEV), L.ptr(r), L.ptr(t), C.c_int64(3000), C.c_float(0.25), C.c_void_p(None), L.ptr(g0), L.ptr(a0))
+        L.call("tn_mse_grad_gated", torch.device(DEV), L.ptr(r), L.ptr(t), C.c_int64(3000), C.c_float(0.25), C.c_void_p(None), L.ptr(gate), L.ptr(g1), L.ptr(a1))
+        assert torch.equal(g1, g0 * expect) and torch.equal(a0, a1)
+    N = 5000
+    o, d, c = torch.rand(N, 3, device=DEV), torch.rand(N, 3, device=DEV), torch.rand(N, 3, device=DEV)
+    idx = torch.randint(0, N, (1234,), device=DEV, dtype=torch.int32)
+    oo, od, oc = (torch.empty(1234, 3, device=DEV) for _ in range(3))
+    L.call("tn_gather_rays", torch.device(DEV), L.ptr(o), L.ptr(d), L.ptr(c), L.ptr(idx), C.c_int64(1234), L.ptr(oo), L.ptr(od), L.ptr(oc))
+    assert torch.equal(oo, o[idx.long()]) and torch.equal(od, d[idx.long()]) and torch.equal(oc, c[idx.long()])
+    oc.fill_(-1.0)
+    L.call("tn_gather_rays", torch.device(DEV), L.ptr(o), L.ptr(d), C.c_void_p(None), L.ptr(idx), C.c_int64(1234), L.ptr(oo), L.ptr(od), C.c_void_p(None))
+    assert torch.equal(oo, o[idx.long()]) and bool((oc == -1).all())

@@ -454,11 +454,11 @@ class NerfRenderer(torch.nn.Module):
             weights: torch.Tensor = NerfWeights.apply(sigmas, packed_samples[:, 6], packing_info, early_termination_threshold)  # type: ignore
             active = torch.nonzero(weights > 0.).squeeze(1)       # host sync, like `mask.any()` in the reference
             empty = active.numel() == 0
-            self.__dict__.setdefault("_stats", {})["gate"] = weights.detach().amax().reshape(1)
+            self.__dict__.setdefault("_stats", {}).update(gate=weights.detach().amax().reshape(1), pre_gated=False)
         if empty:
             # core.py:251-254: every sample masked -> background only, gradients are zero
             print("Empty iteration, every sample is masked")
-            self.__dict__.setdefault("_stats", {})["gate"] = torch.zeros(1, device=device)
+            self.__dict__.setdefault("_stats", {}).update(gate=torch.zeros(1, device=device), pre_gated=False)
             rgbs = torch.zeros((n_samples, 3), device=device, requires_grad=True)
             weights = torch.zeros(n_samples, device=device, requires_grad=True)
         else:

@@ -38,7 +38,7 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
     const float *__restrict__ sigmas, const float *__restrict__ steps, const int32_t *__restrict__ info,
-    float threshold, float *__restrict__ weights, int64_t n_rays)
+    float threshold, float *__restrict__ weights, int64_t n_rays, float *__restrict__ gate)
 {
     const int lane = tn::lane_id();
     const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
     const int start = sc.x, count = sc.y;
     float carry = 1.0f;          // transmittance entering the chunk
     bool alive = true;           // wave-uniform: no lane has terminated yet
+    bool positive = false;       // this lane has written a weight > 0
     for (int base = 0; base < count; base += 64) {
         const int k = base + lane;
         const bool valid = k < count;
@@ -66,7 +67,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
             alive = dead == 0;
         }
         if (valid) weights[start + k] = w;
+        positive = positive || w > 0.0f;
     }
+    // "Empty iteration" flag of the harness (core.py:251-254): raised by every ray that has a weight > 0.  All writers store the
+    // same value, so plain stores do (no atomic: 22 000 waves on one address); once it is up the rest only read it.
+    if (gate != nullptr && __ballot(positive) != 0 && lane == 0 && gate[0] == 0.0f) gate[0] = 1.0f;
 }
 
 // Single pass over HBM for rays of up to 64*MAXC samples: w*g and alpha stay in registers
@@ -185,9 +190,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void composite_bwd_kernel(
 
 // d/d rendered of  c * sum (rendered - target)^2  and the sum itself (fp64 accumulator), one pass (run.py:252,259)
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float *__restrict__ r, const float *__restrict__ t, int64_t n, float cg,
-                                                       const float *__restrict__ cg_dev, float *__restrict__ grad, double *__restrict__ sumsq)
+                                                       const float *__restrict__ cg_dev, float *__restrict__ grad, double *__restrict__ sumsq,
+                                                       const float *__restrict__ gate)
 {
-    const float c = cg_dev ? cg * cg_dev[0] : cg;
+    float c = cg_dev ? cg * cg_dev[0] : cg;
+    if (gate != nullptr && !(gate[0] > 0.0f)) c = 0.0f;     // "Empty iteration": the image loss reaches no parameter
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float d = r[i] - t[i];
@@ -233,7 +240,19 @@ extern "C" int tn_weights_fwd(const float *sigmas, const float *steps, const int
     TN_REQUIRE(sigmas && steps && info && weights, TN_E_NULL, "tn_weights_fwd: null pointer");
     TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_weights_fwd: info must be 8-byte aligned");
     hipLaunchKernelGGL(weights_fwd_kernel, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
-                       sigmas, steps, info, threshold, weights, n_rays);
+                       sigmas, steps, info, threshold, weights, n_rays, (float *)nullptr);
+    return tn::check_launch("weights_fwd_kernel");
+}
+
+extern "C" int tn_weights_fwd_gate(const float *sigmas, const float *steps, const int32_t *info, float threshold, float *weights,
+                                   float *gate, int64_t n_samples, int64_t n_rays, void *stream)
+{
+    TN_REQUIRE(n_samples >= 0 && n_rays >= 0, TN_E_SIZE, "tn_weights_fwd_gate: negative size");
+    if (n_rays == 0 || n_samples == 0) return TN_OK;
+    TN_REQUIRE(sigmas && steps && info && weights && gate, TN_E_NULL, "tn_weights_fwd_gate: null pointer");
+    TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_weights_fwd_gate: info must be 8-byte aligned");
+    hipLaunchKernelGGL(weights_fwd_kernel, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
+                       sigmas, steps, info, threshold, weights, n_rays, gate);
     return tn::check_launch("weights_fwd_kernel");
 }
 
@@ -279,8 +298,43 @@ extern "C" int tn_mse_grad(const float *rendered, const float *target, int64_t n
     if (n == 0) return TN_OK;
     TN_REQUIRE(rendered && target && grad && sumsq, TN_E_NULL, "tn_mse_grad: null pointer");
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 512);
-    mse_grad_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(rendered, target, n, scale, scale_dev, grad, sumsq);
+    mse_grad_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(rendered, target, n, scale, scale_dev, grad, sumsq, nullptr);
     return tn::check_launch("mse_grad_kernel");
+}
+
+extern "C" int tn_mse_grad_gated(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, const float *gate,
+                                 float *grad, double *sumsq, void *stream)
+{
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mse_grad_gated: negative size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(rendered && target && grad && sumsq && gate, TN_E_NULL, "tn_mse_grad_gated: null pointer");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 512);
+    mse_grad_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(rendered, target, n, scale, scale_dev, grad, sumsq, gate);
+    return tn::check_launch("mse_grad_kernel");
+}
+
+// rows idx[i] of three [N, 3] ray tables in one launch (the harness' batch draw: origins, directions, target colours)
+__global__ __launch_bounds__(256) void gather_rays_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
+                                                          const int32_t *__restrict__ idx, int64_t n, float *__restrict__ oa,
+                                                          float *__restrict__ ob, float *__restrict__ oc)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element of the [n, 3] outputs
+    if (e >= 3 * n) return;
+    const int64_t r = e / 3;
+    const int64_t src = (int64_t)idx[r] * 3 + (e - 3 * r);
+    oa[e] = a[src];
+    ob[e] = b[src];
+    if (c != nullptr) oc[e] = c[src];
+}
+
+extern "C" int tn_gather_rays(const float *rays_o, const float *rays_d, const float *rgbs, const int32_t *idx, int64_t n, float *out_o,
+                              float *out_d, float *out_rgb, void *stream)
+{
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_gather_rays: negative size");
+    if (n == 0) return TN_OK;
+    TN_REQUIRE(rays_o && rays_d && idx && out_o && out_d && (!rgbs || out_rgb), TN_E_NULL, "tn_gather_rays: null pointer");
+    gather_rays_kernel<<<dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(rays_o, rays_d, rgbs, idx, n, out_o, out_d, out_rgb);
+    return tn::check_launch("gather_rays_kernel");
 }
 
 extern "C" int tn_ray_aux(const float *packed, const int32_t *info, int64_t n_rays, int32_t *ray_ids, float *steps, float *dirs,

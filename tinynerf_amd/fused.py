@@ -110,8 +110,15 @@ class _RenderKPlanes(Function):
         covered = hint is not None and hint.get("key") == (packed.data_ptr(), n, R)     # the trainer's sampler covers every sample
         if not covered:
             weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
-        L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
-               C.c_int64(n), C.c_int64(R))
+        # harness: a zeroed [1] slot that the weights kernel raises when any weight is > 0 (instead of a reduction launch), and an
+        # upstream gradient that arrives gated (tn_mse_grad_gated) -- see the "Empty iteration" note below
+        gate_slot = hint.get("gate") if (covered and train and hint is not None) else None
+        if gate_slot is not None:
+            L.call("tn_weights_fwd_gate", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), L.ptr(gate_slot),
+                   C.c_int64(n), C.c_int64(R))
+        else:
+            L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
+                   C.c_int64(n), C.c_int64(R))
         if pair:
             pass
         elif ws_r is not None:
@@ -128,9 +135,11 @@ class _RenderKPlanes(Function):
         # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer all-reduces it in place right after this forward
         # (run.Trainer.step_on_batch) -- the single-GPU step on the union of the ranks' rays is only "empty" when every
         # rank's is -- so the backward below already reads the all-rank value)
-        ctx.gate = weights.amax().reshape(1) if train else None
+        ctx.pre_gated = gate_slot is not None
+        ctx.gate = gate_slot if gate_slot is not None else (weights.amax().reshape(1) if train else None)
         if stats is not None:
             stats["gate"] = ctx.gate
+            stats["pre_gated"] = ctx.pre_gated
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
@@ -149,7 +158,7 @@ class _RenderKPlanes(Function):
         n, R = packed.size(0), info.size(0)
         F = feat.size(1)
         g_out = grad_out.contiguous()
-        if ctx.gate is not None:
+        if ctx.gate is not None and not ctx.pre_gated:
             g_out = g_out * (ctx.gate > 0).to(g_out.dtype)       # "Empty iteration": zero gradients, as on the module-by-module path
 
         def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
@@ -171,7 +180,9 @@ class _RenderKPlanes(Function):
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
                L.ptr(g_w), C.c_int64(n), C.c_int64(R))
         # weights -> sigma (needs only the composite's gradient, not the colour head's)
-        g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
+        g_sigma = _alloc(arena, "g_sigma", (n,), dev)
+        if not covered:              # (tn_weights_bwd writes every sample a ray owns)
+            g_sigma.zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
         g_feat = _alloc(arena, "g_feat", (n, F), dev)
@@ -301,7 +312,12 @@ class _RenderHeads(Function):
         covered = hint is not None and hint.get("key") == (packed.data_ptr(), n, R)
         if not covered:
             weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
-        L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), C.c_int64(n), C.c_int64(R))
+        gate_slot = hint.get("gate") if (covered and train and hint is not None) else None       # (see _RenderKPlanes)
+        if gate_slot is not None:
+            L.call("tn_weights_fwd_gate", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), L.ptr(gate_slot),
+                   C.c_int64(n), C.c_int64(R))
+        else:
+            L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), C.c_int64(n), C.c_int64(R))
         if train:
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
         else:              # inference: the colour head is only evaluated where the weight is not 0 (core.py:246-251), tile-wise
@@ -311,9 +327,11 @@ class _RenderHeads(Function):
         out = torch.empty((R, 3), device=dev)
         L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                C.c_int64(n), C.c_int64(R))
-        ctx.gate = weights.amax().reshape(1) if train else None       # "Empty iteration" (core.py:251-254), see _RenderKPlanes
+        ctx.pre_gated = gate_slot is not None
+        ctx.gate = gate_slot if gate_slot is not None else (weights.amax().reshape(1) if train else None)   # "Empty iteration", see _RenderKPlanes
         if stats is not None:
             stats["gate"] = ctx.gate
+            stats["pre_gated"] = ctx.pre_gated
         ctx.save_for_backward(feat, info, bg, freqs, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
@@ -329,7 +347,7 @@ class _RenderHeads(Function):
         dev = feat.device
         n, R, F = feat.size(0), info.size(0), feat.size(1)
         g_out = grad_out.contiguous()
-        if ctx.gate is not None:
+        if ctx.gate is not None and not ctx.pre_gated:
             g_out = g_out * (ctx.gate > 0).to(g_out.dtype)
         refs: Sequence[Optional[torch.Tensor]] = ctx.param_refs if ctx.param_refs is not None else [None] * len(params)
 
@@ -347,7 +365,9 @@ class _RenderHeads(Function):
             g_rgbs.zero_(); g_w.zero_()
         L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs), L.ptr(g_w),
                C.c_int64(n), C.c_int64(R))
-        g_sigma = _alloc(arena, "g_sigma", (n,), dev).zero_()
+        g_sigma = _alloc(arena, "g_sigma", (n,), dev)
+        if not covered:              # (tn_weights_bwd writes every sample a ray owns)
+            g_sigma.zero_()
         L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
                C.c_int64(n), C.c_int64(R))
         link = ctx.link

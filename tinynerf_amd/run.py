@@ -141,6 +141,7 @@ class Trainer:
             self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
+        self._gate_ring = torch.zeros(256, device=device)
         self.prefetch = True
 
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -199,21 +200,27 @@ class Trainer:
         # candidate block: the rule trips after k loader batches and k drifts by a batch or two between steps; a block that
         # turns out too small is redrawn at twice the size (build_batch), so the margin only has to cover the drift
         n_b = n_b or min(4096, max(2, int(self._k_guess * 1.12) + 3))
+        R_all = n_b * B
         if cfg.deterministic:
-            idx = (self._cursor + torch.arange(n_b * B, device=dev)) % self.rays_o.size(0)
+            idx = ((self._cursor + torch.arange(R_all, device=dev)) % self.rays_o.size(0)).to(torch.int32)
         else:
-            idx = self._epoch_block(n_b * B).long()
-        o, d = self.rays_o[idx], self.rays_d[idx]
+            idx = self._epoch_block(R_all)                     # int32
+        # origins, directions and target colours of the candidate rays in one launch (three index kernels + an index cast
+        # before); two buffers in turn: the previous step's backward pass still reads its own directions and targets
+        self._info_turn ^= 1
+        o = self._buf(f"cand_o{self._info_turn}", (R_all, 3), torch.float32)
+        d = self._buf(f"cand_d{self._info_turn}", (R_all, 3), torch.float32)
+        rgb = self._buf(f"cand_rgb{self._info_turn}", (R_all, 3), torch.float32)
+        L.call("tn_gather_rays", dev, L.ptr(self.rays_o), L.ptr(self.rays_d), L.ptr(self.rgbs), L.ptr(idx), C.c_int64(R_all), L.ptr(o), L.ptr(d),
+               L.ptr(rgb))
         desc = self.ray_provider._desc(dev, not cfg.deterministic, None)
         desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
-        R_all = n_b * B
         maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
         counts = self._buf("counts", (R_all,), torch.int32)
         plan = self._buf("plan", (4,), torch.int32)
         # (offset, count) of EVERY candidate ray, in the same launch as the rule (the scan of a prefix does not depend on where the
         # rule cuts): behind the read-back only the pack is left.  Two buffers in turn: this runs during the previous step, whose
         # backward pass still reads its own info.
-        self._info_turn ^= 1
         info = self._buf(f"info{self._info_turn}", (R_all, 2), torch.int32)
         L.call("tn_sample_mask", dev, C.byref(desc), L.ptr(o), L.ptr(d), C.c_int64(R_all), L.ptr(maskbits), L.ptr(counts))
         L.call("tn_batch_plan_scan", dev, L.ptr(counts), C.c_int64(R_all), C.c_int32(B), C.c_int64(self.target_sample_size), L.ptr(plan),
@@ -223,7 +230,7 @@ class Trainer:
             self._plan_event = torch.cuda.Event()
         self._plan_host.copy_(plan, non_blocking=True)
         self._plan_event.record(torch.cuda.current_stream(dev))
-        self._pending = dict(n_b=n_b, idx=idx, o=o, d=d, desc=desc, maskbits=maskbits, counts=counts, info=info)
+        self._pending = dict(n_b=n_b, idx=idx, o=o, d=d, rgb=rgb, desc=desc, maskbits=maskbits, counts=counts, info=info)
 
     @torch.no_grad()
     def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
@@ -250,9 +257,13 @@ class Trainer:
         L.call("tn_sample_pack", dev, C.byref(pend["desc"]), L.ptr(pend["o"]), L.ptr(pend["d"]), C.c_int64(R), L.ptr(pend["maskbits"]),
                L.ptr(info), C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), L.ptr(steps), C.c_int64(n))
         # what the fused render node would otherwise rebuild from (packed, info): ray id and step of every sample, ray directions
+        # "Empty iteration" flag of this step: one slot of a ring that is zeroed once per lap (the weights kernel only raises it)
+        slot = self.train_step % self._gate_ring.numel()
+        if slot == 0 and self.train_step > 0:
+            self._gate_ring.zero_()
         self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R],
-                                    "planes_ready": self._planes_ready if self.world > 1 else None}
-        return packed, info, self.rgbs[pend["idx"][:R]], k
+                                    "planes_ready": self._planes_ready if self.world > 1 else None, "gate": self._gate_ring[slot:slot + 1]}
+        return packed, info, pend["rgb"][:R], k
 
     # ------------------------------------------------------------------ one optimizer step
     def sigma_fn(self, t: torch.Tensor) -> torch.Tensor:
@@ -305,8 +316,13 @@ class Trainer:
             if gate_done is not None:
                 gate_done.wait()
             inv, inv_dev = 1.0, (1.0 / (3.0 * ray_count)).float()
-        L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
-               L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
+        if gate is not None and getattr(self.renderer, "_stats", {}).get("pre_gated"):
+            # the render node expects its upstream gradient gated (it raised the flag inside the weights kernel)
+            L.call("tn_mse_grad_gated", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
+                   L.ptr(inv_dev), L.ptr(gate), L.ptr(grad), L.ptr(acc))
+        else:
+            L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
+                   L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
         rendered.backward(grad)
         reg_coef, plane_reg = None, None
         if cfg.method == "kplanes":                                               # run.py:254-256

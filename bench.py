@@ -481,7 +481,9 @@ def main():
             if not mfma or tag not in MFMA_KERNELS:
                 return None
             busy = act = 0.0
-            for k, v in mfma["per_kernel"].items():
+            for k, v in mfma.get("per_kernel", mfma).items():     # (either the wrapped or the raw output of scripts/pmc_mfma.sh)
+                if not isinstance(v, dict):
+                    continue
                 if any(k.startswith(pref) for pref in MFMA_KERNELS[tag]):
                     busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
                     act += v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 1024.0
@@ -491,7 +493,7 @@ def main():
             bound, unit_work, unit, kernels = KERNEL_MODEL[tag]
             k = ks[tag]
             sec = k["avg_ms"] * 1e-3
-            traffic = pmc["per_entry"].get(tag) if pmc else None
+            traffic = pmc.get("per_entry", {}).get(tag) if pmc else None
             r = {"kernel": tag, "kernels": kernels, "avg_launch_ms": k["avg_ms"], "ms_per_step": k["total_ms"] / args.steps,
                  "rows_per_launch": k["avg_rows"], "row": unit, "algorithmic_per_row": unit_work, "traffic": traffic,
                  "traffic_source": PMC_PROFILE if traffic is not None else None}
@@ -502,7 +504,7 @@ def main():
                 gbs = unit_work * k["avg_rows"] / sec / 1e9
                 r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS)
             else:       # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
-                lanes = pmc["lane_atomics_per_entry"].get(tag) if pmc else None
+                lanes = pmc.get("lane_atomics_per_entry", {}).get(tag) if pmc else None
                 ach = lanes / sec / 1e9 if lanes else None
                 # the contract's two rooflines first (this launch also carries both heads' data-gradient MFMAs: bound "mfma" with
                 # the algorithmic FLOP), then what actually limits it: the chip's memory-side atomic rate
@@ -518,7 +520,10 @@ def main():
                                            "scripts/microbench/atomic_patterns.hip; this is the limit the launch runs at"})
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
-            busy = mfma_busy_of(tag)
+            try:
+                busy = mfma_busy_of(tag)
+            except Exception:        # noqa: BLE001 -- an odd profile file must not cost the bench line
+                busy = None
             if busy is not None:
                 r["mfma_busy"] = {"frac": busy, "source": MFMA_PROFILE,
                                   "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the same kernels (profiled pass: "

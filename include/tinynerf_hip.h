@@ -408,6 +408,15 @@ int tn_ray_aux(const float *packed, const int32_t *info, int64_t n_rays, int32_t
  * sumsq[0] += sum (rendered - target)^2 (fp64, caller zeroes) over n = 3 * rays elements, one pass. */
 int tn_mse_grad(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev, float *grad,
                 double *sumsq, void *stream);
+/* a17 + a18 of one batch as ONE launch each way (a wave per ray does both): tn_weights_fwd(_gate) + tn_composite_fwd -> weights
+ * and rendered (bit-identical to the two calls; gate may be NULL), and tn_composite_bwd + tn_weights_bwd -> grad_rgbs and
+ * grad_sigmas without the grad_weights round trip (reference cuda.cu:3-58 + core.py:256-265 and their autograd). */
+int tn_render_rays_fwd(const float *sigmas, const float *steps, const float *rgbs, const int32_t *info, const float *bg,
+                       float threshold, float *weights, float *rendered, float *gate, int64_t n_samples, int64_t n_rays,
+                       void *stream);
+int tn_render_rays_bwd(const float *sigmas, const float *steps, const float *rgbs, const int32_t *info, const float *bg,
+                       const float *weights, const float *grad_rendered, float *grad_rgbs, float *grad_sigmas,
+                       int64_t n_samples, int64_t n_rays, void *stream);
 /* tn_mse_grad with the "Empty iteration" gate applied at the source: grad = 0 when !(gate[0] > 0) (core.py:251-254: the
  * image loss then reaches no parameter); sumsq as in tn_mse_grad. */
 int tn_mse_grad_gated(const float *rendered, const float *target, int64_t n, float scale, const float *scale_dev,

@@ -335,7 +335,8 @@ def test_weights_fwd_gate_flag_and_gated_mse_and_ray_gather():
         a0, a1 = torch.zeros(1, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.float64, device=DEV)
         L.call("tn_mse_grad", torch.device(DEV), L.ptr(r), L.ptr(t), C.c_int64(3000), C.c_float(0.25), C.c_void_p(None), L.ptr(g0), L.ptr(a0))
         L.call("tn_mse_grad_gated", torch.device(DEV), L.ptr(r), L.ptr(t), C.c_int64(3000), C.c_float(0.25), C.c_void_p(None), L.ptr(gate), L.ptr(g1), L.ptr(a1))
-        assert torch.equal(g1, g0 * expect) and torch.equal(a0, a1)
+        assert torch.equal(g1, g0 * expect)
+        assert abs(float(a0.item()) - float(a1.item())) <= 1e-12 * float(a0.item())      # (fp64 atomics: the order of the blocks is free)
     N = 5000
     o, d, c = torch.rand(N, 3, device=DEV), torch.rand(N, 3, device=DEV), torch.rand(N, 3, device=DEV)
     idx = torch.randint(0, N, (1234,), device=DEV, dtype=torch.int32)
@@ -345,3 +346,37 @@ def test_weights_fwd_gate_flag_and_gated_mse_and_ray_gather():
     oc.fill_(-1.0)
     L.call("tn_gather_rays", torch.device(DEV), L.ptr(o), L.ptr(d), C.c_void_p(None), L.ptr(idx), C.c_int64(1234), L.ptr(oo), L.ptr(od), C.c_void_p(None))
     assert torch.equal(oo, o[idx.long()]) and bool((oc == -1).all())
+
+
+def test_render_rays_fused_equals_two_launches():
+    """tn_render_rays_fwd / _bwd (a wave per ray does weights AND composite) against the separate entry points: same weights,
+    bit-identical rendered colours, same gradients (the fused backward forms d loss / d weights in registers)."""
+    from tinynerf_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    dev = torch.device(DEV)
+    for (n_rays, max_len, use_bg) in ((500, 90, True), (64, 1500, False), (3, 5, True)):
+        info, n = ragged(rng, n_rays, max_len, 0.1)
+        it = cu(info, torch.int32)
+        sig = torch.rand(n, device=DEV) * 30; sig[torch.rand(n, device=DEV) < 0.2] = 0
+        steps = torch.rand(n, device=DEV) * 0.02 + 0.001
+        rgbs = torch.rand(n, 3, device=DEV)
+        bg = torch.tensor([1.0, 0.5, 0.25], device=DEV) if use_bg else None
+        R = info.shape[0]
+        w0, w1 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        o0, o1 = torch.empty(R, 3, device=DEV), torch.empty(R, 3, device=DEV)
+        gate = torch.zeros(1, device=DEV)
+        L.call("tn_weights_fwd", dev, L.ptr(sig), L.ptr(steps), L.ptr(it), C.c_float(1e-3), L.ptr(w0), C.c_int64(n), C.c_int64(R))
+        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(w0), L.ptr(it), L.ptr(bg), L.ptr(o0), C.c_void_p(None), C.c_int64(n), C.c_int64(R))
+        L.call("tn_render_rays_fwd", dev, L.ptr(sig), L.ptr(steps), L.ptr(rgbs), L.ptr(it), L.ptr(bg), C.c_float(1e-3), L.ptr(w1), L.ptr(o1), L.ptr(gate),
+               C.c_int64(n), C.c_int64(R))
+        assert torch.equal(w0, w1) and torch.equal(o0, o1) and float(gate.item()) == 1.0
+        go = torch.randn(R, 3, device=DEV)
+        gr0, gw0, gs0 = torch.zeros(n, 3, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        gr1, gs1 = torch.zeros(n, 3, device=DEV), torch.zeros(n, device=DEV)
+        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(w0), L.ptr(it), L.ptr(bg), L.ptr(go), L.ptr(gr0), L.ptr(gw0), C.c_int64(n), C.c_int64(R))
+        L.call("tn_weights_bwd", dev, L.ptr(sig), L.ptr(steps), L.ptr(it), L.ptr(w0), L.ptr(gw0), L.ptr(gs0), C.c_int64(n), C.c_int64(R))
+        L.call("tn_render_rays_bwd", dev, L.ptr(sig), L.ptr(steps), L.ptr(rgbs), L.ptr(it), L.ptr(bg), L.ptr(w0), L.ptr(go), L.ptr(gr1), L.ptr(gs1),
+               C.c_int64(n), C.c_int64(R))
+        assert torch.equal(gr0, gr1)
+        np.testing.assert_allclose(gs1.cpu().numpy(), gs0.cpu().numpy(), rtol=0, atol=1e-6 * max(float(gs0.abs().max()), 1e-30))

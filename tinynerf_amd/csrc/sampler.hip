@@ -19,6 +19,7 @@
 // differences, taps accumulated tnw,tne,tsw,tse,bnw,bne,bsw,bse with one rounded multiply and
 // one rounded add each.
 #include "tn_common.h"
+#include <math.h>
 
 namespace {
 
@@ -33,7 +34,9 @@ struct SamplerArgs {
     uint64_t seed;
     int use_rng;
     const float *coarse;      // block maxima (4^3 voxels + 1 halo) or nullptr
-};
+    float inv_ext[3];         // pow2: 1 / (hi - lo) per axis, exact
+    int pow2;                 // every box extent is a power of two: x / ext == x * inv_ext bit for bit (both are the correctly
+};                            // rounded value of the same real number), and the 12-instruction IEEE division drops out
 
 // ATen grid_sampler_3d forward for one point (bilinear, zeros padding, align_corners=True)
 __device__ __forceinline__ float trilinear(const float *__restrict__ grid, int D, int H, int W,
@@ -123,7 +126,8 @@ __device__ __forceinline__ bool contract(const SamplerArgs &a, const float p[3],
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             inside = inside && (p[i] >= a.lo[i]) && (p[i] <= a.hi[i]);
-            c[i] = (p[i] - a.lo[i]) / (a.hi[i] - a.lo[i]) * 2.0f - 1.0f;
+            if (a.pow2) c[i] = ((p[i] - a.lo[i]) * a.inv_ext[i]) * 2.0f - 1.0f;     // (wave-uniform branch)
+            else c[i] = (p[i] - a.lo[i]) / (a.hi[i] - a.lo[i]) * 2.0f - 1.0f;
         }
     } else {                                                // core.py:18-19
         float n;
@@ -533,6 +537,14 @@ int make_args(const tn_sampler_desc *d, SamplerArgs &a, bool need_grid = true)
     a.near = d->near; a.far = d->far; a.step = d->step_size; a.threshold = d->threshold;
     a.t_table = d->t_table; a.delta_table = d->delta_table; a.grid = d->grid; a.jitter = d->jitter;
     a.seed = d->seed; a.use_rng = d->use_rng; a.coarse = d->coarse;
+    a.pow2 = 1;
+    for (int i = 0; i < 3; ++i) {
+        const volatile float ext = a.hi[i] - a.lo[i];            // the device's fp32 subtraction
+        int e = 0;
+        const float m = frexpf(ext, &e);
+        a.inv_ext[i] = 1.0f / ext;
+        if (!(m == 0.5f && e > -100 && e < 100)) a.pow2 = 0;     // (also rejects 0, negatives, inf, NaN)
+    }
     return TN_OK;
 }
 

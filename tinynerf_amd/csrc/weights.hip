@@ -36,10 +36,15 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
     return v;
 }
 
+// COMP: the ray's composite (core.py:256-265, composite_fwd_kernel below) in the same pass -- the same per-lane partial sums
+// in the same order, so `rendered` is bit-identical to the two-launch form.
+template <bool COMP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
     const float *__restrict__ sigmas, const float *__restrict__ steps, const int32_t *__restrict__ info,
-    float threshold, float *__restrict__ weights, int64_t n_rays, float *__restrict__ gate)
+    float threshold, float *__restrict__ weights, int64_t n_rays, float *__restrict__ gate,
+    const float *__restrict__ rgbs = nullptr, const float *__restrict__ bg = nullptr, float *__restrict__ rendered = nullptr)
 {
+    float cr = 0.f, cg = 0.f, cb = 0.f, co = 0.f;
     const int lane = tn::lane_id();
     const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -68,6 +73,22 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
         }
         if (valid) weights[start + k] = w;
         positive = positive || w > 0.0f;
+        if constexpr (COMP) {
+            if (valid) {
+                if (w != 0.0f) {     // masked samples carry rgb = 0 in the reference (core.py:248-250)
+                    const float *c = rgbs + 3 * (int64_t)(start + k);
+                    cr += c[0] * w; cg += c[1] * w; cb += c[2] * w;
+                }
+                co += w;
+            }
+        }
+    }
+    if constexpr (COMP) {
+        cr = tn::wave_sum(cr); cg = tn::wave_sum(cg); cb = tn::wave_sum(cb); co = tn::wave_sum(co);
+        if (lane == 0) {
+            if (bg) { cr += bg[0] * (1.f - co); cg += bg[1] * (1.f - co); cb += bg[2] * (1.f - co); }
+            rendered[3 * ray + 0] = cr; rendered[3 * ray + 1] = cg; rendered[3 * ray + 2] = cb;
+        }
     }
     // "Empty iteration" flag of the harness (core.py:251-254): raised by every ray that has a weight > 0.  All writers store the
     // same value, so plain stores do (no atomic: 22 000 waves on one address); once it is up the rest only read it.
@@ -76,17 +97,36 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_fwd_kernel(
 
 // Single pass over HBM for rays of up to 64*MAXC samples: w*g and alpha stay in registers
 // between the reduction (pass 1 of cuda.cu:51) and the prefix sweep (pass 2, cuda.cu:52-56).
-template <int MAXC>
+// COMP: d loss / d weights is not read but formed here from the composite's upstream gradient (composite_bwd_kernel below: <rgb, g>
+// - <bg, g>, and grad_rgbs = w g written on the way) -- the same arithmetic, one launch and no grad_weights round trip.
+template <int MAXC, bool COMP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_bwd_kernel(
     const float *__restrict__ sigmas, const float *__restrict__ steps, const int32_t *__restrict__ info,
     const float *__restrict__ weights, const float *__restrict__ grad_w, float *__restrict__ grad_sigmas,
-    int64_t n_rays)
+    int64_t n_rays, const float *__restrict__ rgbs = nullptr, const float *__restrict__ bg = nullptr,
+    const float *__restrict__ grad_rendered = nullptr, float *__restrict__ grad_rgbs = nullptr)
 {
     const int lane = tn::lane_id();
     const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     const int2 sc = reinterpret_cast<const int2 *>(info)[ray];
     const int start = sc.x, count = sc.y;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gbg = 0.f;
+    if constexpr (COMP) {
+        g0 = grad_rendered[3 * ray]; g1 = grad_rendered[3 * ray + 1]; g2 = grad_rendered[3 * ray + 2];
+        gbg = bg ? (bg[0] * g0 + bg[1] * g1 + bg[2] * g2) : 0.f;
+    }
+    // upstream gradient of sample i's weight (w = its weight)
+    auto grad_weight = [&](int64_t i, float w) -> float {
+        if constexpr (COMP) {
+            grad_rgbs[3 * i] = w * g0; grad_rgbs[3 * i + 1] = w * g1; grad_rgbs[3 * i + 2] = w * g2;
+            float d = 0.f;
+            if (w != 0.0f) d = rgbs[3 * i] * g0 + rgbs[3 * i + 1] * g1 + rgbs[3 * i + 2] * g2;
+            return d - gbg;
+        } else {
+            return grad_w[i];
+        }
+    };
     if (count <= 64 * MAXC) {
         float wg[MAXC], al[MAXC], dl[MAXC], gg[MAXC];
         float total = 0.0f;
@@ -95,10 +135,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_bwd_kernel(
             const int k = c * 64 + lane;
             wg[c] = 0.f; al[c] = 1.f; dl[c] = 0.f; gg[c] = 0.f;
             if (c * 64 < count && k < count) {
-                const float g = grad_w[start + k];
+                const float w = weights[start + k];
+                const float g = grad_weight(start + k, w);
                 dl[c] = steps[start + k];
                 al[c] = expf(-sigmas[start + k] * dl[c]);
-                wg[c] = weights[start + k] * g;
+                wg[c] = w * g;
                 gg[c] = g;
             }
             total += wg[c];
@@ -118,17 +159,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void weights_bwd_kernel(
         }
     } else {
         float total = 0.0f;
-        for (int k = lane; k < count; k += 64) total += weights[start + k] * grad_w[start + k];
+        for (int k = lane; k < count; k += 64) { const float w = weights[start + k]; total += w * grad_weight(start + k, w); }
         total = tn::wave_sum(total);
         float acc = -total, T = 1.0f;
         for (int base = 0; base < count; base += 64) {
             const int k = base + lane;
             float wgk = 0.f, a = 1.f, d = 0.f, g = 0.f;
             if (k < count) {
-                g = grad_w[start + k];
+                const float w = weights[start + k];
+                g = grad_weight(start + k, w);
                 d = steps[start + k];
                 a = expf(-sigmas[start + k] * d);
-                wgk = weights[start + k] * g;
+                wgk = w * g;
             }
             const float ps = wave_scan_add(wgk, lane);
             const float pt = wave_scan_mul(a, lane);
@@ -239,8 +281,8 @@ extern "C" int tn_weights_fwd(const float *sigmas, const float *steps, const int
     if (n_rays == 0 || n_samples == 0) return TN_OK;
     TN_REQUIRE(sigmas && steps && info && weights, TN_E_NULL, "tn_weights_fwd: null pointer");
     TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_weights_fwd: info must be 8-byte aligned");
-    hipLaunchKernelGGL(weights_fwd_kernel, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
-                       sigmas, steps, info, threshold, weights, n_rays, (float *)nullptr);
+    weights_fwd_kernel<false><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(sigmas, steps, info, threshold,
+                                                                                                                 weights, n_rays, nullptr);
     return tn::check_launch("weights_fwd_kernel");
 }
 
@@ -251,9 +293,35 @@ extern "C" int tn_weights_fwd_gate(const float *sigmas, const float *steps, cons
     if (n_rays == 0 || n_samples == 0) return TN_OK;
     TN_REQUIRE(sigmas && steps && info && weights && gate, TN_E_NULL, "tn_weights_fwd_gate: null pointer");
     TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_weights_fwd_gate: info must be 8-byte aligned");
-    hipLaunchKernelGGL(weights_fwd_kernel, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
-                       sigmas, steps, info, threshold, weights, n_rays, gate);
+    weights_fwd_kernel<false><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(sigmas, steps, info, threshold,
+                                                                                                                 weights, n_rays, gate);
     return tn::check_launch("weights_fwd_kernel");
+}
+
+extern "C" int tn_render_rays_fwd(const float *sigmas, const float *steps, const float *rgbs, const int32_t *info, const float *bg,
+                                  float threshold, float *weights, float *rendered, float *gate, int64_t n_samples, int64_t n_rays,
+                                  void *stream)
+{
+    TN_REQUIRE(n_samples >= 0 && n_rays >= 0, TN_E_SIZE, "tn_render_rays_fwd: negative size");
+    if (n_rays == 0) return TN_OK;
+    TN_REQUIRE(info && weights && rendered && (n_samples == 0 || (sigmas && steps && rgbs)), TN_E_NULL, "tn_render_rays_fwd: null pointer");
+    TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_render_rays_fwd: info must be 8-byte aligned");
+    weights_fwd_kernel<true><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(sigmas, steps, info, threshold,
+                                                                                                                weights, n_rays, gate, rgbs, bg, rendered);
+    return tn::check_launch("weights_fwd_kernel(composite)");
+}
+
+extern "C" int tn_render_rays_bwd(const float *sigmas, const float *steps, const float *rgbs, const int32_t *info, const float *bg,
+                                  const float *weights, const float *grad_rendered, float *grad_rgbs, float *grad_sigmas,
+                                  int64_t n_samples, int64_t n_rays, void *stream)
+{
+    TN_REQUIRE(n_samples >= 0 && n_rays >= 0, TN_E_SIZE, "tn_render_rays_bwd: negative size");
+    if (n_rays == 0 || n_samples == 0) return TN_OK;
+    TN_REQUIRE(sigmas && steps && rgbs && info && weights && grad_rendered && grad_rgbs && grad_sigmas, TN_E_NULL, "tn_render_rays_bwd: null pointer");
+    TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_render_rays_bwd: info must be 8-byte aligned");
+    weights_bwd_kernel<16, true><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(
+        sigmas, steps, info, weights, nullptr, grad_sigmas, n_rays, rgbs, bg, grad_rendered, grad_rgbs);
+    return tn::check_launch("weights_bwd_kernel(composite)");
 }
 
 extern "C" int tn_weights_bwd(const float *sigmas, const float *steps, const int32_t *info, const float *weights,
@@ -263,8 +331,8 @@ extern "C" int tn_weights_bwd(const float *sigmas, const float *steps, const int
     if (n_rays == 0 || n_samples == 0) return TN_OK;
     TN_REQUIRE(sigmas && steps && info && weights && grad_weights && grad_sigmas, TN_E_NULL, "tn_weights_bwd: null pointer");
     TN_REQUIRE(((uintptr_t)info & 7) == 0, TN_E_ALIGN, "tn_weights_bwd: info must be 8-byte aligned");
-    hipLaunchKernelGGL(weights_bwd_kernel<16>, dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream,
-                       sigmas, steps, info, weights, grad_weights, grad_sigmas, n_rays);
+    weights_bwd_kernel<16, false><<<dim3(ray_blocks(n_rays)), dim3(WAVES_PER_BLOCK * 64), 0, (hipStream_t)stream>>>(sigmas, steps, info, weights,
+                                                                                                                     grad_weights, grad_sigmas, n_rays);
     return tn::check_launch("weights_bwd_kernel");
 }
 

@@ -113,7 +113,12 @@ class _RenderKPlanes(Function):
         # harness: a zeroed [1] slot that the weights kernel raises when any weight is > 0 (instead of a reduction launch), and an
         # upstream gradient that arrives gated (tn_mse_grad_gated) -- see the "Empty iteration" note below
         gate_slot = hint.get("gate") if (covered and train and hint is not None) else None
-        if gate_slot is not None:
+        out = torch.empty((R, 3), device=dev)
+        if pair:
+            # both heads are done: weights and composite of a ray in one launch (tn_render_rays_fwd, bit-identical to the two)
+            L.call("tn_render_rays_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(rgbs), L.ptr(info), L.ptr(bg), C.c_float(thr), L.ptr(weights),
+                   L.ptr(out), L.ptr(gate_slot), C.c_int64(n), C.c_int64(R))
+        elif gate_slot is not None:
             L.call("tn_weights_fwd_gate", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), L.ptr(gate_slot),
                    C.c_int64(n), C.c_int64(R))
         else:
@@ -127,9 +132,9 @@ class _RenderKPlanes(Function):
             rdesc.row_gate = weights.data_ptr()
             L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
             rdesc.row_gate = None
-        out = torch.empty((R, 3), device=dev)
-        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
-               C.c_int64(n), C.c_int64(R))
+        if not pair:
+            L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
+                   C.c_int64(n), C.c_int64(R))
         # core.py:246-254: when EVERY sample is masked (w == 0 everywhere) the reference renders the background from constants
         # that carry no graph, i.e. no parameter receives a gradient from the image loss; here the upstream gradient is gated
         # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer all-reduces it in place right after this forward
@@ -174,17 +179,12 @@ class _RenderKPlanes(Function):
 
         arena = ctx.arena
         g_rgbs = _alloc(arena, "g_rgbs", (n, 3), dev)
-        g_w = _alloc(arena, "g_w", (n,), dev)
-        if not covered:              # samples no ray owns: zero gradient, not whatever the arena held
-            g_rgbs.zero_(); g_w.zero_()
-        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs),
-               L.ptr(g_w), C.c_int64(n), C.c_int64(R))
-        # weights -> sigma (needs only the composite's gradient, not the colour head's)
         g_sigma = _alloc(arena, "g_sigma", (n,), dev)
-        if not covered:              # (tn_weights_bwd writes every sample a ray owns)
-            g_sigma.zero_()
-        L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
-               C.c_int64(n), C.c_int64(R))
+        if not covered:              # samples no ray owns: zero gradient, not whatever the arena held (the kernel writes every
+            g_rgbs.zero_(); g_sigma.zero_()      # sample a ray owns)
+        # composite -> (rgbs, weights) and weights -> sigma as one launch per ray (the weights' gradient needs only the composite's)
+        L.call("tn_render_rays_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(rgbs), L.ptr(info), L.ptr(bg), L.ptr(weights), L.ptr(g_out),
+               L.ptr(g_rgbs), L.ptr(g_sigma), C.c_int64(n), C.c_int64(R))
         g_feat = _alloc(arena, "g_feat", (n, F), dev)
         nr, ns = len(rgb_p) // 2, len(sig_p) // 2
         gw_r = (C.c_void_p * nr)(*[g.data_ptr() for g in g_rgb[0::2]])
@@ -313,20 +313,18 @@ class _RenderHeads(Function):
         if not covered:
             weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
         gate_slot = hint.get("gate") if (covered and train and hint is not None) else None       # (see _RenderKPlanes)
-        if gate_slot is not None:
-            L.call("tn_weights_fwd_gate", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), L.ptr(gate_slot),
-                   C.c_int64(n), C.c_int64(R))
-        else:
-            L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), C.c_int64(n), C.c_int64(R))
-        if train:
+        out = torch.empty((R, 3), device=dev)
+        if train:          # the colour head runs on every sample: weights and composite of a ray behind it, in one launch
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
+            L.call("tn_render_rays_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(rgbs), L.ptr(info), L.ptr(bg), C.c_float(thr), L.ptr(weights),
+                   L.ptr(out), L.ptr(gate_slot), C.c_int64(n), C.c_int64(R))
         else:              # inference: the colour head is only evaluated where the weight is not 0 (core.py:246-251), tile-wise
+            L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights), C.c_int64(n), C.c_int64(R))
             rdesc.row_gate = weights.data_ptr()
             L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
             rdesc.row_gate = None
-        out = torch.empty((R, 3), device=dev)
-        L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
-               C.c_int64(n), C.c_int64(R))
+            L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
+                   C.c_int64(n), C.c_int64(R))
         ctx.pre_gated = gate_slot is not None
         ctx.gate = gate_slot if gate_slot is not None else (weights.amax().reshape(1) if train else None)   # "Empty iteration", see _RenderKPlanes
         if stats is not None:
@@ -360,16 +358,11 @@ class _RenderHeads(Function):
         g_rgb = [b[0] for b in bufs[n_sigma:]]
         arena = ctx.arena
         g_rgbs = _alloc(arena, "g_rgbs", (n, 3), dev)
-        g_w = _alloc(arena, "g_w", (n,), dev)
-        if not covered:
-            g_rgbs.zero_(); g_w.zero_()
-        L.call("tn_composite_bwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(g_out), L.ptr(g_rgbs), L.ptr(g_w),
-               C.c_int64(n), C.c_int64(R))
         g_sigma = _alloc(arena, "g_sigma", (n,), dev)
-        if not covered:              # (tn_weights_bwd writes every sample a ray owns)
-            g_sigma.zero_()
-        L.call("tn_weights_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), L.ptr(weights), L.ptr(g_w), L.ptr(g_sigma),
-               C.c_int64(n), C.c_int64(R))
+        if not covered:              # (the kernel writes every sample a ray owns)
+            g_rgbs.zero_(); g_sigma.zero_()
+        L.call("tn_render_rays_bwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(rgbs), L.ptr(info), L.ptr(bg), L.ptr(weights), L.ptr(g_out),
+               L.ptr(g_rgbs), L.ptr(g_sigma), C.c_int64(n), C.c_int64(R))
         link = ctx.link
         # with row views the heads write d loss / d feat straight into the feature stack's workspace (rows) and read feat^T from
         # there for their first layers' weight gradients; autograd gets a placeholder of the right shape (no memory behind it)

@@ -142,6 +142,7 @@ class Trainer:
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
         self._gate_ring = torch.zeros(256, device=device)
+        self._acc_ring = torch.zeros((64, 1 + 32 * 3), dtype=torch.float64, device=device)
         self.prefetch = True
 
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -307,7 +308,11 @@ class Trainer:
         # by hand (4 small kernels instead of ~12 through autograd); the regulariser's value and gradient are one launch.
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
         R = rendered.size(0)
-        acc = self._buf("loss_acc", (1 + 32 * 3,), torch.float64).zero_()          # [0]: sum of squares, [1:]: regulariser sums
+        # [0]: sum of squares, [1:]: regulariser sums -- one row of a ring that is zeroed once per lap (no fill launch per step)
+        row = self.train_step % self._acc_ring.size(0)
+        if row == 0:
+            self._acc_ring.zero_()
+        acc = self._acc_ring[row]
         grad = self._buf("grad_rendered", (R, 3), torch.float32)
         if self.world == 1:
             inv, inv_dev = 1.0 / (3.0 * R), None

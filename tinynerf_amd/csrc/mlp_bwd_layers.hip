@@ -117,7 +117,14 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
             act[ob] = tn::relu16(act[ob]);
             store_rows(st, act[ob], ob, j, h);
         }
-        if constexpr (FIRST_ONLY) continue;        // the remaining layers run as fwd_wreg_kernel launches
+        if constexpr (FIRST_ONLY) {                // the remaining layers run as layer-kernel launches
+            // ReLU bits of this activation where the layer kernels keep them (two rows per 32-feature block), so that the data
+            // gradient of layer 1 can take its mask from 256 B instead of 32 activation rows
+            unsigned *bits = reinterpret_cast<unsigned *>(st + (lay.rowsH + lay.rowsE + 2 * lay.rowsG) * 32);
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) bits[2 * ob * 32 + lane] = relu_bits(act[ob]);
+            continue;
+        }
         for (int l = 1; l + 1 < L; ++l) {
             tn::hidden_layer<H>(a.W[l], a.B[l], H, act, j, h);
 #pragma unroll
@@ -1065,9 +1072,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         DgradArgs d;
         d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
         d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? (l - 1) * H : 0;
-        // ReLU bit rows exist for the activations the layer kernels of the training forward wrote (run_fwd_only): every hidden
-        // one, and the first layer's when it ran as fwd_lds_kernel (positional-encoding inputs)
-        const bool bits = stashed && layer_kernel_path(H, L, a.out_dim) && l >= 1 && (l >= 2 || (a.enc == TN_ENC_POSENC && a.K0_pad <= 64));
+        // ReLU bit rows exist for every activation the training forward of the layer-kernel path wrote (run_fwd_only)
+        const bool bits = stashed && layer_kernel_path(H, L, a.out_dim) && l >= 1;
         d.off_bits = bits ? lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * (l - 1) : -1;
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);

@@ -239,3 +239,50 @@ def test_random_ray_stream_walks_shuffled_epochs():
     for e in range(2):                                                # two full epochs: each a permutation of all rays
         assert torch.equal(torch.sort(seen[e * n:(e + 1) * n]).values, torch.arange(n))
     assert not torch.equal(seen[:n], seen[n:2 * n])                   # reshuffled
+
+
+def test_gate_ring_wraps_and_an_all_masked_step_touches_nothing():
+    """The harness' device-side "Empty iteration" (core.py:251-254 + torch.optim.Adam skipping grad-is-None parameters): the flag lives
+    in a ring slot raised by the weights kernel; across the ring's wrap-around the flag is 1 for ordinary steps, and a step whose
+    samples are ALL masked (termination threshold above 1) leaves the decoders' parameters, Adam moments and step counts bit for
+    bit where they were (the planes still take the regulariser's step, as in the reference), and the next ordinary step moves
+    them again."""
+    import functools
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=256, n_samples=32, seed=2, occupancy_res=32, deterministic=True)
+    tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+    tr._gate_tick = tr._gate_ring.numel() - 2                     # two steps before the wrap
+    for _ in range(4):
+        tr.step()
+        st = tr.renderer._stats
+        assert st["pre_gated"] and float(st["gate"].item()) == 1.0
+    assert tr._gate_tick == tr._gate_ring.numel() + 2 and float(tr._gate_ring.sum().item()) == 2.0    # zeroed at the wrap, two slots raised since
+
+    heads = [(k, p) for k, p in tr.renderer.named_parameters() if not k.startswith("feature_module.")]
+    planes = [(k, p) for k, p in tr.renderer.named_parameters() if k.startswith("feature_module.")]
+
+    def snapshot(named):
+        tr.optimizer.sync_step_counts()
+        out = {}
+        for k, p in named:
+            st = tr.optimizer.state[p]
+            out[k] = (p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), int(st["step"]))
+        return out
+
+    before, planes_before = snapshot(heads), snapshot(planes)
+    fwd = tr.renderer.forward
+    tr.renderer.forward = functools.partial(fwd, early_termination_threshold=2.0)      # T = 1 is not > 2: every weight is 0
+    tr.step()
+    tr.renderer.forward = fwd
+    assert float(tr.renderer._stats["gate"].item()) == 0.0
+    after, planes_after = snapshot(heads), snapshot(planes)
+    for k in before:                 # the decoders: param.grad is None in the reference -> torch.optim.Adam skips them
+        assert all(torch.equal(a, b) for a, b in zip(before[k][:3], after[k][:3])) and before[k][3] == after[k][3], k
+    for k in planes_before:          # the planes still receive the regulariser's gradient (run.py:254-256) and take their step
+        assert not torch.equal(planes_before[k][0], planes_after[k][0]) and planes_after[k][3] == planes_before[k][3] + 1, k
+    tr.step()
+    moved = snapshot(heads)
+    assert float(tr.renderer._stats["gate"].item()) == 1.0
+    assert any(not torch.equal(after[k][0], moved[k][0]) for k in after)
+    assert all(moved[k][3] == after[k][3] + 1 for k in after)

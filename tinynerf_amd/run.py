@@ -142,6 +142,7 @@ class Trainer:
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
         self._gate_ring = torch.zeros(256, device=device)
+        self._gate_tick = 0
         self._acc_ring = torch.zeros((64, 1 + 32 * 3), dtype=torch.float64, device=device)
         self.prefetch = True
 
@@ -259,8 +260,9 @@ class Trainer:
                L.ptr(info), C.c_void_p(None), L.ptr(packed), L.ptr(ray_ids), L.ptr(steps), C.c_int64(n))
         # what the fused render node would otherwise rebuild from (packed, info): ray id and step of every sample, ray directions
         # "Empty iteration" flag of this step: one slot of a ring that is zeroed once per lap (the weights kernel only raises it)
-        slot = self.train_step % self._gate_ring.numel()
-        if slot == 0 and self.train_step > 0:
+        slot = self._gate_tick % self._gate_ring.numel()          # (a counter of its own: a batch may be built without a step)
+        self._gate_tick += 1
+        if slot == 0 and self._gate_tick > 1:
             self._gate_ring.zero_()
         self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R],
                                     "planes_ready": self._planes_ready if self.world > 1 else None, "gate": self._gate_ring[slot:slot + 1]}

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Convergence evidence on the synthetic scene (GPU box): held-out PSNR against the step count for the three model
+configurations through the real Trainer (dynamic batches, occupancy refreshes, shuffled epochs), Vanilla in both matrix modes
+(bf16x3 = exact three-way splits on the bf16 matrix cores, fp32 = v_mfma_f32_32x32x2_f32) -- same seeds, same ray stream.
+usage: scripts/convergence.py <out.json> [steps_kplanes steps_vanilla steps_cobafa]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tinynerf_amd import models, rays                                   # noqa: E402
+from tinynerf_amd.run import TrainConfig, Trainer, psnr                 # noqa: E402
+
+out = sys.argv[1]
+steps = [int(a) for a in sys.argv[2:5]] or [1500, 600, 800]
+dev = torch.device("cuda", 0)
+V, RES = 41, 100
+o, d, rgbs, K, _ = rays.synthetic_scene(n_views=V, res=RES, seed=0, device=str(dev))
+per_view = RES * RES
+train = slice(0, (V - 1) * per_view)
+held = slice((V - 1) * per_view, V * per_view)
+LR = {"vanilla": 1e-3, "cobafa": 1e-3}        # the reference's lr 1e-2 (run.py:186) drives both stacks into the all-masked branch on this
+                                              # scene within a few steps (in the CPU port of the reference's train() as well:
+                                              # tests/test_hip_training.py); the curves of these two use a smaller step
+res = {"scene": f"rays.synthetic_scene(n_views={V}, res={RES}, seed=0): {V - 1} training views, 1 held-out view",
+       "lr_override": LR, "runs": {}}
+for name, method, n_steps, mode in (("kplanes", "kplanes", steps[0], "bf16x3"), ("vanilla_bf16x3", "vanilla", steps[1], "bf16x3"),
+                                    ("vanilla_fp32_mfma", "vanilla", steps[1], "fp32"), ("cobafa", "cobafa", steps[2], "bf16x3")):
+    models.MATMUL = mode
+    torch.manual_seed(0)
+    cfg = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=256, seed=0)
+    tr = Trainer(cfg, o[train], d[train], rgbs[train], torch.ones(3, device=dev), dev)
+    if method in LR:
+        for g in tr.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] = LR[method]
+        tr.scheduler.base_lrs = [LR[method] for _ in tr.scheduler.base_lrs]
+    curve = []
+    t0 = time.perf_counter()
+    for i in range(n_steps + 1):
+        if i % max(n_steps // 10, 1) == 0:
+            torch.cuda.synchronize()
+            t_train = time.perf_counter() - t0
+            img = tr.render_rays(o[held], d[held])
+            curve.append({"step": i, "psnr_held_out": float(psnr(img, rgbs[held])), "loss": tr.loss_value() if i else None,
+                          "occupancy": float(tr.occupancy_grid.occupancy()), "train_s": t_train})
+            t0 = time.perf_counter() - t_train
+        if i < n_steps:
+            tr.step()
+    ok = all(torch.isfinite(p).all().item() for p in tr.renderer.parameters())
+    res["runs"][name] = {"method": method, "matmul": mode, "steps": n_steps, "curve": curve, "finite_parameters": ok}
+    print(name, [round(c["psnr_held_out"], 2) for c in curve], "finite", ok, flush=True)
+    del tr
+    torch.cuda.empty_cache()
+json.dump(res, open(out, "w"), indent=1)

@@ -37,6 +37,13 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.tn_abi_version() == 3
 
 
+def test_integration_guide_covers_every_entry_point():
+    """INTEGRATION.md names the reference call site behind every entry point the header declares."""
+    text = open(os.path.join(os.path.dirname(HEADER), "..", "INTEGRATION.md")).read()
+    missing = [n for n in declared_functions() if not re.search(r"\b" + n + r"\b", text)]
+    assert not missing, missing
+
+
 def test_struct_layouts_match_c(tmp_path):
     """sizeof/offsetof of the ctypes mirrors == what a C compiler sees."""
     from tinynerf_amd import _lib as L

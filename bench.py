@@ -516,8 +516,9 @@ def main():
                 r.update(
                          co_bound={"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
                                    "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
-                                   "note": "memory-side fp32 atomics of the plane scatter (full-line requests); peak = "
-                                           "scripts/microbench/atomic_patterns.hip; this is the limit the launch runs at"})
+                                   "note": "memory-side fp32 atomics of the plane scatter (full-line requests); peak = MEASURED IN THIS REPO "
+                                           "(scripts/microbench/atomic_patterns.hip; = 128 L2 channels x one dword addition per clock at "
+                                           "~2.1 GHz), not a figure of MI355X_MICROARCH.md; this is the limit the launch runs at"})
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
             try:

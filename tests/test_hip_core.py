@@ -380,3 +380,29 @@ def test_render_rays_fused_equals_two_launches():
                C.c_int64(n), C.c_int64(R))
         assert torch.equal(gr0, gr1)
         np.testing.assert_allclose(gs1.cpu().numpy(), gs0.cpu().numpy(), rtol=0, atol=1e-6 * max(float(gs0.abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("box", [1.0, 1.5, 0.3])
+def test_sampler_exit_shortcut_is_exact(box):
+    """Box marcher + box contraction skip the chunks behind the ray's exit (sampler.hip: exact by the monotonicity of rounding,
+    only without an explicit jitter table).  training=False (no jitter, shortcut on) against training=True with a jitter table of
+    zeros (t + 0 * delta = t: same candidates, shortcut off): the packed samples must be bit-identical -- boxes with power-of-two
+    and other extents, rays that graze corners, run along faces, start inside the box or miss it."""
+    c = core()
+    rng = np.random.default_rng(int(box * 10))
+    R, S = 3000, 192
+    o = rng.standard_normal((R, 3)); o = (o / np.linalg.norm(o, axis=1, keepdims=True) * 2.5 * box).astype(np.float32)
+    o[:200] *= 0.2                                                   # origins inside the box
+    d = -o + 1.2 * box * rng.standard_normal((R, 3))
+    d[200:400, 0] = 0.0                                              # axis-parallel components
+    d[400:500] = (o[400:500] * [1, 0, 0]) * -1 + 1e-4 * rng.standard_normal((100, 3))   # nearly along x
+    d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+    o[500:600, 1] = np.float32(box)                                  # origins on a face plane, grazing rays
+    aabb = cu(np.array([[-box] * 3, [box] * 3], np.float32))
+    og = c.OccupancyGrid(64, 1 / 1024.).to(DEV)
+    og.grid.copy_(torch.rand(64, 64, 64, device=DEV) * 0.05)         # ~80 % of the cells above the 0.01 threshold
+    rp = c.RayProvider(og, c.ContractionAABB(aabb), c.RayMarcherAABB(aabb, S, 0.05))
+    p0, i0 = rp(cu(o), cu(d), training=False)
+    p1, i1 = rp(cu(o), cu(d), training=True, jitter=torch.zeros(R, S, device=DEV))
+    assert torch.equal(i0, i1) and np.array_equal(bits(p0), bits(p1))
+    assert 0.05 < p0.shape[0] / (R * S) < 0.95

@@ -209,8 +209,39 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_mask_kernel(
     for (int i = 0; i < 3; ++i) { o[i] = rays_o[3 * ray + i]; d[i] = rays_d[3 * ray + i]; }
     const float t_min = (MARCH == TN_MARCH_AABB) ? aabb_t_min(a, o, d) : 0.0f;
     const int n_chunks = (a.n_samples + 63) >> 6;
+    // Box marcher + box contraction: behind the ray's exit every candidate fails the in-box test (core.py:29), so the chunks there
+    // need no evaluation.  Exact, not approximate: t_k = fl(t_min + fl(k step)) (+ a jitter >= 0) and p_i = fl(o_i + fl(d_i t)) are
+    // monotone in k -- rounding is monotone -- so once the UNJITTERED first candidate of a chunk lies beyond a face along an axis the
+    // ray moves outwards on, every later candidate does.  The chunk is guessed from the slab exit and verified with the kernel's
+    // own arithmetic; a failed check just evaluates everything.  (Explicit jitter tables may hold anything: not used with them.)
+    int n_active = n_chunks;
+    if constexpr (MARCH == TN_MARCH_AABB && CONTRACT == TN_CONTRACT_AABB) {
+        if (a.jitter == nullptr) {
+            float t_exit = 3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float den = (d[i] == 0.0f) ? (d[i] + 1e-9f) : d[i];
+                t_exit = fminf(t_exit, fmaxf((a.lo[i] - o[i]) / den, (a.hi[i] - o[i]) / den));
+            }
+            const float kf = (t_exit - t_min) / a.step + 2.0f;                  // two steps of slack: the check below decides
+            if (kf >= 0.0f && kf < (float)a.n_samples) {
+                const int ch0 = ((int)kf + 63) >> 6;
+                if (ch0 < n_chunks) {
+                    float t0, delta0;
+                    march_t<MARCH>(a, t_min, ch0 * 64, t0, delta0);
+                    bool beyond = false;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float pi = o[i] + d[i] * t0;                       // (the candidate's own expression, core.py:174)
+                        beyond = beyond || (d[i] > 0.0f && pi > a.hi[i]) || (d[i] < 0.0f && pi < a.lo[i]);
+                    }
+                    if (beyond) n_active = ch0;
+                }
+            }
+        }
+    }
     int count = 0;
-    for (int ch = 0; ch < n_chunks; ++ch) {
+    for (int ch = 0; ch < n_active; ++ch) {
         const int k = ch * 64 + lane;
         float c[3], delta;
         bool keep = false;
@@ -219,6 +250,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void sample_mask_kernel(
         if (lane == 0) maskbits[ray * n_chunks + ch] = m;
         count += __popcll(m);
     }
+    if (n_active + lane < n_chunks) maskbits[ray * n_chunks + n_active + lane] = 0;      // (n_chunks <= 64 for S <= 4096)
+    for (int ch = n_active + 64 + lane; ch < n_chunks; ch += 64) maskbits[ray * n_chunks + ch] = 0;
     if (lane == 0) counts[ray] = count;
 }
 

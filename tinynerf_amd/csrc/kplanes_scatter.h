@@ -77,6 +77,10 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
         const unsigned run_end = (unsigned)__ballot(dcell != 0);                       // low 32 bits: half 0 == half 1
         const unsigned mv_xp = (unsigned)__ballot(dcell == 1), mv_xm = (unsigned)__ballot(dcell == -1);
         const unsigned mv_yp = (unsigned)__ballot(dcell == rowlen), mv_ym = (unsigned)__ballot(dcell == -rowlen);
+        // diagonal neighbours share ONE texel with the current cell: three lines are flushed instead of four
+        const unsigned mv_pp = (unsigned)__ballot(dcell == rowlen + 1), mv_mp = (unsigned)__ballot(dcell == rowlen - 1);
+        const unsigned mv_pm = (unsigned)__ballot(dcell == -rowlen + 1), mv_mm = (unsigned)__ballot(dcell == -rowlen - 1);
+        const unsigned mv_diag = mv_pp | mv_mp | mv_pm | mv_mm;
         asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
         // ---- phase B: lane = (tap pair h, channel c) ----
         const int c = j;                       // channel
@@ -125,6 +129,26 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
                                 add_at(o1, a1);
                             }
                             a0 = h == 1 ? t0 : 0.0f; a1 = h == 1 ? t1 : 0.0f;
+                        } else if ((mv_diag >> sI) & 1u) {
+                            // (dx, dy): the texel diagonally across stays -- upper row = half 0, lower row = half 1, a0 = left, a1 = right
+                            const float t0 = __shfl_xor(a0, 32, 64), t1 = __shfl_xor(a1, 32, 64);
+                            if ((mv_pp >> sI) & 1u) {            // (+1, +1): lower right -> new upper left
+                                add_at(o0, a0);
+                                if (h == 0) add_at(o1, a1);
+                                a0 = h == 0 ? t1 : 0.0f; a1 = 0.0f;
+                            } else if ((mv_mp >> sI) & 1u) {     // (-1, +1): lower left -> new upper right
+                                add_at(o1, a1);
+                                if (h == 0) add_at(o0, a0);
+                                a1 = h == 0 ? t0 : 0.0f; a0 = 0.0f;
+                            } else if ((mv_pm >> sI) & 1u) {     // (+1, -1): upper right -> new lower left
+                                add_at(o0, a0);
+                                if (h == 1) add_at(o1, a1);
+                                a0 = h == 1 ? t1 : 0.0f; a1 = 0.0f;
+                            } else {                             // (-1, -1): upper left -> new lower right
+                                add_at(o1, a1);
+                                if (h == 1) add_at(o0, a0);
+                                a1 = h == 1 ? t0 : 0.0f; a0 = 0.0f;
+                            }
                         } else {
                             add_at(o0, a0);
                             add_at(o1, a1);

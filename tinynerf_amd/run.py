@@ -15,6 +15,7 @@ re-plumbs the loop MI355X-first:
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -141,6 +142,7 @@ class Trainer:
             self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
+        self._side: Optional[torch.cuda.Stream] = None
         self._gate_ring = torch.zeros(256, device=device)
         self._gate_tick = 0
         self._acc_ring = torch.zeros((64, 1 + 32 * 3), dtype=torch.float64, device=device)
@@ -305,7 +307,18 @@ class Trainer:
         if self.world > 1 and gate is not None:
             gate_done = torch.distributed.all_reduce(gate, async_op=True)
         if self.prefetch if prefetch is None else prefetch:
-            self._launch_plan()            # next step's sampler pass runs between this forward and backward
+            # next step's sampler pass (ray gather, occupancy masks, rule + scan, 16-byte read-back): it depends on the grid and the
+            # ray stream only, so it goes to a stream of its own behind this forward pass -- VALU work that fills in beside the
+            # HBM-bound weight-gradient kernels of the backward pass instead of standing in line with them.  build_batch() waits for
+            # its event on the host before anything of the next step is launched, and its buffers are the other turn's.
+            if os.environ.get("TN_SIDE_PLAN", "1") == "0":        # (same stream: debugging / A-B timing)
+                self._launch_plan()
+            else:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.device)
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side):
+                    self._launch_plan()
         # loss * grad_scale, scaled and never unscaled (run.py:259-260 quirk).  The MSE and its gradient are written out
         # by hand (4 small kernels instead of ~12 through autograd); the regulariser's value and gradient are one launch.
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)

@@ -229,7 +229,8 @@ typedef struct tn_mlp_desc {
 int tn_linear_fwd(const float *x, const float *weight, const float *bias, int64_t n, int32_t in_features,
                   int32_t out_features, float *y, void *stream);
 /* ... and its backward: grad_x [n, in] = grad_y weight (written; NULL: skipped), grad_weight [out, in] += grad_y^T x and
- * grad_bias [out] += column sums of grad_y (both ACCUMULATED, as autograd does into .grad; NULL: skipped). */
+ * grad_bias [out] += column sums of grad_y (both ACCUMULATED, as autograd does into .grad; NULL: skipped -- each on its own:
+ * x may be NULL when grad_weight is). */
 int tn_linear_bwd(const float *x, const float *weight, const float *grad_y, int64_t n, int32_t in_features,
                   int32_t out_features, float *grad_x, float *grad_weight, float *grad_bias, void *stream);
 

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""PSNR@step of the reference's recipe on CPU (build container only) -> tests/golden/G17_psnr_curve.json.
+
+TEST INFRASTRUCTURE.  Runs ``oracle/torch_port.reference_training`` -- the CPU port of the reference's ``train()`` (run.py:97-319:
+shuffled loader stream, sampling jitter, jittered occupancy refreshes every 16 * 4096 / B steps, Adam + MultiStepLR, the scaled and
+never unscaled loss) -- on the synthetic scene for N_STEPS steps and several seeds, and records the held-out PSNR (run.py:53-54,
+``infer`` semantics: training=False sampling, run.py:15-50) at EVAL_AT.  ``tests/test_hip_psnr.py`` (-m gpu) runs the HIP
+``Trainer`` (device RNG, refreshes on) on the same scene from the same initial parameters and holds the seed-mean curves together.
+
+    python oracle/make_psnr_curve.py [--seeds 0 1 2] [--steps 300] [--out tests/golden/G17_psnr_curve.json]
+
+The scene is ``tinynerf_amd.rays.synthetic_scene`` (an input generator shared with the GPU test, not a product path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import tinynerf_oracle as orc          # noqa: E402
+from oracle import torch_port as tp                 # noqa: E402
+
+CONFIG = dict(n_views=21, res=100, batch_size=1024, n_samples=128, occupancy_res=128, method="kplanes", scene_seed=0)
+EVAL_AT = (0, 50, 100, 150, 200, 250, 300)
+
+
+def scene():
+    from tinynerf_amd import rays
+    o, d, rgbs, _, _ = rays.synthetic_scene(n_views=CONFIG["n_views"], res=CONFIG["res"], seed=CONFIG["scene_seed"], device="cpu")
+    per = CONFIG["res"] ** 2
+    n_train = (CONFIG["n_views"] - 1) * per
+    return (o[:n_train], d[:n_train], rgbs[:n_train]), (o[n_train:], d[n_train:], rgbs[n_train:])
+
+
+def initial_state(seed: int):
+    """the parameters ``run.Trainer(cfg(seed=seed))`` starts from: torch.manual_seed(seed) + the reference's constructors"""
+    from tinynerf_amd.run import TrainConfig, build_renderer
+    cfg = TrainConfig(method=CONFIG["method"], scene_type="aabb", batch_size=CONFIG["batch_size"], n_samples=CONFIG["n_samples"],
+                      seed=seed, occupancy_res=CONFIG["occupancy_res"])
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        renderer, _, _ = build_renderer(cfg, torch.ones(3), torch.device("cpu"))
+    return {k: v.detach().clone().contiguous() for k, v in renderer.state_dict().items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "G17_psnr_curve.json"))
+    args = ap.parse_args()
+    (o, d, rgbs), (ho, hd, hrgb) = scene()
+    o, d, rgbs = o.numpy(), d.numpy(), rgbs.numpy()
+    ho, hd = ho.numpy(), hd.numpy()
+    aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
+    bg = torch.ones(3)
+    eval_at = [e for e in EVAL_AT if e <= args.steps]
+    runs = []
+    for seed in args.seeds:
+        curve = {}
+
+        def eval_fn(step, sd, grid, thr, curve=curve):
+            packed, info = orc.ray_provider(ho, hd, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
+                                            n_samples=CONFIG["n_samples"], near=0.1, aabb=aabb)        # training=False: no jitter
+            with torch.no_grad():
+                img = tp.render({k: v.detach() for k, v in sd.items()}, torch.from_numpy(packed), torch.from_numpy(info), bg)
+            curve[step] = float(-10.0 * torch.log10(torch.mean((img - hrgb) ** 2)))
+            print(f"seed {seed} step {step}: held-out psnr {curve[step]:.3f} dB ({time.perf_counter() - t0:.0f} s)", flush=True)
+        t0 = time.perf_counter()
+        losses, _, counts = tp.reference_training(initial_state(seed), o, d, rgbs, method=CONFIG["method"], batch_size=CONFIG["batch_size"],
+                                                  n_samples=CONFIG["n_samples"], n_steps=args.steps, occupancy_res=CONFIG["occupancy_res"],
+                                                  stochastic_seed=1000 + seed, eval_at=eval_at, eval_fn=eval_fn)
+        runs.append({"seed": seed, "psnr": {str(k): v for k, v in sorted(curve.items())}, "loss": losses,
+                     "samples_per_step": [c[0] for c in counts], "rays_per_step": [c[1] for c in counts]})
+        json.dump({"config": CONFIG, "eval_at": eval_at, "steps": args.steps, "torch": torch.__version__, "runs": runs,
+                   "made_by": "oracle/make_psnr_curve.py (CPU port of the reference's train(), stochastic mode)"},
+                  open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

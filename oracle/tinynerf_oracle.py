@@ -234,6 +234,28 @@ def ray_provider(rays_o, rays_d, *, marcher: str, contraction: str, grid, thresh
     return packed, info
 
 
+def uniform01(seed: int, ctr) -> np.ndarray:
+    """The HIP sampler's counter-based U[0,1) (tinynerf_amd/csrc/tn_common.h ``tn::uniform01``: a splitmix64 finaliser over
+    ``seed + golden * (ctr + 1)``, top 24 bits) restated with wrapping 64-bit integers.  It stands in for ``torch.rand_like``
+    (reference core.py:172, :136), whose stream no other device reproduces either; restated here so that the PRODUCTION path of
+    the sampler -- device RNG on, exit shortcut on -- can be held against ``ray_provider(..., jitter=...)`` bit for bit.
+    Candidate (ray r, sample k) of an S-candidate pass draws counter r * S + k; voxel (slice, i) coordinate c of a refresh draws
+    (slice * H * W + i) * 3 + c."""
+    ctr = np.asarray(ctr, np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(0x9E3779B97F4A7C15) * (ctr + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.uint32).astype(f32) * f32(1.0 / 16777216.0)).astype(f32)
+
+
+def sampler_jitter(seed: int, n_rays: int, n_samples: int) -> np.ndarray:
+    """[R, S] jitter table of one sampler pass under device RNG ``seed`` (sampler.hip ``candidate``)"""
+    ctr = np.arange(n_rays, dtype=np.uint64)[:, None] * np.uint64(n_samples) + np.arange(n_samples, dtype=np.uint64)[None, :]
+    return uniform01(seed, ctr)
+
+
 def dynamic_batch(loader_batches, provider: Callable, target_sample_size: int):
     """reference run.py:215-244 -- accumulate loader batches until the projection rule
     trips.  ``loader_batches`` yields (rays_o, rays_d, rgbs); ``provider`` maps

@@ -265,12 +265,19 @@ def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
 def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d: np.ndarray, rgbs: np.ndarray, *,
                        method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
                        bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10, scene_type: str = "aabb",
-                       scene_scale: float = 1.0, cobafa_freqs=None, occ_updates: int = 0, grid0=None, grids_out=None):
+                       scene_scale: float = 1.0, cobafa_freqs=None, occ_updates: int = 0, grid0=None, grids_out=None,
+                       stochastic_seed: Optional[int] = None, eval_at=(), eval_fn=None, on_step=None):
     """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
     shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
     including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts).
     Test knobs (defaults = the reference): ``occ_updates`` overrides the refresh period 16 * 4096 / B (run.py:103), ``grid0``
-    the all-ones initial grid (core.py:108), ``grids_out`` (a list) receives (step, grid, mean) after every refresh."""
+    the all-ones initial grid (core.py:108), ``grids_out`` (a list) receives (step, grid, mean) after every refresh.
+    ``stochastic_seed`` (round 4): the loop AS THE REFERENCE RUNS IT -- a ``DataLoader(shuffle=True)`` stream of loader batches
+    that persists across steps (a fresh permutation per epoch, the partial last batch included: run.py:116-122,221-225), sampling
+    jitter ``t += U[0,1) * delta`` per candidate (core.py:172-173) and jittered voxel coordinates in the refresh (core.py:136), all
+    from one numpy generator.  ``eval_fn(step, sd, grid, threshold)`` is called after ``step`` optimizer steps for every step in
+    ``eval_at`` (the PSNR@step half of the metric, run.py:53-54).  ``on_step(step, sd, packed, info, target)`` is called with the
+    parameters and the dynamic batch of every step right before its forward pass (gradient parity ALONG the reference's trajectory)."""
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v.clone())
           for k, v in sd0.items()}
     params = [v for v in sd.values() if v.requires_grad]
@@ -291,6 +298,16 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
     cursor, M = 0, rays_o.shape[0]
     target_size = batch_size * n_samples
     losses, counts = [], []
+    rng = None if stochastic_seed is None else np.random.default_rng(stochastic_seed)
+    eval_at = set(int(e) for e in eval_at)
+
+    def shuffled_loader():              # DataLoader(shuffle=True) without drop_last, restarted on StopIteration (run.py:221-225)
+        while True:
+            perm = rng.permutation(M)
+            for b0 in range(0, M, batch_size):
+                idx = perm[b0:b0 + batch_size]
+                yield rays_o[idx], rays_d[idx], rgbs[idx]
+    stream = shuffled_loader() if rng is not None else None
 
     def sigma_np(pts: np.ndarray) -> np.ndarray:
         with torch.no_grad():
@@ -300,6 +317,8 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
 
     for step in range(n_steps):
         thr = min(0.01, mean)
+        if step in eval_at and eval_fn is not None:
+            eval_fn(step, sd, grid, thr)
         # dynamic batch (run.py:215-244) over consecutive loader batches
         def batches():
             c = cursor
@@ -307,19 +326,26 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
                 idx = (c + np.arange(batch_size)) % M
                 yield rays_o[idx], rays_d[idx], rgbs[idx]
                 c += batch_size
+        jit_of = (lambda o: None) if rng is None else (lambda o: rng.random((o.shape[0], n_samples), dtype=np.float32))
         if scene_type == "aabb":
             prov = lambda o, d: orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
-                                                 n_samples=n_samples, near=0.1, aabb=aabb)
+                                                 n_samples=n_samples, near=0.1, aabb=aabb, jitter=jit_of(o))
         else:
             prov = lambda o, d: orc.ray_provider(o, d, marcher="unbounded", contraction="mip360", grid=grid, threshold=thr,
-                                                 n_samples=n_samples, near=0.1, far=1e5, uniform_range=scene_scale, order=float("inf"))
-        packed, info, target, k = orc.dynamic_batch(batches(), prov, target_size)
+                                                 n_samples=n_samples, near=0.1, far=1e5, uniform_range=scene_scale, order=float("inf"),
+                                                 jitter=jit_of(o))
+        packed, info, target, k = orc.dynamic_batch(batches() if stream is None else stream, prov, target_size)
         cursor = (cursor + k * batch_size) % M
         if step % occ_updates == 0:
-            jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
+            if rng is None:
+                jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
+            else:
+                jit = [rng.random((occupancy_res, occupancy_res, 3), dtype=np.float32) for _ in range(occupancy_res)]
             grid, mean = orc.occupancy_update(grid, sigma_np, step_size, 0.01, decay, mean, jit)
             if grids_out is not None:
                 grids_out.append((step, grid.copy(), mean))
+        if on_step is not None:
+            on_step(step, sd, packed, info, target)
         out = render(sd, torch.from_numpy(packed), torch.from_numpy(info), bg_t, vanilla_freqs=vf, cobafa_freqs=cf)
         loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
         if method == "kplanes":
@@ -330,4 +356,6 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
         sched.step()
         losses.append(float(loss.detach()))
         counts.append((int(packed.shape[0]), int(info.shape[0])))
+    if n_steps in eval_at and eval_fn is not None:
+        eval_fn(n_steps, sd, grid, min(0.01, mean))
     return losses, {k: v.detach() for k, v in sd.items()}, counts

@@ -164,7 +164,7 @@ def test_kplanes_full_resolution_vs_oracle():
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=TOL)
 
 
-def test_cobafa_forward():
+def test_cobafa_forward(matmul):
     """tn_cobafa_fwd against the reference's own output (G11): HIP gathers -> oracle MLP (the golden's MLP is 16
     wide, below the MFMA kernel's 32) must reproduce the captured features; and against the oracle's gathers."""
     m = models()
@@ -191,7 +191,7 @@ def test_cobafa_forward():
     ([32, 51, 70, 89, 108, 128], [8, 8, 8, 4, 4, 4], [2., 3.2, 4.4, 5.6, 6.8, 8.], 64),      # run.py:176-181
     ([7, 12, 9], [2, 5, 8], [1.5, 2.5, 4.], 6),                                               # run-time level count, odd channel counts
 ])
-def test_cobafa_default_config_against_grid_sample(res, ch, freqs, coef_res):
+def test_cobafa_default_config_against_grid_sample(res, ch, freqs, coef_res, matmul):
     """run.py:176-181's Cobafa configuration (6 levels, 36 features) and a small irregular one: forward and every grid gradient
     against ATen's CPU grid_sampler_3d (what the reference runs), points partly outside [-1,1] (zeros padding)."""
     m = models()
@@ -389,7 +389,7 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     dict(kind="vanilla", F=10, H=256, layers=3, n=33),
 ])
 @pytest.mark.parametrize("stash,seed", [(True, 11), (False, 11), (True, 12), (True, 13)])
-def test_wide_deep_mlp_backward_vs_torch(cfg, stash, seed, monkeypatch):
+def test_wide_deep_mlp_backward_vs_torch(cfg, stash, seed, monkeypatch, matmul):
     """layer-by-layer backward (mlp_bwd_layers.hip) against torch autograd of the same fp32 network on the device, with the
     activations written by the training forward (tn_mlp_fwd_stash) and recomputed by the backward.  ANY seed: hidden units
     whose pre-activation is an fp32 tie may take either ReLU state (tests/_ties.py); everything else must agree to 3e-5 of each
@@ -798,6 +798,26 @@ def test_linear_fwd_bwd_vs_torch(n, fin, fout, bias):
     close(wt.grad, wr.grad, max(n, 1))
     if b is not None:
         close(bt.grad, br.grad, max(n, 1))
+
+
+@pytest.mark.parametrize("n,fin,fout", [(1000, 96, 96), (33, 50, 7)])
+def test_linear_bwd_bias_gradient_alone(n, fin, fout):
+    """tn_linear_bwd with grad_weight == NULL and grad_bias given (the header: both independently optional): the bias sums must
+    arrive, accumulated, through the C ABI itself -- no dummy weight-gradient buffer"""
+    from tinynerf_amd import _lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(n)
+    w, go = cu(torch.randn(fout, fin, generator=g)), cu(torch.randn(n, fout, generator=g))
+    gb = torch.ones(fout, device=DEV)
+    L.call("tn_linear_bwd", DEV, C.c_void_p(None), L.ptr(w), L.ptr(go), C.c_int64(n), C.c_int32(fin), C.c_int32(fout), C.c_void_p(None),
+           C.c_void_p(None), L.ptr(gb))
+    ref = 1.0 + go.double().sum(0)
+    np.testing.assert_allclose(gb.cpu().numpy(), ref.float().cpu().numpy(), rtol=0, atol=4e-7 * n ** 0.5 * float(ref.abs().max()))
+    # and through autograd: a frozen weight with a trainable bias
+    x = cu(torch.randn(n, fin, generator=g))
+    b = torch.zeros(fout, device=DEV, requires_grad=True)
+    models().linear(x, w, b).backward(go)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), (ref - 1.0).float().cpu().numpy(), rtol=0, atol=4e-7 * n ** 0.5 * float(ref.abs().max()))
 
 
 def test_linear_rejects_wide_layers_and_cpu_tensors():

@@ -136,7 +136,7 @@ def _vanilla_renderer(g):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_vanilla_renderer_vs_reference(fused):
+def test_vanilla_renderer_vs_reference(fused, matmul):
     """fused: heads + scan + composite as one autograd node, every sample through the colour head (tinynerf_amd.fused);
     not fused: module by module with the boolean gather of core.py:246-249."""
     from tinynerf_amd import core
@@ -166,7 +166,7 @@ def test_vanilla_renderer_vs_reference(fused):
 
 # ------------------------------------------------------------------------------------------------ G15 (BASELINE config 5)
 @pytest.mark.parametrize("fused", [True, False])
-def test_config5_sampler_and_renderer_vs_reference(fused):
+def test_config5_sampler_and_renderer_vs_reference(fused, matmul):
     from tinynerf_amd import core, models as m
     g = load_golden("G15_config5_cobafa_unbounded")
     S = int(g["n_samples"])
@@ -204,7 +204,18 @@ def test_config5_sampler_and_renderer_vs_reference(fused):
     # tensor is therefore max(2e-5, 4 x that distance): colour head strict, sigma path as loose as the reference itself is.
     cond = tp.weights_conditioning(ref)
     assert cond["rgb_decoder.net.net.0.weight"] == 0.0 and cond["sigma_decoder.net.net.2.bias"] > 1e-3
-    assert_grads_match_up_to_relu_ties(got, ref, {k: max(2e-5, 4.0 * c) for k, c in cond.items()}, golden={n: g["grad." + n] for n in got})
+    # Round-3 verdict: a 16 % tolerance pins nothing.  On THIS medium only the tensors the reference itself determines to better
+    # than the cap are compared (the colour head at 2e-5: it does not pass through the weights backward; whatever else is
+    # conditioned below 2e-3: the coefficient grid and most of the 128-wide stack); the sigma path of config 5's composition is pinned by the thin-medium evaluation below
+    # (every tensor, < 4e-4) and by G16 (terminated rays, cap 6e-3) -- not by a loose assert here.
+    CAP = 8e-3
+    pinned = sorted(k for k, c in cond.items() if 4.0 * c <= CAP)
+    assert any(k.startswith("rgb_decoder") for k in pinned) and len(pinned) >= 10, pinned
+
+    def only(dct):
+        return {k: dct[k] for k in pinned}
+    assert_grads_match_up_to_relu_ties(only(got), lambda: only(ref()), {k: max(2e-5, 4.0 * cond[k]) for k in pinned},
+                                       golden={n: g["grad." + n] for n in pinned}, cond_cap=CAP)
     # (tightly pinned twin of this fixture with terminated rays: G16, test_config5_moderate_medium_vs_reference)
     # the same composition where the reference is well conditioned: thin medium (sigma bias - 4: no ray terminates),
     # every tensor to 2e-5 ... 4 x its (small) conditioning against the CPU port
@@ -223,7 +234,7 @@ def test_config5_sampler_and_renderer_vs_reference(fused):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_config5_moderate_medium_vs_reference(fused):
+def test_config5_moderate_medium_vs_reference(fused, matmul):
     """G16: config 5's composition (unbounded marcher + inf-norm Mip-360 contraction + Cobafa + renderer) with a medium in which
     33 of 48 rays terminate (127 samples with w == 0) while the reference's fp32 weights backward stays well conditioned: the
     far samples, whose steps of up to 13.8 amplify the suffix-sum cancellation of cuda.cu:49-56 in G15, are culled by the grid.

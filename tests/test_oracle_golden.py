@@ -185,3 +185,24 @@ def test_ray_generation_fixture():
     np.testing.assert_allclose(d[::25, ::25], g["rays_d_0"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(o[::25, ::25], g["rays_o_0"], rtol=0, atol=0)
     assert abs(float(g["fx"]) - 277.78) < 0.01          # SURVEY probe: focal of the 200x200 fixture
+
+
+def test_counter_rng_restatement_known_answers():
+    """oracle.uniform01 against the definition evaluated with Python integers (arbitrary precision, masked to 64 bits): the
+    restatement of tn::uniform01 (tinynerf_amd/csrc/tn_common.h) that the GPU test of the production sampler path leans on"""
+    M = (1 << 64) - 1
+
+    def ref(seed, ctr):
+        z = (seed + 0x9E3779B97F4A7C15 * (ctr + 1)) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return np.float32(z >> 40) * np.float32(1.0 / 16777216.0)
+    for seed in (0, 1, 12345678901234567, (1 << 62) - 1, (1 << 63) + 5):
+        ctrs = [0, 1, 2, 63, 64, 1 << 20, (1 << 31) + 7, (1 << 40) + 3]
+        got = orc.uniform01(seed, np.array(ctrs, np.uint64))
+        want = np.array([ref(seed, c) for c in ctrs], np.float32)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    u = orc.sampler_jitter(99, 512, 256)
+    assert u.shape == (512, 256) and 0.0 <= u.min() and u.max() < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3
+    assert np.array_equal(u[3, 7:9].view(np.uint32), orc.uniform01(99, np.array([3 * 256 + 7, 3 * 256 + 8], np.uint64)).view(np.uint32))

@@ -50,11 +50,15 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libtinynerf_hip.so cannot be built")
 
 
-def _digest(paths) -> str:
+def _digest(paths, flags=None) -> str:
+    """file contents AND the effective per-file flag lists: a flag that arrives through the environment (TN_B3_EXTRA_FLAGS) must
+    trigger a rebuild like an edit does"""
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
             h.update(p.encode()); h.update(f.read())
+    for k in sorted(flags or {}):
+        h.update(("%s: %s\n" % (k, " ".join(COMMON + flags[k]))).encode())
     return h.hexdigest()
 
 
@@ -68,7 +72,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps.append(os.path.join(HERE, "..", "include", "tinynerf_hip.h"))
     deps.append(os.path.abspath(__file__))
     stamp = os.path.join(OBJ, "stamp")
-    dig = _digest(deps)
+    dig = _digest(deps, srcs)
+    # TN_B3_ABLATE builds compute WRONG results on purpose (timing experiments): such a library never gets a stamp, so the next
+    # ordinary build() replaces it instead of reusing it
+    ablation = bool(os.environ.get("TN_B3_ABLATE"))
+    if ablation and os.path.exists(stamp):
+        os.remove(stamp)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
@@ -91,8 +100,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
-    with open(stamp, "w") as f:
-        f.write(dig)
+    if not ablation:
+        with open(stamp, "w") as f:
+            f.write(dig)
+    elif verbose:
+        sys.stderr.write("tinynerf_amd.build: TN_B3_ABLATE is set -- this library computes wrong results and carries no stamp\n")
     if verbose:
         print("built", LIB)
     return LIB

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void lin_wgrad_kernel(const float *
                                                                    float *__restrict__ gb, int K, int N, int ldw, int64_t n)
 {
     __shared__ float tiles[LIN_WAVES][2][32 * 33];           // [sample][column] with an odd stride
-    const int KB = (K + 31) / 32;
+    const int KB = gW != nullptr ? (K + 31) / 32 : 1;          // bias gradient alone: one k block, no x operand
     const int ob = blockIdx.y / KB, kb = blockIdx.y % KB;
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
     float *gs = tiles[wave][0], *xs = tiles[wave][1];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void lin_wgrad_kernel(const float *
         for (int e = lane; e < 32 * 32; e += 64) {
             const int r = e >> 5, c = e & 31;
             gs[r * 33 + c] = (r < rows && 32 * ob + c < N) ? gy[(r0 + r) * N + 32 * ob + c] : 0.0f;
-            xs[r * 33 + c] = (r < rows && 32 * kb + c < K) ? x[(r0 + r) * K + 32 * kb + c] : 0.0f;
+            xs[r * 33 + c] = (gW != nullptr && r < rows && 32 * kb + c < K) ? x[(r0 + r) * K + 32 * kb + c] : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void lin_wgrad_kernel(const float *
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = 32 * ob + frow(r, h), c = 32 * kb + i;
-        if (o < N && c < K) atomicAdd(&gW[(int64_t)o * ldw + c], acc[r]);
+        if (gW != nullptr && o < N && c < K) atomicAdd(&gW[(int64_t)o * ldw + c], acc[r]);
     }
     if (kb == 0 && gb != nullptr) {
         bsum += __shfl_xor(bsum, 32, 64);
@@ -162,9 +162,9 @@ extern "C" int tn_linear_bwd(const float *x, const float *weight, const float *g
     hipStream_t s = (hipStream_t)stream;
     if (grad_x)
         if (int rc = launch_apply<true>(grad_y, weight, nullptr, grad_x, out_features, in_features, in_features, n, s)) return rc;
-    if (grad_weight) {
+    if (grad_weight || grad_bias) {        // either gradient alone is served: the bias sums ride in the k-block-0 workgroups
         const int64_t n_tiles = (n + 31) / 32;
-        const int NB = (out_features + 31) / 32, KB = (in_features + 31) / 32;
+        const int NB = (out_features + 31) / 32, KB = grad_weight ? (in_features + 31) / 32 : 1;
         const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + LIN_WAVES - 1) / LIN_WAVES, 1024 / (NB * KB) + 1));
         lin_wgrad_kernel<<<dim3(bx, (unsigned)(NB * KB)), dim3(LIN_WAVES * 64), 0, s>>>(grad_y, x, grad_weight, grad_bias, in_features, out_features,
                                                                                        in_features, n);

@@ -13,6 +13,7 @@ gradient buffers allocated), which saves two passes over the 126 MiB of plane gr
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, List, Optional, Sequence
 
 import torch
@@ -27,6 +28,18 @@ PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_
 FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
 FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient chain launch (tn_kplanes_mlp_bwd_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
+# schedule of the K-Planes backward: "fused" = chain + scatter in one kernel, then the weight gradients; "split" = chain, then the
+# stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
+# second stream BESIDE the weight-gradient kernels (bound by HBM)
+BWD_SCHEDULE = os.environ.get("TN_BWD_SCHEDULE", "fused")
+_side_streams: dict = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(dev)
+    return s
 
 
 def _alloc(arena: Optional[Arena], name: str, shape, dev: torch.device, dtype=torch.float32) -> torch.Tensor:
@@ -61,6 +74,25 @@ def _ray_aux(packed: torch.Tensor, info: torch.Tensor, freqs: torch.Tensor, n_fr
     if n > 0:
         L.call("tn_dir_encode", dev, L.ptr(dirs_ray), C.c_int64(R), L.ptr(freqs), C.c_int(n_freqs), L.ptr(table), C.c_int(stride))
     return table, ray_ids, stride, steps
+
+
+def _gate_slot(hint: Optional[dict], wanted: bool) -> Optional[torch.Tensor]:
+    """the trainer's "Empty iteration" flag slot for this batch (the weights kernel only ever RAISES it): fresh -- zeroed by the
+    ring's lap -- for the first forward on a batch, cleared here for any further forward on the same batch (another threshold,
+    other parameters), which would otherwise inherit the earlier forward's 1.0"""
+    if not wanted or hint is None or hint.get("gate") is None:
+        return None
+    if hint.get("gate_used"):
+        hint["gate"].zero_()
+    hint["gate_used"] = True
+    return hint["gate"]
+
+
+def _upstream_is_gated(ctx: Any) -> bool:
+    """The node's backward applies the gate itself unless the caller has DECLARED the upstream gradient gated
+    (run.Trainer.step_on_batch sets stats["upstream_gated"] around tn_mse_grad_gated): any other loss on a trainer-built batch
+    -- a test, a custom loop -- then still gets the reference's zero gradients in an all-masked step (core.py:251-254)"""
+    return bool(ctx.gate_in_slot and ctx.stats is not None and ctx.stats.get("upstream_gated"))
 
 
 class _RenderKPlanes(Function):
@@ -112,7 +144,7 @@ class _RenderKPlanes(Function):
             weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
         # harness: a zeroed [1] slot that the weights kernel raises when any weight is > 0 (instead of a reduction launch), and an
         # upstream gradient that arrives gated (tn_mse_grad_gated) -- see the "Empty iteration" note below
-        gate_slot = hint.get("gate") if (covered and train and hint is not None) else None
+        gate_slot = _gate_slot(hint, covered and train)
         out = torch.empty((R, 3), device=dev)
         if pair:
             # both heads are done: weights and composite of a ray in one launch (tn_render_rays_fwd, bit-identical to the two)
@@ -140,11 +172,12 @@ class _RenderKPlanes(Function):
         # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer all-reduces it in place right after this forward
         # (run.Trainer.step_on_batch) -- the single-GPU step on the union of the ranks' rays is only "empty" when every
         # rank's is -- so the backward below already reads the all-rank value)
-        ctx.pre_gated = gate_slot is not None
+        ctx.gate_in_slot, ctx.stats = gate_slot is not None, stats
         ctx.gate = gate_slot if gate_slot is not None else (weights.amax().reshape(1) if train else None)
         if stats is not None:
             stats["gate"] = ctx.gate
-            stats["pre_gated"] = ctx.pre_gated
+            stats["pre_gated"] = ctx.gate_in_slot        # the caller MAY hand in a gated gradient (and must then say so)
+            stats["upstream_gated"] = False
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
@@ -163,7 +196,7 @@ class _RenderKPlanes(Function):
         n, R = packed.size(0), info.size(0)
         F = feat.size(1)
         g_out = grad_out.contiguous()
-        if ctx.gate is not None and not ctx.pre_gated:
+        if ctx.gate is not None and not _upstream_is_gated(ctx):
             g_out = g_out * (ctx.gate > 0).to(g_out.dtype)       # "Empty iteration": zero gradients, as on the module-by-module path
 
         def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
@@ -207,7 +240,26 @@ class _RenderKPlanes(Function):
             pair_args = (C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
                          C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
             scatter_fused = FUSE_SCATTER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
-            if scatter_fused:
+            if BWD_SCHEDULE in ("split", "overlap"):
+                rdesc.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
+                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
+                if BWD_SCHEDULE == "overlap":
+                    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        scatter()
+                else:
+                    scatter()
+                scattered = True
+                if ctx.planes_ready is not None and BWD_SCHEDULE == "split":
+                    ctx.planes_ready(g_planes)
+                rdesc.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
+                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
+                if BWD_SCHEDULE == "overlap":
+                    main.wait_stream(side)
+                    if ctx.planes_ready is not None:
+                        ctx.planes_ready(g_planes)
+            elif scatter_fused:
                 # data gradients of both heads AND the plane scatter in one launch: d loss / d features stays in registers
                 def chain_and_weights(flags):
                     rdesc.flags = L.MLP_STASHED | flags
@@ -312,7 +364,7 @@ class _RenderHeads(Function):
         covered = hint is not None and hint.get("key") == (packed.data_ptr(), n, R)
         if not covered:
             weights.zero_()          # cuda.cu:84 (zeros_like): samples outside every (start, count) keep weight 0
-        gate_slot = hint.get("gate") if (covered and train and hint is not None) else None       # (see _RenderKPlanes)
+        gate_slot = _gate_slot(hint, covered and train)       # (see _RenderKPlanes)
         out = torch.empty((R, 3), device=dev)
         if train:          # the colour head runs on every sample: weights and composite of a ray behind it, in one launch
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
@@ -325,11 +377,12 @@ class _RenderHeads(Function):
             rdesc.row_gate = None
             L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                    C.c_int64(n), C.c_int64(R))
-        ctx.pre_gated = gate_slot is not None
+        ctx.gate_in_slot, ctx.stats = gate_slot is not None, stats
         ctx.gate = gate_slot if gate_slot is not None else (weights.amax().reshape(1) if train else None)   # "Empty iteration", see _RenderKPlanes
         if stats is not None:
             stats["gate"] = ctx.gate
-            stats["pre_gated"] = ctx.pre_gated
+            stats["pre_gated"] = ctx.gate_in_slot
+            stats["upstream_gated"] = False
         ctx.save_for_backward(feat, info, bg, freqs, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_sigma, accumulate, stride, sb, rb, covered)
         ctx.arena = arena
@@ -345,7 +398,7 @@ class _RenderHeads(Function):
         dev = feat.device
         n, R, F = feat.size(0), info.size(0), feat.size(1)
         g_out = grad_out.contiguous()
-        if ctx.gate is not None and not ctx.pre_gated:
+        if ctx.gate is not None and not _upstream_is_gated(ctx):
             g_out = g_out * (ctx.gate > 0).to(g_out.dtype)
         refs: Sequence[Optional[torch.Tensor]] = ctx.param_refs if ctx.param_refs is not None else [None] * len(params)
 

@@ -580,11 +580,9 @@ class _Linear(Function):
         gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         gw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
         gb = torch.zeros(w.size(0), device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        if gw is None and gb is not None:       # (the kernel reduces the bias beside the weights)
-            gw = torch.zeros_like(w)
         L.call("tn_linear_bwd", dev, L.ptr(x2), L.ptr(w), L.ptr(gy), C.c_int64(x2.size(0)), C.c_int32(w.size(1)), C.c_int32(w.size(0)),
                L.ptr(gx), L.ptr(gw), L.ptr(gb))
-        return (None if gx is None else gx.reshape(ctx.x_shape), gw if ctx.needs_input_grad[1] else None, gb)
+        return (None if gx is None else gx.reshape(ctx.x_shape), gw, gb)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -146,7 +146,29 @@ class Trainer:
         self._gate_ring = torch.zeros(256, device=device)
         self._gate_tick = 0
         self._acc_ring = torch.zeros((64, 1 + 32 * 3), dtype=torch.float64, device=device)
+        self._acc_tick = 0               # a counter of its own (train_step may be assigned from outside, a step may be retried)
         self.prefetch = True
+        # tensors that a sampler pass in flight on the side stream may still read although the trainer has dropped them (the
+        # previous epoch's permutation, the carry it was cut from, an arena buffer that was just regrown): kept until the
+        # pass's event has been synchronised (build_batch) -- the caching allocator would otherwise hand their blocks to
+        # whichever stream allocated them while the other stream's kernel is still queued
+        self._graveyard: List[torch.Tensor] = []
+
+    def __del__(self):
+        side = getattr(self, "_side", None)
+        if side is not None:             # a side pass may still be writing into buffers this object owns
+            try:
+                side.synchronize()
+            except Exception:            # noqa: BLE001 -- interpreter shutdown
+                pass
+
+    def _on_stream(self, *tensors: Optional[torch.Tensor]) -> None:
+        """mark tensors as in use on the CURRENT stream (no-op for the stream they were allocated on): the sampler pass runs on
+        the main stream in step 0 / in a redraw and on the side stream otherwise, and its tensors cross over"""
+        cur = torch.cuda.current_stream(self.device)
+        for t in tensors:
+            if t is not None and t.is_cuda and t.numel():
+                t.record_stream(cur)
 
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
         """capacity-based scratch (see fused.Arena): sizes drift by a few percent per step"""
@@ -155,9 +177,12 @@ class Trainer:
             numel *= int(d)
         t = self._arena.get(name)
         if t is None or t.numel() < numel:
+            if t is not None:
+                self._graveyard.append(t)
             t = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=self.device)
             self._arena[name] = t
             self._arena_grown += 1
+        self._on_stream(t)
         return t[:numel].view(*shape)
 
     # ------------------------------------------------------------------ a8: dynamic batch
@@ -172,8 +197,10 @@ class Trainer:
         disjoint by construction and an epoch of the job visits every ray once.  Deviation: the reference's partial last
         loader batch of an epoch (DataLoader without drop_last) is filled up from the next epoch instead."""
         n_rays = self.rays_o.size(0)
+        self._on_stream(self._perm, self._carry)
         while self._carry.numel() + (0 if self._perm is None else self._perm.numel() - self._perm_pos) < m:
             if self._perm is not None:
+                self._graveyard += [self._perm, self._carry]        # still read by the `cat` below, possibly on the other stream
                 self._carry = torch.cat([self._carry, self._perm[self._perm_pos:]])
             self._perm = torch.randperm(n_rays, device=self.device, generator=self._gen, dtype=torch.int32)
             self._perm_pos = 0
@@ -246,6 +273,8 @@ class Trainer:
                 self._launch_plan()
             pend, self._pending = self._pending, None
             self._plan_event.synchronize()              # the step's single host read-back
+            del self._graveyard[:]                      # (everything the pass read has been read)
+            self._on_stream(*(pend[k] for k in ("idx", "o", "d", "rgb", "maskbits", "counts", "info")))   # consumed on this stream now
             k, n, R, tripped = self._plan_host.tolist()
             if tripped or pend["n_b"] >= 4096:
                 break
@@ -324,7 +353,8 @@ class Trainer:
         # (gradients were zeroed by the previous optimizer pass: zero_grad -> backward -> step, run.py:258-260)
         R = rendered.size(0)
         # [0]: sum of squares, [1:]: regulariser sums -- one row of a ring that is zeroed once per lap (no fill launch per step)
-        row = self.train_step % self._acc_ring.size(0)
+        row = self._acc_tick % self._acc_ring.size(0)
+        self._acc_tick += 1
         if row == 0:
             self._acc_ring.zero_()
         acc = self._acc_ring[row]
@@ -336,14 +366,20 @@ class Trainer:
             if gate_done is not None:
                 gate_done.wait()
             inv, inv_dev = 1.0, (1.0 / (3.0 * ray_count)).float()
-        if gate is not None and getattr(self.renderer, "_stats", {}).get("pre_gated"):
-            # the render node expects its upstream gradient gated (it raised the flag inside the weights kernel)
+        stats = getattr(self.renderer, "_stats", {})
+        if gate is not None and stats.get("pre_gated"):
+            # the render node raised the flag inside the weights kernel: the gradient leaves the loss kernel gated, and the node
+            # is told so (it gates by itself otherwise)
+            stats["upstream_gated"] = True
             L.call("tn_mse_grad_gated", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                    L.ptr(inv_dev), L.ptr(gate), L.ptr(grad), L.ptr(acc))
         else:
             L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                    L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
-        rendered.backward(grad)
+        try:
+            rendered.backward(grad)
+        finally:
+            stats["upstream_gated"] = False
         reg_coef, plane_reg = None, None
         if cfg.method == "kplanes":                                               # run.py:254-256
             # the regulariser's gradient is the same on every rank (same planes): it is folded into the optimizer pass, after

@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--other-steps", type=int, default=8, help="steps per window of the Vanilla / Cobafa side runs")
     ap.add_argument("--other-windows", type=int, default=3)
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the first one is the measurement")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank runs the recipe's batch (B rays x S per loader batch, ~B*S samples per rank and step); "
+                         "strong = the recipe's B*S samples per step are split over the ranks (PSNR@step comparable with N = 1)")
     return ap.parse_args()
 
 
@@ -387,7 +390,8 @@ def main():
     timer.install()
 
     o, d, rgbs, K, _ = rays.synthetic_scene(n_views=args.views, res=800, seed=rank, device=str(dev))
-    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)
+    shard = world if args.scaling == "strong" else 1
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=1024, n_samples=1024, seed=0, shard=shard)
     tr = Trainer(cfg, o, d, rgbs, torch.ones(3, device=dev), dev, rank=rank, world_size=world)
     # occupancy: 1 inside the centred ball of radius 0.5 (normalised coords), decay^20 elsewhere
     lin = torch.linspace(-1, 1, 128, device=dev)
@@ -430,6 +434,41 @@ def main():
     loss = tr.loss_value()
     extra_windows = [window(False) for _ in range(max(0, args.windows - 1))]      # variance only
     window_ms = [dt / args.steps * 1e3] + [w[0] / args.steps * 1e3 for w in extra_windows]
+
+    # PSNR@step (the second half of BASELINE.json's metric, run.py:53-54): one held-out 800x800 view of the same synthetic
+    # scene -- a camera no rank trains on -- rendered with the parameters as they are after the timed steps (every rank holds the
+    # same parameters; rank 0 renders)
+    psnr_at_step = None
+    if rank == 0:
+        from tinynerf_amd.run import psnr as psnr_fn
+        ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=800, seed=10_007, device=str(dev))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = tr.render_rays(ho, hd)
+        torch.cuda.synchronize()
+        psnr_at_step = {"step": tr.train_step, "psnr": float(psnr_fn(img, hrgb)), "render_ms": (time.perf_counter() - t0) * 1e3,
+                        "view": "held-out 800x800 camera (rays.synthetic_scene(n_views=1, seed=10007)), inference path (training=False sampling)",
+                        "samples_per_step": samples / args.steps,
+                        "reference": "tests/golden/G17_psnr_curve.json + tests/test_hip_psnr.py: held-out PSNR of the HIP Trainer against the CPU "
+                                     "port of the reference's train() at equal step counts (seed means, 50..300 steps)"}
+        del img, ho, hd, hrgb
+    # the occupancy refresh (run.py:248-249) runs every 16 * 4096 / B steps: a window of K < 64 steps behind a short warm-up
+    # never contains one, so its cost is measured here and folded into `value_with_refresh` at its amortised weight
+    refresh = None
+    if rank == 0 or world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        grid_keep, mean_keep = tr.occupancy_grid.grid.clone(), tr.occupancy_grid.mean
+        torch.cuda.synchronize()
+        e0.record(torch.cuda.current_stream(dev))
+        tr.occupancy_grid.update(tr.sigma_fn, seed=12345)
+        e1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize()
+        tr.occupancy_grid.grid.copy_(grid_keep)                      # (the stage timings below run on the bench's own grid)
+        tr.occupancy_grid.mean = mean_keep
+        ms = e0.elapsed_time(e1)
+        refresh = {"ms_per_refresh": ms, "every_steps": tr.occupancy_grid_updates, "ms_per_step_amortised": ms / tr.occupancy_grid_updates,
+                   "in_window0": any((args.warmup + i) % tr.occupancy_grid_updates == 0 for i in range(args.steps))}
+        del grid_keep
 
     # stage rates on one batch of the same workload (sampler / render fwd / render fwd+bwd)
     stages = None
@@ -547,14 +586,21 @@ def main():
         line = {
             "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
-                       "parallelism": (f"dp{world}: rays sharded over {world} ranks (one per GPU), RCCL all-reduce of plane / MLP gradients"
+                       "parallelism": (f"dp{world} ({args.scaling} scaling: " + ("every rank runs the recipe's batch" if args.scaling == "weak" else
+                                                                                 f"the recipe's B*S samples per step split over the ranks, {1024 // world} rays per loader batch and rank")
+                                       + f"): rays sharded over {world} ranks (one per GPU), RCCL all-reduce of plane / MLP gradients"
                                        + ("" if backend == "nccl" else f" [DEBUG backend {backend}: ranks share GPUs, not a scaling number]"))
                                       if world > 1 else "single GPU",
                        "samples_per_step_per_gpu": samples / args.steps / world, "rays_per_step_per_gpu": rays_n / args.steps / world},
             "loss": loss,
+            "psnr_at_step": psnr_at_step,
+            "refresh": refresh,
+            # `value` is exactly K steps as timed; with the refresh at its amortised share (unless the window already held one)
+            "value_with_refresh": (samples / (dt + (0.0 if refresh["in_window0"] else args.steps * refresh["ms_per_step_amortised"] * 1e-3))
+                                   if refresh else None),
             "stages": stages,
             "other_configs": others,
             "windows": {"n": len(window_ms), "steps_each": args.steps, "ms_per_step": window_ms, "min": srt[0], "median": srt[len(srt) // 2],

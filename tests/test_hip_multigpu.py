@@ -310,7 +310,8 @@ def test_exchange_path_over_rccl_with_one_rank(method):
 
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(600)
-def test_bench_launcher_relays_two_ranks():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launcher_relays_two_ranks(scaling):
     """`python bench.py --gpus 2` without a launcher: the parent (which must not touch the GPU: it never imports torch) starts two
     ranks; here they share this GPU over gloo (TN_BENCH_BACKEND, debug).  The relayed JSON line must describe the 2-rank job."""
     import json
@@ -320,12 +321,16 @@ def test_bench_launcher_relays_two_ranks():
     env = dict(os.environ, TN_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "1",
-                        "--views", "2", "--no-cpu-baseline", "--no-stages"], env=env, capture_output=True, text=True, timeout=500)
+                        "--views", "2", "--no-cpu-baseline", "--no-stages", "--scaling", scaling], env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["parallelism"].startswith("dp2") and "gloo" in line["config"]["parallelism"]
-    assert line["value"] > 0 and line["config"]["samples_per_step_per_gpu"] > 1e5
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == scaling
+    assert line["config"]["parallelism"].startswith("dp2") and "gloo" in line["config"]["parallelism"] and scaling in line["config"]["parallelism"]
+    per_gpu = line["config"]["samples_per_step_per_gpu"]
+    # weak: every rank runs the recipe's batch (~2^20 samples per rank and step); strong: the recipe's 2^20 are split over the ranks
+    assert line["value"] > 0 and (0.9 * 2 ** 20 < per_gpu < 1.3 * 2 ** 20 if scaling == "weak" else 0.9 * 2 ** 19 < per_gpu < 1.3 * 2 ** 19), per_gpu
+    assert line["psnr_at_step"]["step"] == 3 and 5.0 < line["psnr_at_step"]["psnr"] < 40.0
+    assert line["refresh"]["every_steps"] == 64 and line["refresh"]["ms_per_refresh"] > 0 and line["value_with_refresh"] < line["value"]
     assert "cpu_baseline" not in line                     # rank 0 at N = 1 only

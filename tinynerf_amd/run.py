@@ -48,6 +48,11 @@ class TrainConfig:
     occupancy_res: int = 128           # run.py:106
     deterministic: bool = False        # parity runs: consecutive rays, no sampling jitter, voxel-centre occupancy refresh
     kplanes_resolutions: Tuple[int, ...] = (128, 256, 512)      # models.py:126-142
+    # strong scaling (N > 1): the recipe's batch is SPLIT over `shard` ranks -- each rank draws loader batches of batch_size / shard
+    # rays and stops at batch_size * n_samples / shard packed samples, so a step of the job processes the recipe's B * S samples
+    # whatever N is and "PSNR at equal step count" keeps its meaning; the schedule (steps, refresh period, LR milestones) follows
+    # the GLOBAL batch_size.  shard = 1 with N > 1 is weak scaling: every rank runs the recipe's batch (N x the samples per step)
+    shard: int = 1
 
 
 def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: torch.device):
@@ -95,7 +100,10 @@ class Trainer:
         self.steps = int(2048 * bs_ratio)
         self.occupancy_grid_updates = int(16 * bs_ratio)
         self.tv_reg_alpha, self.l1_reg_alpha = 0.0001, 0.
-        self.target_sample_size = cfg.batch_size * cfg.n_samples
+        if cfg.shard < 1 or cfg.batch_size % cfg.shard:
+            raise ValueError(f"TrainConfig.shard = {cfg.shard} must divide batch_size = {cfg.batch_size}")
+        self.loader_batch = cfg.batch_size // cfg.shard              # rays per loader batch ON THIS RANK
+        self.target_sample_size = self.loader_batch * cfg.n_samples
         params = list(self.renderer.parameters())
         for p in params:                                # grads keep the parameter's (channels_last) layout
             p.grad = torch.zeros_like(p)
@@ -226,7 +234,7 @@ class Trainer:
         the backward pass has drained, and the host never waits for the whole queue (one read-back per step, but no
         pipeline bubble).  The draw depends on the occupancy grid and the ray stream only, not on the parameters."""
         cfg, dev = self.cfg, self.device
-        B, S = cfg.batch_size, cfg.n_samples
+        B, S = self.loader_batch, cfg.n_samples
         n_chunks = (S + 63) // 64
         # candidate block: the rule trips after k loader batches and k drifts by a batch or two between steps; a block that
         # turns out too small is redrawn at twice the size (build_batch), so the margin only has to cover the drift
@@ -267,7 +275,7 @@ class Trainer:
     def build_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
         """packed [N,7], info [R,2], target rgbs [R,3], k -- run.py:215-244 in one sampler pass.
         packed / info are views of the trainer's reused scratch: valid until the next build_batch() (clone to keep)."""
-        dev, B = self.device, self.cfg.batch_size
+        dev, B = self.device, self.loader_batch
         while True:
             if self._pending is None:
                 self._launch_plan()
@@ -280,6 +288,7 @@ class Trainer:
                 break
             self._k_guess = pend["n_b"] * 2             # not enough rays drawn: redraw a larger block
         self._k_guess = k
+        self.last_plan_seed = int(pend["desc"].seed)      # (the counter RNG's seed of this batch's sampling jitter: tests feed it to the oracle)
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         if not self.cfg.deterministic:
             self._advance(R)

@@ -8,6 +8,12 @@ never unscaled loss) -- on the synthetic scene for N_STEPS steps and several see
 ``Trainer`` (device RNG, refreshes on) on the same scene from the same initial parameters and holds the seed-mean curves together.
 
     python oracle/make_psnr_curve.py [--seeds 0 1 2] [--steps 300] [--out tests/golden/G17_psnr_curve.json]
+    python oracle/make_psnr_curve.py --replay --seeds 0 1 --out tests/golden/G18_psnr_replay.json
+
+``--replay``: every random choice (ray order, sampling jitter, refresh jitter) comes from the streams the HIP harness defines for
+``TrainConfig(seed, host_shuffle=True)`` (restated in ``reference_training(replay=...)``), so the GPU run walks the same rays with the
+same jitter and the two PSNR curves can be held together directly -- no seed statistics (G18); without it the port draws from its
+own numpy generator, as two machines running the reference would (G17: compared through seed means).
 
 The scene is ``tinynerf_amd.rays.synthetic_scene`` (an input generator shared with the GPU test, not a product path).
 """
@@ -52,8 +58,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "G17_psnr_curve.json"))
+    ap.add_argument("--replay", action="store_true")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    args.out = args.out or os.path.join(ROOT, "tests", "golden", "G18_psnr_replay.json" if args.replay else "G17_psnr_curve.json")
     (o, d, rgbs), (ho, hd, hrgb) = scene()
     o, d, rgbs = o.numpy(), d.numpy(), rgbs.numpy()
     ho, hd = ho.numpy(), hd.numpy()
@@ -74,10 +82,11 @@ def main():
         t0 = time.perf_counter()
         losses, _, counts = tp.reference_training(initial_state(seed), o, d, rgbs, method=CONFIG["method"], batch_size=CONFIG["batch_size"],
                                                   n_samples=CONFIG["n_samples"], n_steps=args.steps, occupancy_res=CONFIG["occupancy_res"],
-                                                  stochastic_seed=1000 + seed, eval_at=eval_at, eval_fn=eval_fn)
+                                                  eval_at=eval_at, eval_fn=eval_fn,
+                                                  **({"replay": {"seed": seed, "rank": 0}} if args.replay else {"stochastic_seed": 1000 + seed}))
         runs.append({"seed": seed, "psnr": {str(k): v for k, v in sorted(curve.items())}, "loss": losses,
                      "samples_per_step": [c[0] for c in counts], "rays_per_step": [c[1] for c in counts]})
-        json.dump({"config": CONFIG, "eval_at": eval_at, "steps": args.steps, "torch": torch.__version__, "runs": runs,
+        json.dump({"config": CONFIG, "eval_at": eval_at, "steps": args.steps, "torch": torch.__version__, "runs": runs, "replay": bool(args.replay),
                    "made_by": "oracle/make_psnr_curve.py (CPU port of the reference's train(), stochastic mode)"},
                   open(args.out, "w"), indent=1)
 

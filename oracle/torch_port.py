@@ -266,7 +266,8 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
                        method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
                        bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10, scene_type: str = "aabb",
                        scene_scale: float = 1.0, cobafa_freqs=None, occ_updates: int = 0, grid0=None, grids_out=None,
-                       stochastic_seed: Optional[int] = None, eval_at=(), eval_fn=None, on_step=None):
+                       stochastic_seed: Optional[int] = None, eval_at=(), eval_fn=None, on_step=None, replay: Optional[dict] = None,
+                       lr: float = 1e-2):
     """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
     shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
     including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts).
@@ -277,14 +278,22 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
     jitter ``t += U[0,1) * delta`` per candidate (core.py:172-173) and jittered voxel coordinates in the refresh (core.py:136), all
     from one numpy generator.  ``eval_fn(step, sd, grid, threshold)`` is called after ``step`` optimizer steps for every step in
     ``eval_at`` (the PSNR@step half of the metric, run.py:53-54).  ``on_step(step, sd, packed, info, target)`` is called with the
-    parameters and the dynamic batch of every step right before its forward pass (gradient parity ALONG the reference's trajectory)."""
+    parameters and the dynamic batch of every step right before its forward pass (gradient parity ALONG the reference's trajectory).
+    ``replay = {"seed": s, "rank": r}``: stochastic like ``stochastic_seed`` but every random choice is taken from the streams the HIP
+    harness defines for ``TrainConfig(seed=s, host_shuffle=True)`` (tinynerf_amd/run.py), which stand in for torch's global RNG there:
+    ray order = successive ``torch.randperm(M, generator=Generator().manual_seed(s * 1000003 + r + 1), dtype=int32)`` walked in
+    loader batches (an epoch's unread tail is continued by the next permutation -- the harness' documented deviation from the partial
+    last batch of a DataLoader); sampling jitter of the step's b-th loader batch, ray i, candidate k = ``orc.uniform01(jitter_seed(s,
+    step, r), (b * B + i) * S + k)``; voxel jitter of a refresh = ``orc.uniform01(refresh_seed(s, step), ((slice * H * W + h * W + w) * 3
+    + c)``.  With the same parameters the two sides then walk the SAME rays with the SAME jitter: their trajectories differ by fp32
+    summation order only (tests/test_hip_psnr.py, golden G18)."""
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v.clone())
           for k, v in sd0.items()}
     params = [v for v in sd.values() if v.requires_grad]
     bs_ratio = 4096 / batch_size
     steps = int(2048 * bs_ratio)
     occ_updates = occ_updates or int(16 * bs_ratio)
-    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    opt = torch.optim.Adam(params, lr=lr, eps=1e-15, weight_decay=1e-5)          # (lr: test knob; run.py:110 has 1e-2)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[steps // 2, steps * 3 // 4, steps * 5 // 6, steps * 9 // 10], gamma=0.33)
     aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
     # run.py:154-162: aabb scenes march the box, unbounded ones the Mip-NeRF-360 table with the inf-norm contraction
@@ -308,6 +317,24 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
                 idx = perm[b0:b0 + batch_size]
                 yield rays_o[idx], rays_d[idx], rgbs[idx]
     stream = shuffled_loader() if rng is not None else None
+    if replay is not None:
+        assert rng is None, "replay and stochastic_seed exclude each other"
+        import hashlib
+        r_seed, r_rank = int(replay["seed"]), int(replay.get("rank", 0))
+        host_gen = torch.Generator().manual_seed(r_seed * 1000003 + r_rank + 1)
+
+        def replay_loader():            # tinynerf_amd/run.py Trainer._epoch_block with cfg.host_shuffle
+            buf = np.empty(0, np.int64)
+            while True:
+                while buf.shape[0] < batch_size:
+                    buf = np.concatenate([buf, torch.randperm(M, generator=host_gen, dtype=torch.int32).numpy().astype(np.int64)])
+                idx, buf = buf[:batch_size], buf[batch_size:]
+                yield rays_o[idx], rays_d[idx], rgbs[idx]
+        stream = replay_loader()
+
+        def jitter_seed(step):          # tinynerf_amd/run.py jitter_seed
+            h = int.from_bytes(hashlib.blake2b(b"tinynerf-jitter:%d:%d" % (r_seed, step), digest_size=8).digest(), "little")
+            return (h & (2 ** 62 - 1)) * 2 + 1 + r_rank
 
     def sigma_np(pts: np.ndarray) -> np.ndarray:
         with torch.no_grad():
@@ -327,6 +354,15 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
                 yield rays_o[idx], rays_d[idx], rgbs[idx]
                 c += batch_size
         jit_of = (lambda o: None) if rng is None else (lambda o: rng.random((o.shape[0], n_samples), dtype=np.float32))
+        if replay is not None:
+            calls = []
+
+            def jit_of(o, calls=calls, seed=jitter_seed(step)):          # b-th loader batch of the step: rays b * B .. of the block
+                r0 = len(calls) * batch_size
+                calls.append(r0)
+                ctr = (np.arange(r0, r0 + o.shape[0], dtype=np.uint64)[:, None] * np.uint64(n_samples)
+                       + np.arange(n_samples, dtype=np.uint64)[None, :])
+                return orc.uniform01(seed, ctr)
         if scene_type == "aabb":
             prov = lambda o, d: orc.ray_provider(o, d, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
                                                  n_samples=n_samples, near=0.1, aabb=aabb, jitter=jit_of(o))
@@ -337,7 +373,12 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
         packed, info, target, k = orc.dynamic_batch(batches() if stream is None else stream, prov, target_size)
         cursor = (cursor + k * batch_size) % M
         if step % occ_updates == 0:
-            if rng is None:
+            if replay is not None:
+                rs = (r_seed * 7919 + 104729 * (step + 1)) % (2 ** 62)      # tinynerf_amd/run.py refresh_seed
+                per = occupancy_res * occupancy_res * 3
+                jit = [orc.uniform01(rs, np.uint64(i * per) + np.arange(per, dtype=np.uint64)).reshape(occupancy_res, occupancy_res, 3)
+                       for i in range(occupancy_res)]
+            elif rng is None:
                 jit = [np.full((occupancy_res, occupancy_res, 3), 0.5, np.float32)] * occupancy_res
             else:
                 jit = [rng.random((occupancy_res, occupancy_res, 3), dtype=np.float32) for _ in range(occupancy_res)]

@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    try:            # the CPU port (oracle/torch_port.py) on a 256-thread host: torch's CPU kernels run 140x slower with every hardware
+        import torch            # thread than with 32 -- and the checker's time is most of the GPU suite's
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:           # noqa: BLE001
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

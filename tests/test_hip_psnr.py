@@ -1,15 +1,19 @@
 """PSNR@step -- the second half of BASELINE.json's metric -- of the HIP Trainer against the CPU port of the reference's train().
 
-Golden: ``tests/golden/G17_psnr_curve.json`` (``oracle/make_psnr_curve.py``, build container): held-out PSNR (run.py:53-54) of
-``oracle/torch_port.reference_training`` in its stochastic form -- the loop as the reference runs it: shuffled loader stream,
-``t += U * delta`` sampling jitter, jittered occupancy refreshes every 64 steps, Adam + MultiStepLR, the never-unscaled 2^10 loss
-scale -- on the synthetic scene (20 training views + 1 held-out view at 100 x 100, B = 1024, S = 128, 128^3 occupancy grid, full
-128/256/512 K-Planes), 300 steps, several seeds.  Here the production path runs the same recipe on the same scene FROM THE SAME
-INITIAL PARAMETERS per seed (device RNG for shuffling / jitter / refresh, side-stream sampler prefetch, fused kernels, TV folded
-into Adam): the two sides share no random stream -- as two runs of the reference on two machines would not -- so single curves
-differ by the recipe's own seed-to-seed noise and the SEED MEANS are compared.  Gate (north star): within 0.1 dB at equal step
-count wherever the means are determined that well -- the test derives the standard error of each mean from the spread over
-seeds it measures itself, asserts 0.1 dB + 2 standard errors, and requires the standard error itself to stay below 0.1 dB."""
+Both goldens come from ``oracle/make_psnr_curve.py`` (build container): ``oracle/torch_port.reference_training`` -- the loop as the
+reference runs it (run.py:97-319): shuffled loader stream, ``t += U * delta`` sampling jitter, jittered occupancy refreshes every 64
+steps, Adam + MultiStepLR, the never-unscaled 2^10 loss scale -- on the synthetic scene (20 training views + 1 held-out view at
+100 x 100, B = 1024, S = 128, 128^3 occupancy grid, full 128 / 256 / 512 K-Planes), 300 steps, held-out PSNR (run.py:53-54) every 50.
+
+* **G18 (replay): the gate.**  The port takes every random choice from the streams the HIP harness defines (host permutation of the
+  rays, counter RNG for the sampling and refresh jitter, restated in the oracle and pinned bit for bit by tests/test_hip_core.py and
+  tests/test_hip_training.py).  The production path (side-stream sampler prefetch, fused gather / scatter kernels, TV folded into
+  Adam, device-side batch rule) then walks the SAME rays with the SAME jitter from the SAME initial parameters: what is left is fp32
+  summation order, amplified by Adam.  PSNR at equal step count must agree within 0.1 dB (north star) at 50, 100, 200 and 300 steps,
+  the first steps' dynamic batches must have the same size and their losses agree to 1e-4.
+* **G17 (independent streams): a cross-check.**  The port draws from its own numpy generator, as a second machine running the
+  reference would.  Single curves then differ by the recipe's seed-to-seed noise (0.2 dB at 50 steps, 0.7 - 1 dB later: measured
+  here over 16 seeds), so seed means are compared, within 2.5 standard errors of their difference."""
 import json
 import os
 
@@ -19,61 +23,69 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G17_psnr_curve.json")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CHECK_AT = (50, 100, 200, 300)
-GPU_SEEDS = tuple(range(8))
 
 
-def _run(seed, cfg_g, o, d, rgbs, ho, hd, hrgb, eval_at):
+def _scene(c):
+    from tinynerf_amd import rays
+    o, d, rgbs, _, _ = rays.synthetic_scene(n_views=c["n_views"], res=c["res"], seed=c["scene_seed"], device=DEV)
+    n_train = (c["n_views"] - 1) * c["res"] ** 2
+    return (o[:n_train].contiguous(), d[:n_train].contiguous(), rgbs[:n_train].contiguous()), (o[n_train:], d[n_train:], rgbs[n_train:])
+
+
+def _run(seed, c, train, held, eval_at, host_shuffle):
     from tinynerf_amd.run import TrainConfig, Trainer, psnr
     dev = torch.device(DEV)
-    cfg = TrainConfig(method=cfg_g["method"], scene_type="aabb", batch_size=cfg_g["batch_size"], n_samples=cfg_g["n_samples"], seed=seed,
-                      occupancy_res=cfg_g["occupancy_res"])
-    tr = Trainer(cfg, o, d, rgbs, torch.ones(3, device=dev), dev)
-    curve = {}
+    cfg = TrainConfig(method=c["method"], scene_type="aabb", batch_size=c["batch_size"], n_samples=c["n_samples"], seed=seed,
+                      occupancy_res=c["occupancy_res"], host_shuffle=host_shuffle)
+    tr = Trainer(cfg, *train, torch.ones(3, device=dev), dev)
+    curve, losses, counts = {}, [], []
     for step in range(max(eval_at) + 1):
         if step in eval_at:
             with torch.no_grad():
-                curve[step] = float(psnr(tr.render_rays(ho, hd), hrgb))
+                curve[step] = float(psnr(tr.render_rays(held[0], held[1]), held[2]))
         if step < max(eval_at):
-            tr.step()
-    return curve, tr
+            st = tr.step()
+            counts.append(int(st["n_samples"]))
+            if step < 16:
+                losses.append(tr.loss_value())
+    assert all(torch.isfinite(p).all().item() for p in tr.renderer.parameters())
+    return curve, losses, counts
 
 
-def test_psnr_at_step_matches_the_reference_recipe():
-    from tinynerf_amd import rays
-    g = json.load(open(GOLDEN))
-    c = g["config"]
-    eval_at = [int(e) for e in g["eval_at"]]
-    assert g["steps"] >= 300 and all(s in eval_at for s in CHECK_AT) and len(g["runs"]) >= 3
-    o, d, rgbs, _, _ = rays.synthetic_scene(n_views=c["n_views"], res=c["res"], seed=c["scene_seed"], device=DEV)
-    per = c["res"] ** 2
-    n_train = (c["n_views"] - 1) * per
-    ho, hd, hrgb = o[n_train:], d[n_train:], rgbs[n_train:]
-    o, d, rgbs = o[:n_train].contiguous(), d[:n_train].contiguous(), rgbs[:n_train].contiguous()
-    ref = np.array([[run["psnr"][str(s)] for s in eval_at] for run in g["runs"]])            # [ref seeds, eval points]
-    got = []
-    for seed in GPU_SEEDS:
-        curve, tr = _run(seed, c, o, d, rgbs, ho, hd, hrgb, eval_at)
-        got.append([curve[s] for s in eval_at])
-        assert all(torch.isfinite(p).all().item() for p in tr.renderer.parameters())
-        del tr
-    got = np.array(got)
-    # step 0: the same parameters on both sides (seed s <-> seed s), inference path against the CPU port: no randomness at all
-    n0 = min(len(g["runs"]), len(GPU_SEEDS))
-    by_seed = {run["seed"]: run for run in g["runs"]}
-    for k, seed in enumerate(GPU_SEEDS[:n0]):
-        if seed in by_seed:
-            assert abs(got[k, eval_at.index(0)] - by_seed[seed]["psnr"]["0"]) < 2e-3, (seed, got[k, 0], by_seed[seed]["psnr"]["0"])
+def test_psnr_at_step_on_the_reference_trajectory():
+    """G18: same rays, same jitter, same initial parameters -> PSNR@step within 0.1 dB of the CPU port of the reference."""
+    g = json.load(open(os.path.join(GOLDEN, "G18_psnr_replay.json")))
+    assert g["replay"] and g["steps"] >= 300
+    c, eval_at = g["config"], [int(e) for e in g["eval_at"]]
+    train, held = _scene(c)
+    report = {}
+    for run in g["runs"]:
+        curve, losses, counts = _run(run["seed"], c, train, held, eval_at, host_shuffle=True)
+        # the first refresh-free stretch: the same grid on both sides, so bit-identical rays + jitter give the same batch sizes
+        assert counts[:8] == run["samples_per_step"][:8], (counts[:8], run["samples_per_step"][:8])
+        np.testing.assert_allclose(losses[:8], run["loss"][:8], rtol=1e-4)
+        report[run["seed"]] = {s: (round(curve[s], 3), round(run["psnr"][str(s)], 3)) for s in eval_at}
+        for s in (0,) + CHECK_AT:
+            assert abs(curve[s] - run["psnr"][str(s)]) < (2e-3 if s == 0 else 0.1), (run["seed"], s, report[run["seed"]])
+    print("PSNR@step (HIP, CPU port of the reference) per seed:", report)
+    assert all(v[300][0] > v[0][0] + 3.0 for v in report.values())              # and it learns
+
+
+def test_psnr_at_step_seed_means_with_independent_streams():
+    """G17: no shared random stream -- seed means within 2.5 standard errors of their difference; 16 seeds here."""
+    g = json.load(open(os.path.join(GOLDEN, "G17_psnr_curve.json")))
+    assert not g.get("replay") and g["steps"] >= 300 and len(g["runs"]) >= 3
+    c, eval_at = g["config"], [int(e) for e in g["eval_at"]]
+    train, held = _scene(c)
+    ref = np.array([[run["psnr"][str(s)] for s in eval_at] for run in g["runs"]])
+    got = np.array([[_run(seed, c, train, held, eval_at, host_shuffle=False)[0][s] for s in eval_at] for seed in range(16)])
     report = {}
     for s in CHECK_AT:
         i = eval_at.index(s)
-        m_ref, m_got = ref[:, i].mean(), got[:, i].mean()
         se = float(np.sqrt(ref[:, i].var(ddof=1) / ref.shape[0] + got[:, i].var(ddof=1) / got.shape[0]))
-        report[s] = (round(float(m_got), 3), round(float(m_ref), 3), round(se, 3))
-    print("PSNR@step (HIP mean, reference-port mean, standard error of the difference):", report)
+        report[s] = (round(float(got[:, i].mean()), 3), round(float(ref[:, i].mean()), 3), round(se, 3))
+    print("PSNR@step seed means (HIP over 16 seeds, CPU port over %d seeds, standard error of the difference):" % ref.shape[0], report)
     for s, (m_got, m_ref, se) in report.items():
-        assert se < 0.1, (s, report)                               # the comparison must be able to see 0.1 dB
-        assert abs(m_got - m_ref) <= 0.1 + 2.0 * se, (s, report)   # north-star gate + the measured noise of the two means
-    # and it learns: > 4 dB over the initial image within 300 steps on both sides
-    assert got[:, eval_at.index(300)].mean() > got[:, eval_at.index(0)].mean() + 4.0
+        assert abs(m_got - m_ref) <= 2.5 * max(se, 0.05), (s, report)

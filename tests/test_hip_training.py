@@ -357,18 +357,15 @@ def test_trainer_batch_with_device_rng_matches_the_oracle_bit_for_bit():
     grid = torch.where(xx * xx + yy * yy + zz * zz < 0.3, 1.0, 0.003) * (0.5 + 0.5 * torch.rand(32, 32, 32, generator=torch.Generator().manual_seed(1)))
     tr.occupancy_grid.grid.copy_(grid.to(dev))
     tr.occupancy_grid.mean = float(tr.occupancy_grid.grid.mean().item())
-    seeds = torch.Generator().manual_seed(cfg.seed + 17)                      # Trainer._occ_seed_gen
-    drawn = []
     aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
     o_np, d_np = o.numpy(), d.numpy()
     for it in range(3):
         packed, info, target, k = tr.build_batch()
-        # the seed of the pass that produced this batch: the next draw of the trainer's seed stream (two draws when the first
-        # candidate block was too small and had to be redrawn)
-        seed = tr.last_plan_seed
-        while not drawn or drawn[-1] != seed:
-            drawn.append(int(torch.randint(0, 2 ** 62, (1,), generator=seeds).item()) * 2 + 1)
-            assert len(drawn) <= 8, (drawn, seed)
+        # the seed of the pass that produced this batch: a pure function of (cfg.seed, batch number, rank), whether or not the first
+        # candidate block was too small and had to be redrawn (it is, here: k = 13 > the initial guess)
+        from tinynerf_amd.run import jitter_seed
+        seed = jitter_seed(cfg.seed, it, 0)
+        assert tr.last_plan_seed == seed
         idx = target[:, 0].long().cpu().numpy()
         R = idx.shape[0]
         assert R == k * B
@@ -423,9 +420,18 @@ def test_gradients_along_the_reference_trajectory(method, res, n_steps, matmul):
         def ref():
             return tp.grads_of(cur, lambda p: cfg.grad_scale * torch.nn.functional.mse_loss(
                 tp.render(p, pk, inf_, bg, vanilla_freqs=vf, cobafa_freqs=cf), tg))[0]
+        if not ref():
+            # "Empty iteration" (core.py:251-254: every sample masked -- the recipe's lr drives the 10-layer stack there within a
+            # few steps, on the CPU port exactly as here): the reference leaves every param.grad at None; here every gradient is 0
+            assert all(float(np.abs(v).max()) == 0.0 for v in got.values()), step
+            checked.append((step, -1))
+            return
         flips = assert_grads_match_up_to_relu_ties(dict(got), ref, 1e-4, weights_conditioning=True, cond_cap=2e-3)
         checked.append((step, flips))
     ref_losses, _, _ = tp.reference_training(sd0, o.numpy(), d.numpy(), rgb.numpy(), method=method, batch_size=256, n_samples=32,
-                                             n_steps=n_steps, occupancy_res=32, cobafa_freqs=cf, on_step=on_step)
-    assert len(checked) == n_steps
+                                             n_steps=n_steps, occupancy_res=32, cobafa_freqs=cf, on_step=on_step,
+                                             lr=1e-2 if method == "kplanes" else 1e-3)
+    # (the recipe's lr 1e-2 drives the two deep stacks into the all-masked branch after two steps on this scene -- in the port as
+    # here; with 1e-3 the trajectory keeps real gradients.  The HIP optimizer plays no part: parameters come from the port.)
+    assert len(checked) == n_steps and sum(1 for _, f in checked if f >= 0) >= 4, checked       # steps with a real gradient
     np.testing.assert_allclose(hip_losses, ref_losses, rtol=2e-5)     # every step's loss (MSE + TV), on identical parameters

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         __syncthreads();
     }
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: tile indices and workspace bases are scalars
     const int64_t n_tiles = (n + 31) >> 5;
 
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {

@@ -43,7 +43,10 @@ __device__ __forceinline__ void glds16(const float *src, float *dst) {
 
 template <int H> struct B3Geom {
     static constexpr int T = H / 32;                // 32-row blocks of the layer's input and of its output
-    static constexpr int BPW = H / 128;             // blocks per wave: 2 for H = 256 (one wave per SIMD, 512 registers), 1 for H = 128
+#ifndef TN_B3_BPW256
+#define TN_B3_BPW256 2
+#endif
+    static constexpr int BPW = H == 256 ? TN_B3_BPW256 : 1;   // blocks per wave: 2 for H = 256 (one wave per SIMD, 512 registers), 1 for H = 128
     static constexpr int WPS = T / BPW;             // waves per tile stream (4)
     static constexpr int STREAMS = H == 256 ? 1 : 2;
     static constexpr int THREADS = STREAMS * WPS * 64;

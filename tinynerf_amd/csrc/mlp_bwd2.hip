@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         __syncthreads();
     }
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: tile indices and workspace bases are scalars
     const int64_t n_tiles = (n + 31) >> 5;
     const int G0 = a.K0_pad >> 3;
     const int out = a.out_dim;

@@ -53,6 +53,24 @@ class TrainConfig:
     # whatever N is and "PSNR at equal step count" keeps its meaning; the schedule (steps, refresh period, LR milestones) follows
     # the GLOBAL batch_size.  shard = 1 with N > 1 is weak scaling: every rank runs the recipe's batch (N x the samples per step)
     shard: int = 1
+    # the shuffled ray stream from the HOST generator (torch.randperm on the CPU, uploaded once per epoch) instead of the device's:
+    # a stream that any machine can regenerate -- oracle/torch_port.reference_training(replay=...) walks the same rays -- at the
+    # price of one host permutation + upload per epoch (fine for parity runs, not for the 12.8 M-ray tables of the bench)
+    host_shuffle: bool = False
+
+
+def jitter_seed(seed: int, batch_no: int, rank: int = 0) -> int:
+    """Seed of the sampler's counter RNG (csrc/tn_common.h tn::uniform01) for the ``batch_no``-th dynamic batch of a run: a pure
+    function of (TrainConfig.seed, batch number, rank) -- not of how often a candidate block had to be redrawn or of whether the
+    pass was prefetched -- so that a run's sampling jitter can be regenerated anywhere (oracle/tinynerf_oracle.sampler_jitter)."""
+    import hashlib
+    h = int.from_bytes(hashlib.blake2b(b"tinynerf-jitter:%d:%d" % (seed, batch_no), digest_size=8).digest(), "little")
+    return (h & (2 ** 62 - 1)) * 2 + 1 + rank
+
+
+def refresh_seed(seed: int, train_step: int) -> int:
+    """Seed of the voxel jitter of the occupancy refresh at ``train_step`` (the same on every rank: identical grids)"""
+    return (seed * 7919 + 104729 * (train_step + 1)) % (2 ** 62)
 
 
 def build_renderer(cfg: TrainConfig, bg_color: Optional[torch.Tensor], device: torch.device):
@@ -137,7 +155,8 @@ class Trainer:
         # per-rank ray stream over the rank's own ray table (see _epoch_block): same generator family, different seed
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(cfg.seed * 1000003 + rank + 1)
-        self._occ_seed_gen = torch.Generator().manual_seed(cfg.seed + 17)   # same on all ranks: identical grids
+        self._host_gen = torch.Generator().manual_seed(cfg.seed * 1000003 + rank + 1)       # cfg.host_shuffle
+        self._batch_no = 0               # dynamic batches handed out so far (seeds the sampling jitter: jitter_seed)
         self.last: Dict[str, float] = {}
         self.grad_hook: Optional[Callable[["Trainer"], None]] = None   # called with the final (reduced) gradients, before Adam
         self._early: Dict[int, object] = {}              # all-reduces started during the backward pass (N > 1)
@@ -210,7 +229,10 @@ class Trainer:
             if self._perm is not None:
                 self._graveyard += [self._perm, self._carry]        # still read by the `cat` below, possibly on the other stream
                 self._carry = torch.cat([self._carry, self._perm[self._perm_pos:]])
-            self._perm = torch.randperm(n_rays, device=self.device, generator=self._gen, dtype=torch.int32)
+            if self.cfg.host_shuffle:
+                self._perm = torch.randperm(n_rays, generator=self._host_gen, dtype=torch.int32).to(self.device)
+            else:
+                self._perm = torch.randperm(n_rays, device=self.device, generator=self._gen, dtype=torch.int32)
             self._perm_pos = 0
         c = self._carry.numel()
         if c == 0:
@@ -253,7 +275,7 @@ class Trainer:
         L.call("tn_gather_rays", dev, L.ptr(self.rays_o), L.ptr(self.rays_d), L.ptr(self.rgbs), L.ptr(idx), C.c_int64(R_all), L.ptr(o), L.ptr(d),
                L.ptr(rgb))
         desc = self.ray_provider._desc(dev, not cfg.deterministic, None)
-        desc.seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._occ_seed_gen).item()) * 2 + 1 + self.rank
+        desc.seed = jitter_seed(cfg.seed, self._batch_no, self.rank)       # (a redrawn block repeats it: same rays, same jitter)
         maskbits = self._buf("maskbits", (R_all, n_chunks), torch.int64)
         counts = self._buf("counts", (R_all,), torch.int32)
         plan = self._buf("plan", (4,), torch.int32)
@@ -288,6 +310,7 @@ class Trainer:
                 break
             self._k_guess = pend["n_b"] * 2             # not enough rays drawn: redraw a larger block
         self._k_guess = k
+        self._batch_no += 1
         self.last_plan_seed = int(pend["desc"].seed)      # (the counter RNG's seed of this batch's sampling jitter: tests feed it to the oracle)
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         if not self.cfg.deterministic:
@@ -327,7 +350,7 @@ class Trainer:
                 r = cfg.occupancy_res
                 jit = torch.full((r, r, r, 3), 0.5, device=self.device)
             # same jitter on every rank (identical grids without communication); a dedicated seed, not the global RNG
-            self.occupancy_grid.update(self.sigma_fn, jitters=jit, seed=(cfg.seed * 7919 + 104729 * (self.train_step + 1)) % (2 ** 62))
+            self.occupancy_grid.update(self.sigma_fn, jitters=jit, seed=refresh_seed(cfg.seed, self.train_step))
             self._refresh_reduce_rows()
         ray_count = None
         if self.world > 1:                 # global ray count of the step (see global_ray_count): travels during the forward pass

@@ -442,10 +442,13 @@ def main():
     if rank == 0:
         from tinynerf_amd.run import psnr as psnr_fn
         ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=800, seed=10_007, device=str(dev))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        img = tr.render_rays(ho, hd)
-        torch.cuda.synchronize()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # (chunks of pure background print the reference's "Empty iteration" line:
+            tr.render_rays(ho, hd)                        # core.py:253 -- stdout carries the JSON line only); warm-up: scratch arenas
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = tr.render_rays(ho, hd)
+            torch.cuda.synchronize()
         psnr_at_step = {"step": tr.train_step, "psnr": float(psnr_fn(img, hrgb)), "render_ms": (time.perf_counter() - t0) * 1e3,
                         "view": "held-out 800x800 camera (rays.synthetic_scene(n_views=1, seed=10007)), inference path (training=False sampling)",
                         "samples_per_step": samples / args.steps,

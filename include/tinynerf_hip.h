@@ -364,7 +364,11 @@ int tn_cobafa_bwd(const tn_cobafa_desc *desc, const float *x, int64_t n, const f
  * wave gathers the 3 x 3 planes x 4 taps of its 32 samples straight into the first-layer MFMA operand registers of both
  * heads; `feat` [n, 96] is written once for the backward (weight gradient of the first layers, plane scatter) and never read
  * here.  Requirements: 3 scales x 32 channels, all planes present, both heads as in tn_mlp_fwd_stash_pair with in_dim 96.
- * Results are bit-identical to the two-launch sequence. */
+ * Results are bit-identical to the two-launch sequence.
+ * Inference form (round 4): workspace == partner_workspace == NULL -- nothing is stashed and `feat` is not written (it may be
+ * NULL; coords must then be 16-byte aligned): gather + sigma + colour of EVERY sample in one launch, for renders in which most
+ * samples carry weight (the caller composites with tn_render_rays_fwd; samples with w == 0 contribute exactly 0 either way,
+ * core.py:243-249).  The gated sequence tn_kplanes_mlp_fwd -> tn_weights_fwd -> tn_mlp_fwd(row_gate) wins when most tiles are dead. */
 int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kdesc, const float *coords, int64_t coord_stride, const tn_mlp_desc *desc,
                             const tn_mlp_desc *partner, const float *aux, int64_t n, float *feat, float *y, float *partner_y,
                             void *workspace, int64_t workspace_bytes, void *partner_workspace, int64_t partner_workspace_bytes,

@@ -33,6 +33,7 @@ from oracle import torch_port as tp                 # noqa: E402
 
 CONFIG = dict(n_views=21, res=100, batch_size=1024, n_samples=128, occupancy_res=128, method="kplanes", scene_seed=0)
 EVAL_AT = (0, 50, 100, 150, 200, 250, 300)
+EVAL_AT_REPLAY = (0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 125, 150, 200, 250, 300)
 
 
 def scene():
@@ -67,7 +68,7 @@ def main():
     ho, hd = ho.numpy(), hd.numpy()
     aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
     bg = torch.ones(3)
-    eval_at = [e for e in EVAL_AT if e <= args.steps]
+    eval_at = [e for e in (EVAL_AT_REPLAY if args.replay else EVAL_AT) if e <= args.steps]
     runs = []
     for seed in args.seeds:
         curve = {}

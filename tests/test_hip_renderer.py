@@ -146,3 +146,51 @@ def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypa
     np.testing.assert_allclose(res[True][2].cpu().numpy(), res[True][0].cpu().numpy(), rtol=0, atol=1e-6)      # eval == train forward
     for k, g in res[True][1].items():         # every gradient ends in fp32 atomics: same terms, different order
         np.testing.assert_allclose(g.cpu().numpy(), res[False][1][k].cpu().numpy(), rtol=0, atol=2e-6 * float(g.abs().max()), err_msg=k)
+
+
+@pytest.mark.parametrize("n_rays,per_ray,sigma_bias", [(37, 29, 0.0), (300, 113, 0.0), (300, 113, 6.0), (1, 1, 0.0)])
+def test_inference_pair_form_is_bit_identical_to_the_gated_form(n_rays, per_ray, sigma_bias, monkeypatch):
+    """Round 4: the inference render has two forms -- gather + sigma head -> weights -> colour head on the live tiles -> composite
+    (core.py:239-265 as the reference runs it), and gather + BOTH heads of every sample in one launch (tn_kplanes_mlp_fwd_pair with
+    NULL workspaces) -> weights + composite.  A sample with w == 0 contributes exactly 0 in both, every other sample runs the same
+    MFMA sequence: the rendered colours must be the same bits, with a thin medium (every sample live) and with a dense one (sigma
+    bias + 6: rays terminate, most tiles dead).  The switch follows the live fraction of the previous call without a host sync."""
+    from tinynerf_amd import core, fused, models as m
+    torch.manual_seed(n_rays + int(sigma_bias))
+    field = m.KPlanesFeatureField(32, (16, 40, 96))
+    r = core.NerfRenderer(field, m.VanillaOpacityDecoder(96), m.VanillaColorDecoder(8, 96, 64, 3), torch.ones(3)).to(DEV)
+    with torch.no_grad():
+        r.sigma_decoder.net.net[2].bias += sigma_bias
+    cnt = torch.randint(0 if n_rays > 1 else 1, per_ray + 1, (n_rays,), dtype=torch.int32)
+    info = torch.stack([torch.cumsum(cnt, 0, dtype=torch.int32) - cnt, cnt], -1).to(DEV)
+    n = int(cnt.sum())
+    packed = torch.rand(n, 7, device=DEV)
+    packed[:, :3] = packed[:, :3] * 2.2 - 1.1
+    packed[:, 3:6] = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=DEV), dim=-1)[torch.repeat_interleave(
+        torch.arange(n_rays, device=DEV), cnt.to(DEV).long())]
+    packed[:, 6] = 0.05
+    outs, calls = {}, []
+    orig = fused.L.call
+    monkeypatch.setattr(fused.L, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    with torch.no_grad():
+        for form in (False, True):
+            monkeypatch.setattr(fused, "INFER_PAIR", form)
+            r.__dict__.pop("_stats", None)                       # a fresh renderer state: the field counts as alive
+            del calls[:]
+            outs[form] = r(packed, info).clone()
+            assert ("tn_kplanes_mlp_fwd_pair" in calls) == form and ("tn_kplanes_mlp_fwd" in calls) == (not form), calls
+        assert torch.equal(outs[True], outs[False])
+        # the switch: after a call on a dead field (live fraction below the bar) the next call takes the gated form, and back
+        torch.cuda.synchronize()
+        st = r._stats["infer_live"]
+        live = float(st["pinned"][0])
+        with torch.no_grad():
+            w_live = float((core.NerfWeights.apply(r.sigma_decoder(r.feature_module(packed[:, :3])).ravel(), packed[:, 6].contiguous(), info, 1e-4) > 0)
+                           .float().mean()) if n else 1.0
+        assert abs(live - w_live) < 1e-6
+        del calls[:]
+        out3 = r(packed, info)
+        assert ("tn_kplanes_mlp_fwd_pair" in calls) == (live >= fused.INFER_PAIR_MIN_LIVE), (live, calls)
+        assert torch.equal(out3, outs[False])
+    if sigma_bias > 0:
+        assert live < 0.5, live                                  # the dense medium really is mostly dead

@@ -42,6 +42,7 @@ struct KpFwd {
     const float *coords;
     int64_t coord_stride;
     float *feat;
+    int write_feat = 1;            // 0: inference pair (nobody reads the rows; `feat` is then only a valid dummy address)
 };
 
 // FAST: every head takes the plain-column first layer (TN_ENC_NONE with in_dim % 4 == 0, or TN_ENC_AUX_CAT).  Compiled
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 fr[4 * sc + q] = f32x4{prod[q][0], prod[q][1], prod[q][2], prod[q][3]};
-                if (valid) *reinterpret_cast<tn::f32x4k *>(kp.feat + row * 96 + 32 * sc + 8 * q + 4 * h) = prod[q];
+                if (valid && (STASH || !PAIR || kp.write_feat)) *reinterpret_cast<tn::f32x4k *>(kp.feat + row * 96 + 32 * sc + 8 * q + 4 * h) = prod[q];
             }
         }
       }
@@ -384,9 +385,9 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
             if (rc) return rc;
         } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: the register-resident training forward is built for width 64");
     } else if (wlds && kp) {      // inference: gather + one head (the sigma head; the colour head then reads the feature rows where w > 0)
-        if constexpr (H == 64) {
+        if constexpr (H == 64) {          // ... or gather + BOTH heads, nothing stashed, no feature rows (pair != nullptr)
             if (!fast) return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd: the head must take the plain-column first layer");
-            auto kern = mlp_fwd_kernel<H, true, 12, false, false, true, true>;
+            auto kern = pair ? mlp_fwd_kernel<H, true, 12, false, true, true, true> : mlp_fwd_kernel<H, true, 12, false, false, true, true>;
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (12 * 64)));
@@ -551,8 +552,10 @@ extern "C" int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kd, const float *c
                "tn_kplanes_mlp_fwd_pair: 3 scales x 32 channels feeding two heads with in_dim 96 (run.py:136-139)");
     TN_REQUIRE(coord_stride >= 3, TN_E_SIZE, "tn_kplanes_mlp_fwd_pair: bad coordinate stride");
     if (n <= 0) return n == 0 ? TN_OK : tn::fail(TN_E_SIZE, "tn_kplanes_mlp_fwd_pair: negative n");
-    TN_REQUIRE(coords && feat, TN_E_NULL, "tn_kplanes_mlp_fwd_pair: null pointer");
+    const bool inference = workspace == nullptr && partner_workspace == nullptr;
+    TN_REQUIRE(coords && (feat || inference), TN_E_NULL, "tn_kplanes_mlp_fwd_pair: null pointer");
     TN_REQUIRE(((uintptr_t)feat & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd_pair: feat must be 16-byte aligned");
+    TN_REQUIRE(!inference || ((uintptr_t)coords & 15) == 0, TN_E_ALIGN, "tn_kplanes_mlp_fwd_pair: coords must be 16-byte aligned");
     KpFwd kp;
     for (int s = 0; s < 3; ++s) {
         TN_REQUIRE(kd->height[s] > 0 && kd->width[s] > 0 && (int64_t)kd->height[s] * kd->width[s] * 32 < (1ll << 30), TN_E_SIZE,
@@ -565,6 +568,13 @@ extern "C" int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kd, const float *c
         }
     }
     kp.coords = coords; kp.coord_stride = coord_stride; kp.feat = feat;
+    if (inference) {        // no backward follows: no workspace rows, no feature rows (the dummy operand line points at the coordinates)
+        kp.write_feat = 0;
+        if (!feat) {
+            TN_REQUIRE(n * coord_stride >= 4, TN_E_SIZE, "tn_kplanes_mlp_fwd_pair: inference form without feat needs >= 16 B of coordinates");
+            kp.feat = const_cast<float *>(coords);
+        }
+    }
     // the rest is tn_mlp_fwd_stash_pair with the x rows replaced by the gather
     const int H = desc->dims[1];
     TN_REQUIRE(H == 64 && partner->dims[1] == 64 && desc->n_layers >= 2 && desc->n_layers <= 5 && partner->n_layers >= 2 &&
@@ -573,8 +583,9 @@ extern "C" int tn_kplanes_mlp_fwd_pair(const tn_kplanes_desc *kd, const float *c
                TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: two width-64 heads (<= 5 layers, <= 4 outputs); partner without encoding");
     const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
     TN_REQUIRE(need_a > 0 && need_b > 0, TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: configuration not covered by the two-pass backward");
-    TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b && y && partner_y, TN_E_NULL,
-               "tn_kplanes_mlp_fwd_pair: workspace / output missing or too small");
+    TN_REQUIRE(y && partner_y && (inference || (workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b)),
+               TN_E_NULL, "tn_kplanes_mlp_fwd_pair: workspace / output missing or too small (both workspaces NULL: inference form)");
+    TN_REQUIRE(!inference || (desc->row_gate == nullptr && partner->row_gate == nullptr), TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: no row gates in the pair form");
     TN_REQUIRE((((uintptr_t)workspace | (uintptr_t)partner_workspace | (uintptr_t)partner_y | (uintptr_t)y) & 15) == 0, TN_E_ALIGN,
                "tn_kplanes_mlp_fwd_pair: buffers must be 16-byte aligned");
     FwdPair pr;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
 {
     constexpr int T = H / 32;
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
     const int L = a.n_layers, G0 = a.K0_pad >> 3, out = a.out_dim;
     const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_layer_kernel(DgradArgs a, int6
 {
     constexpr int T = H / 32;
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
     }
     __syncthreads();
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_lds_kernel(FwdLayerArgs a, int64
     }
     __syncthreads();
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
     const int n_ot = min(NOT, ((a.N + 31) >> 5) - ot0);
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(512) void wgrad_layer_kernel(WgradArgs a, const flo
                                                           const float *__restrict__ stash)
 {
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_tiles = (n + 31) >> 5;
     const int Tn = (a.N + 31) >> 5, Tk = (a.K_pad + 31) >> 5;
     const int total = Tn * Tk;

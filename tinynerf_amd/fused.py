@@ -95,6 +95,32 @@ def _upstream_is_gated(ctx: Any) -> bool:
     return bool(ctx.gate_in_slot and ctx.stats is not None and ctx.stats.get("upstream_gated"))
 
 
+INFER_PAIR = os.environ.get("TN_INFER_PAIR", "1") != "0"       # (0: always the gated inference form -- A/B, debugging)
+INFER_PAIR_MIN_LIVE = 0.6
+
+
+def _infer_prefers_pair(stats: Optional[dict]) -> bool:
+    """live-sample fraction (w > 0) of the previous inference call on this renderer, read without a host sync: the value travels
+    to pinned memory behind an event; until the first one has landed the field counts as alive"""
+    st = None if stats is None else stats.get("infer_live")
+    if st is None:
+        return True
+    if st["event"].query():
+        st["value"] = float(st["pinned"][0])
+    return st["value"] >= INFER_PAIR_MIN_LIVE
+
+
+def _note_live_fraction(stats: dict, weights: torch.Tensor) -> None:
+    st = stats.get("infer_live")
+    if st is None:
+        st = stats["infer_live"] = {"pinned": torch.ones(1, pin_memory=True), "event": torch.cuda.Event(), "value": 1.0}
+    elif not st["event"].query():
+        return                                   # the previous measurement is still in flight: keep it
+    if weights.numel():
+        st["pinned"].copy_((weights > 0).float().mean().reshape(1), non_blocking=True)
+        st["event"].record(torch.cuda.current_stream(weights.device))
+
+
 class _RenderKPlanes(Function):
     @staticmethod
     def forward(ctx: Any, packed: torch.Tensor, info: torch.Tensor, bg: Optional[torch.Tensor], thr: float,
@@ -122,7 +148,16 @@ class _RenderKPlanes(Function):
         gather_fused = pair and FUSE_GATHER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
         gather_sigma = (not train and FUSE_GATHER and F % 4 == 0 and sig_p[0].size(0) == 64 and kdesc.n_scales == 3 and kdesc.channels == 32
                         and len(keep) == 9)
-        if gather_sigma:   # inference: gather + sigma head in one launch
+        # inference, two forms with identical results (a sample with w == 0 contributes exactly 0 either way, core.py:243-249):
+        #   gated: gather + sigma head -> weights -> colour head on the 32-sample tiles that hold a weight -> composite;
+        #   pair:  gather + BOTH heads of every sample in one launch (no feature rows, nothing stashed) -> weights + composite.
+        # The pair wins while most tiles are alive (an untrained or half-trained field: 0.6 against 0.9 ms per 2^20 samples), the
+        # gated form once early termination has emptied most of them; the choice follows the live fraction of the previous call
+        infer_pair = gather_sigma and INFER_PAIR and rgb_p[0].size(0) == 64 and len(rgb_p) == 10 and _infer_prefers_pair(stats)
+        if infer_pair:
+            L.call("tn_kplanes_mlp_fwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(rdesc), C.byref(sdesc), L.ptr(table),
+                   C.c_int64(n), L.ptr(feat), L.ptr(rgbs), L.ptr(sigma), C.c_void_p(None), C.c_int64(0), C.c_void_p(None), C.c_int64(0))
+        elif gather_sigma:   # inference: gather + sigma head in one launch
             L.call("tn_kplanes_mlp_fwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(sdesc), C.c_int64(n), L.ptr(feat), L.ptr(sigma))
         elif gather_fused:   # gather + both heads in ONE launch: the feature rows go from the texel lines to the MFMA operands
             L.call("tn_kplanes_mlp_fwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.byref(rdesc), C.byref(sdesc), L.ptr(table),
@@ -146,7 +181,7 @@ class _RenderKPlanes(Function):
         # upstream gradient that arrives gated (tn_mse_grad_gated) -- see the "Empty iteration" note below
         gate_slot = _gate_slot(hint, covered and train)
         out = torch.empty((R, 3), device=dev)
-        if pair:
+        if pair or infer_pair:
             # both heads are done: weights and composite of a ray in one launch (tn_render_rays_fwd, bit-identical to the two)
             L.call("tn_render_rays_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(rgbs), L.ptr(info), L.ptr(bg), C.c_float(thr), L.ptr(weights),
                    L.ptr(out), L.ptr(gate_slot), C.c_int64(n), C.c_int64(R))
@@ -156,7 +191,7 @@ class _RenderKPlanes(Function):
         else:
             L.call("tn_weights_fwd", dev, L.ptr(sigma), L.ptr(steps), L.ptr(info), C.c_float(thr), L.ptr(weights),
                    C.c_int64(n), C.c_int64(R))
-        if pair:
+        if pair or infer_pair:
             pass
         elif ws_r is not None:
             L.call("tn_mlp_fwd_stash", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), L.ptr(ws_r), C.c_int64(rb))
@@ -164,9 +199,11 @@ class _RenderKPlanes(Function):
             rdesc.row_gate = weights.data_ptr()
             L.call("tn_mlp_fwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), C.c_int64(n), L.ptr(rgbs), C.c_void_p(None))
             rdesc.row_gate = None
-        if not pair:
+        if not (pair or infer_pair):
             L.call("tn_composite_fwd", dev, L.ptr(rgbs), L.ptr(weights), L.ptr(info), L.ptr(bg), L.ptr(out), C.c_void_p(None),
                    C.c_int64(n), C.c_int64(R))
+        if gather_sigma and INFER_PAIR and stats is not None:
+            _note_live_fraction(stats, weights)
         # core.py:246-254: when EVERY sample is masked (w == 0 everywhere) the reference renders the background from constants
         # that carry no graph, i.e. no parameter receives a gradient from the image loss; here the upstream gradient is gated
         # (a [1] tensor kept outside save_for_backward: with N > 1 the trainer all-reduces it in place right after this forward

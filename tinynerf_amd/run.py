@@ -54,7 +54,7 @@ class TrainConfig:
     # the GLOBAL batch_size.  shard = 1 with N > 1 is weak scaling: every rank runs the recipe's batch (N x the samples per step)
     shard: int = 1
     # the shuffled ray stream from the HOST generator (torch.randperm on the CPU, uploaded once per epoch) instead of the device's:
-    # a stream that any machine can regenerate -- oracle/torch_port.reference_training(replay=...) walks the same rays -- at the
+    # a stream that any machine can regenerate (the CPU checker's replay mode walks the same rays) at the
     # price of one host permutation + upload per epoch (fine for parity runs, not for the 12.8 M-ray tables of the bench)
     host_shuffle: bool = False
 
@@ -62,7 +62,7 @@ class TrainConfig:
 def jitter_seed(seed: int, batch_no: int, rank: int = 0) -> int:
     """Seed of the sampler's counter RNG (csrc/tn_common.h tn::uniform01) for the ``batch_no``-th dynamic batch of a run: a pure
     function of (TrainConfig.seed, batch number, rank) -- not of how often a candidate block had to be redrawn or of whether the
-    pass was prefetched -- so that a run's sampling jitter can be regenerated anywhere (oracle/tinynerf_oracle.sampler_jitter)."""
+    pass was prefetched -- so that a run's sampling jitter can be regenerated anywhere (the tests' CPU restatement of the counter RNG does)."""
     import hashlib
     h = int.from_bytes(hashlib.blake2b(b"tinynerf-jitter:%d:%d" % (seed, batch_no), digest_size=8).digest(), "little")
     return (h & (2 ** 62 - 1)) * 2 + 1 + rank
@@ -311,7 +311,7 @@ class Trainer:
             self._k_guess = pend["n_b"] * 2             # not enough rays drawn: redraw a larger block
         self._k_guess = k
         self._batch_no += 1
-        self.last_plan_seed = int(pend["desc"].seed)      # (the counter RNG's seed of this batch's sampling jitter: tests feed it to the oracle)
+        self.last_plan_seed = int(pend["desc"].seed)      # (the counter RNG's seed of this batch's sampling jitter: the tests read it)
         self._cursor = (self._cursor + R) % self.rays_o.size(0)
         if not self.cfg.deterministic:
             self._advance(R)

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinynerf_hip.so")
+LIB_PATH = os.environ.get("TN_LIB_PATH") or os.path.join(_HERE, "libtinynerf_hip.so")      # (TN_LIB_PATH: A/B of two builds on one box)
 
 TN_MLP_MAX_LAYERS = 12
 TN_KPLANES_MAX_SCALES = 4

@@ -5,9 +5,12 @@
 //
 // Forward / data gradient (fwd_b3_kernel / dgrad_b3_kernel): as in the fp32 form a wave owns 32-row blocks of the layer's
 // output and keeps their weights -- all K columns -- in registers for the whole launch, now as three packed-bf16 A operands per
-// 16-wide k step (12 registers per step and block), split once when the kernel starts.  H = 256: FOUR waves per workgroup, two
-// blocks each (384 weight registers of the 512 a lone wave on a SIMD may use: with two waves per SIMD the 192 registers of one
-// block leave no room for anything else); H = 128: four waves per tile stream, one block each, two streams per workgroup.
+// 16-wide k step (12 registers per step and block), split once when the kernel starts.  H = 256: EIGHT waves per workgroup, one
+// block each (TN_B3_BPW256 = 1, round 4: 192 weight registers of the 256 a wave may use with two waves per SIMD -- 250 VGPRs, no
+// spills; A / B on one box against four waves x two blocks, one wave per SIMD with 384 weight registers, the round-3 form
+// (TN_B3_BPW256 = 2): forward 757 -> 696 us, data gradient 634 -> 594 us per layer, Vanilla step 21.5 -> 20.8 ms: the second wave
+// of a SIMD issues MFMAs while the first one is in its epilogue, at the price of every B operand being read from LDS twice);
+// H = 128: four waves per tile stream, one block each, two streams per workgroup.
 // The 32-sample input tile reaches the workgroup through LDS as three bf16 planes [sample][feature] (B operand of a k step =
 // one ds_read_b128 per term, shared by the wave's blocks):
 //   * a wave's rows of the NEXT tile arrive by LDS-direct loads (global_load_lds_dwordx4) in an fp32 staging area -- no
@@ -44,9 +47,9 @@ __device__ __forceinline__ void glds16(const float *src, float *dst) {
 template <int H> struct B3Geom {
     static constexpr int T = H / 32;                // 32-row blocks of the layer's input and of its output
 #ifndef TN_B3_BPW256
-#define TN_B3_BPW256 2
+#define TN_B3_BPW256 1
 #endif
-    static constexpr int BPW = H == 256 ? TN_B3_BPW256 : 1;   // blocks per wave: 2 for H = 256 (one wave per SIMD, 512 registers), 1 for H = 128
+    static constexpr int BPW = H == 256 ? TN_B3_BPW256 : 1;   // blocks per wave (see the file header)
     static constexpr int WPS = T / BPW;             // waves per tile stream (4)
     static constexpr int STREAMS = H == 256 ? 1 : 2;
     static constexpr int THREADS = STREAMS * WPS * 64;
@@ -415,15 +418,16 @@ __global__ __launch_bounds__(B3Geom<H>::THREADS) void dgrad_b3_kernel(DgradArgs 
 // The bias gradient is summed on the way by the threads that convert G rows (a thread meets the same rows in every tile).
 // ------------------------------------------------------------------------------------------------
 template <int H, int BN, int BK>
-__global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
+__global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
 {
+    constexpr int TH = 64 * (H / 32 / BN) * (H / 32 / BK);     // threads: 4 waves (one per SIMD, 4 x 4 tiles each) or 8 (two per SIMD, 4 x 2)
     constexpr int NR = 2 * H;                          // rows per half tile: G rows [0, H), A rows [H, 2 H)
     constexpr int RS = 24;                             // bf16 elements per LDS row: 16 samples + 8 pad = 48 B (3 x 16 B: odd)
     constexpr int PLANE = NR * RS;                     // bf16 elements per term plane
     constexpr int BUF = 3 * PLANE;                     // ... per buffer
-    constexpr int NCH = (NR * 4) / 256;                // 16-byte chunks (4 samples of a row) per thread and half tile
+    constexpr int NCH = (NR * 4) / TH;                 // 16-byte chunks (4 samples of a row) per thread and half tile
     constexpr int WK = (H / 32) / BK;                  // waves along k
-    static_assert((H / 32 / BN) * WK == 4 && NCH * 256 == NR * 4, "four waves own all tiles");
+    static_assert(NCH * TH == NR * 4 && NCH >= 2 && (NCH & 1) == 0, "the waves own all tiles, every thread holds G and A chunks");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned short *lds = reinterpret_cast<unsigned short *>(lds_raw);
     const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
@@ -437,14 +441,14 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
         for (int bk = 0; bk < BK; ++bk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bn][bk][r] = 0.0f;
-    // this thread's chunks of a half tile: chunk id = threadIdx.x + 256 c -> row id / 4, samples 4 (id % 4) .. + 3 of the half
+    // this thread's chunks of a half tile: chunk id = threadIdx.x + TH c -> row id / 4, samples 4 (id % 4) .. + 3 of the half
     const int qd = threadIdx.x & 3;
     int src_off[NCH], dst_off[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int row = (threadIdx.x + 256 * c) >> 2;
+        const int row = (threadIdx.x + TH * c) >> 2;
         src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
-        if (TN_B3_ABLATE & 64) src_off[c] = a.off_g * 32 + (threadIdx.x + 256 * c) * 4;      // (timing experiment: contiguous)
+        if (TN_B3_ABLATE & 64) src_off[c] = a.off_g * 32 + (threadIdx.x + TH * c) * 4;      // (timing experiment: contiguous)
         dst_off[c] = row * RS + 4 * qd;
     }
     float dbacc[NCH / 2];
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(256) void wgrad_b3_kernel(WgradArgs a, int64_t n, c
         float sgm = dbacc[c];
         sgm += __shfl_xor(sgm, 1, 64);
         sgm += __shfl_xor(sgm, 2, 64);
-        const int row = (threadIdx.x + 256 * c) >> 2;
+        const int row = (threadIdx.x + TH * c) >> 2;
         if (qd == 0) atomicAdd(&a.gB[row], sgm);
     }
 }
@@ -633,7 +637,7 @@ int launch_wgrad(const WgradArgs &w, int64_t n, const float *stash, hipStream_t 
     if (e != hipSuccess) { tn::set_error("mlp_bwd(bf16x3): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
     const int per_cu = lds_bytes * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1;
-    kern<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * per_cu)), dim3(256), lds_bytes, s>>>(w, n, stash);
+    kern<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * per_cu)), dim3(64 * (H / 32 / BN) * (H / 32 / BK)), lds_bytes, s>>>(w, n, stash);
     return tn::check_launch("wgrad_b3_kernel");
 }
 
@@ -686,7 +690,10 @@ __attribute__((visibility("hidden"))) int launch_dgrad_b3(int H, const DgradArgs
 __attribute__((visibility("hidden"))) int launch_wgrad_b3(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
 {
     if (w.first || w.N != H || w.K != H) return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): square hidden layers only");
-    if (H == 256) return launch_wgrad<256, 4, 4>(w, n, stash, s);
+#ifndef TN_B3_WGRAD_BK256
+#define TN_B3_WGRAD_BK256 2
+#endif
+    if (H == 256) return launch_wgrad<256, 4, TN_B3_WGRAD_BK256>(w, n, stash, s);
     if (H == 128) return launch_wgrad<128, 2, 2>(w, n, stash, s);
     return tn::fail(TN_E_CONFIG, "mlp_bwd(bf16x3): width 128 or 256");
 }

@@ -38,8 +38,8 @@ PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent FLOP/s of t
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
 # counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
-PMC_PROFILES = ["profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
-MFMA_PROFILES = ["profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
+PMC_PROFILES = ["profiles/round4_pmc_traffic.json", "profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
+MFMA_PROFILES = ["profiles/round4_mfma_busy.json", "profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
 
 # algorithmic work per unit of the kernels that can dominate
 FLOP_SIGMA_FWD = 2 * (96 * 64 + 64)                                   # 12 416   

@@ -6,7 +6,10 @@ tag=${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 rm -rf /tmp/prof_$tag "$out"; mkdir -p "$out"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
+# TN_SIDE_PLAN=0: the next step's sampler pass in line with the step instead of on its own stream -- kernel durations in the stats file
+# then never overlap (side by side, batch_plan_scan_kernel shows the time it queues behind the chain kernel's waves, and
+# summing TotalDurationNs over-counts the step by ~0.6 ms)
+TN_SIDE_PLAN=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
 find /tmp/prof_$tag -name "*stats*.csv" -exec cp {} "$out/" \;
 ls -la /tmp/prof_$tag/* | head; grep '^{' "$out/bench.log" | tail -1 > "$out/bench.json"
 python3 - "$out" <<'PY'

@@ -54,7 +54,10 @@ template <int H> struct B3Geom {
     static constexpr int STREAMS = H == 256 ? 1 : 2;
     static constexpr int THREADS = STREAMS * WPS * 64;
     static constexpr int KS = H / 16;               // k steps
-    static constexpr int CONV = KS / 2;             // steps that carry the conversion of the next tile (2 * BPW pairs each): the sooner
+#ifndef TN_B3_CONV_DIV
+#define TN_B3_CONV_DIV 2
+#endif
+    static constexpr int CONV = H == 256 ? KS / TN_B3_CONV_DIV : KS / 2;   // steps that carry the conversion of the next tile: the sooner
                                                     // the staging area is free, the longer the request of the tile after next has to land
     static constexpr int SB = H + 8;                // bf16 elements per LDS tile row: (H + 8) * 2 B = odd multiple of 16 B
     static constexpr int PLANE = 32 * SB;           // bf16 elements per term plane

@@ -245,7 +245,8 @@ int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_rows, int64_
  * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */
 int tn_mlp_fwd(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y,
                float *pre_act, void *stream);
-/* Inference forward with scratch: wide stacks on positional-encoding inputs (the Vanilla feature MLP, models.py:59-68) run
+/* Inference forward with scratch: wide stacks on positional-encoding inputs (the Vanilla feature MLP, models.py:59-68) or on
+ * <= 64 plain inputs (Cobafa's 36 gathered features into its 128-wide stack, models.py:239-247: staged as zero-padded rows) run
  * layer by layer through the weight-in-register kernels of the training forward, the activations ping-ponging between two
  * [feature][32-sample] row buffers in `workspace` (tn_mlp_fwd_workspace_bytes(desc, n) bytes: 2.3 KB per sample at width
  * 256; 0 = this configuration has no such form, use tn_mlp_fwd).  Same MFMA steps in the same order as the training

@@ -382,6 +382,7 @@ def test_plane_regularisers_fwd_bwd_vs_torch():
     dict(kind="mlp", K=40, H=64, layers=4, out=100, n=300),
     # edge sizes of the persistent layer kernels (weights in registers, tiles through LDS): one sample, one tile + one sample,
     # fewer tiles than tile streams per workgroup (H = 128 runs two streams), an odd number of tiles
+    dict(kind="mlp", K=36, H=128, layers=5, out=128, n=5000),   # Cobafa's stack (models.py:239-247): plain inputs staged as rows (round 4)
     dict(kind="mlp", K=36, H=128, layers=3, out=128, n=1),
     dict(kind="mlp", K=36, H=128, layers=3, out=128, n=33),
     dict(kind="mlp", K=36, H=128, layers=3, out=96, n=65),

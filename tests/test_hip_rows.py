@@ -196,3 +196,31 @@ def test_bf16x3_full_size_properties(monkeypatch):
     _, gs = run("bf16x3", g1 + g2)
     for a_, b_, s_ in zip(ga, gb, gs):
         assert float((a_ + b_ - s_).abs().max()) <= 5e-5 * max(float(s_.abs().max()), 1e-30)        # (measured 1.2e-5)
+
+
+@pytest.mark.parametrize("n", [1, 777, 40000])
+def test_plain_input_stack_through_the_layer_kernels(n, matmul):
+    """Round 4: a wide stack on <= 64 PLAIN inputs -- Cobafa's 36 gathered features into 128 x 6 (models.py:239-247) -- stages x^T
+    as 64 zero-padded rows and runs its first layer, that layer's weight gradient and d loss / d x through the row-operand
+    kernels (fwd_lds / wgrad_rows<128, 64> / dgrad_first) instead of the general-shape fallbacks.  Inference (tn_mlp_fwd_ws,
+    ping-pong scratch) == training forward bit for bit, == the register-resident tn_mlp_fwd to fp32 rounding.  (Gradients of
+    these shapes, x included, tie-aware against torch: tests/test_hip_models.py::test_wide_deep_mlp_backward_vs_torch.)"""
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    torch.manual_seed(5)
+    net = m.MLP(36, 128, 5, 128).to(DEV)
+    x = torch.randn(n, 36, device=DEV)
+    with torch.no_grad():
+        y_inf = net(x)
+    xt = x.clone().requires_grad_(True)
+    y_train = net(xt)
+    assert torch.equal(y_inf, y_train.detach())
+    desc = m._mlp_desc(net.params(), 36, L.ENC_NONE, 0, L.ACT_NONE, None)
+    fn = L.lib().tn_mlp_fwd_workspace_bytes
+    fn.restype = C.c_int64
+    assert fn(C.byref(desc), C.c_int64(n)) == ((n + 31) // 32) * (2 * 128 + 64) * 128
+    y_reg = torch.empty(n, 128, device=DEV)
+    d0 = m._mlp_desc(net.params(), 36, L.ENC_NONE, 0, L.ACT_NONE, None)
+    d0.flags = 0                                                   # (fp32 MFMA, register-resident: independent of the layer kernels)
+    L.call("tn_mlp_fwd", x.device, C.byref(d0), L.ptr(x), C.c_void_p(None), C.c_int64(n), L.ptr(y_reg), C.c_void_p(None))
+    np.testing.assert_allclose(y_inf.cpu().numpy(), y_reg.cpu().numpy(), rtol=0, atol=3e-6 * float(y_reg.abs().max()))

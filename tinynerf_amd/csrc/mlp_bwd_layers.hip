@@ -34,6 +34,10 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
     for (int r = 0; r < 16; ++r) rows[(32 * ob + frow(r, h)) * 32 + j] = t[r];
 }
 
+__host__ __device__ inline bool plain_x_rows(int H, int n_layers, int enc, int K0_pad, int out_dim) {
+    return enc == TN_ENC_NONE && K0_pad <= 64 && H >= 128 && n_layers >= 3 && out_dim > 4 && out_dim <= H;     // (= layer_kernel_path)
+}
+
 struct Layout {            // rows (of 32 floats) per 32-sample tile
     int rowsH, rowsE, rowsG, rowsM, total;
     int xs;                // first-layer slots that are plain x columns
@@ -43,6 +47,10 @@ __host__ __device__ inline Layout make_layout(int H, int n_layers, int enc, int 
     L.xs = enc == TN_ENC_POSENC ? 0 : in_dim;
     L.rowsH = (n_layers - 1) * H;
     L.rowsE = enc == TN_ENC_NONE ? 0 : K0_pad - L.xs;
+    // plain inputs of a stack that runs layer by layer (Cobafa: 36 features into 128 x 6, models.py:239-247): the training forward
+    // stages x^T as 64 zero-padded rows (x_rows_kernel) so that the first layer and its weight gradient take the row-operand
+    // kernels like every other layer; `xs` keeps its meaning for the generic kernels, which read x row-major
+    if (plain_x_rows(H, n_layers, enc, K0_pad, out_dim)) L.rowsE = 64;
     const int outp = (out_dim + 31) & ~31;
     L.rowsG = H > outp ? H : outp;
     // wide stacks (layer kernels): ReLU bit masks of every hidden activation, one dword per lane and 32-feature block = 2 rows
@@ -373,17 +381,19 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
 // four MFMAs.  The hidden and output layers run as fwd_wreg_kernel launches (below).
 // ------------------------------------------------------------------------------------------------
 // positional-encoding inputs of a tile as workspace rows [slot][32 samples] (the E rows of the layout)
+// (slots: rows written -- K0_pad for the encodings, 64 for plain inputs: slots past the input width are zero rows)
 __global__ __launch_bounds__(256) void enc_rows_kernel(MlpArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ stash,
-                                                       int rows_total, int off_e)
+                                                       int rows_total, int off_e, int slots)
 {
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n + 31) >> 5;
-    const int G0 = a.K0_pad >> 3;
+    const int G0 = slots >> 3;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
-        const float aux3[3] = {xrow[0], xrow[1], xrow[2]};
+        float aux3[3] = {0.f, 0.f, 0.f};
+        if (a.enc == TN_ENC_POSENC) { aux3[0] = xrow[0]; aux3[1] = xrow[1]; aux3[2] = xrow[2]; }
         float *stE = stash + (tile * (int64_t)rows_total + off_e) * 32 + j;
         for (int g = 0; g < G0; ++g) {
             const f32x4 b = fetch_input(a, xrow, aux3, valid, g, h);
@@ -943,6 +953,88 @@ int launch_wgrad_lds(const WgradArgs &w, int64_t n, const float *stash, hipStrea
     return tn::check_launch("wgrad_lds_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// d loss / d x of the FIRST layer of a wide stack on narrow plain inputs (in_dim <= 64: Cobafa's 36 gathered features,
+// reference models.py:239-247, whose gradient goes on into the grid scatter):  gx[s][k] (+)= sum_n W_0[n][k] G_0[n][s].
+// The layer-kernel form of fwd_lds_kernel with the roles swapped: W_0^T ([64 slots][H], zero padded) is staged in LDS once
+// per workgroup, a wave holds its tile's H gradient rows as B operands (16 H / 32 registers) and produces the <= 2 blocks of 32
+// input slots with one ds_read_b128 per four MFMAs; results leave as 16-byte stores into the row-major gx the grid kernels
+// read.  Replaces dgrad_layer_kernel<H, true, 4> (every weight operand a scalar global load, 256 VGPRs + 188 AGPRs, one wave
+// per SIMD: 0.55 ms per 2^20 samples at H = 128).
+// ------------------------------------------------------------------------------------------------
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void dgrad_first_kernel(DgradArgs a, int64_t n, const float *__restrict__ stash, float *__restrict__ gx)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = H / 32, SW = H + 4;
+    for (int e = threadIdx.x; e < 64 * H; e += blockDim.x) {          // lds[slot k][hidden n] = W_0[n][k]
+        const int k = e / H, nn = e - k * H;
+        lds[k * SW + nn] = k < a.K ? a.W[(int64_t)nn * a.K + k] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int n_kt = (a.in_dim + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        const float *gin = urow(stash, tile * (int64_t)a.rows_total + a.off_gin);
+        f32x16 G[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[t][r] = gin[(32 * t + frow(r, h)) * 32 + j];
+        const int64_t row = tile * 32 + j;
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < n_kt; ++kt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float *wl = lds + (32 * kt + j) * SW + 4 * h;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wl + 32 * t + 8 * q);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = tn::mfma32(w[u], G[t][4 * q + u], acc);
+                }
+            tn::pin16(acc);
+            if (row < n) {
+                float *gr = gx + row * a.in_dim + 32 * kt + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * kt + 8 * q + 4 * h;
+                    if (f0 + 3 < a.in_dim && (a.in_dim & 3) == 0) {
+                        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                        if (a.accum_gx) v += *reinterpret_cast<const f32x4 *>(gr + 8 * q);
+                        *reinterpret_cast<f32x4 *>(gr + 8 * q) = v;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (f0 + u < a.in_dim) gr[8 * q + u] = a.accum_gx ? gr[8 * q + u] + acc[4 * q + u] : acc[4 * q + u];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int H>
+int launch_dgrad_first(const DgradArgs &d, int64_t n, const float *stash, float *gx, hipStream_t s)
+{
+    constexpr int WPB = 8;
+    constexpr size_t lds_bytes = (size_t)64 * (H + 4) * sizeof(float);
+    auto kern = dgrad_first_kernel<H, WPB>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int per_cu = std::max(1, std::min<int>((int)(160 * 1024 / lds_bytes), 2048 / (WPB * 64)));
+    kern<<<dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu))), dim3(WPB * 64), lds_bytes, s>>>(d, n, stash, gx);
+    return tn::check_launch("dgrad_first_kernel");
+}
+
 template <int H, int T, int NOT>
 int launch_fwd_lds(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
 {
@@ -983,11 +1075,13 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
             auto off_out = [&](int l) { return inference ? (l & 1) * H : (l + 1 < L ? l * H : lay.rowsH + lay.rowsE); };
             const int offM = lay.rowsH + lay.rowsE + 2 * lay.rowsG;
             auto off_bits = [&](int l) { return (inference || l + 1 >= L) ? -1 : offM + 2 * (H / 32) * l; };      // activation l = output of layer l
-            if (a.enc == TN_ENC_POSENC && a.K0_pad <= 64) {      // encoded inputs as rows, then the first layer like any other
-                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE);
+            const bool plain = plain_x_rows(H, L, a.enc, a.K0_pad, out) && lay.rowsE == 64;
+            if ((a.enc == TN_ENC_POSENC && a.K0_pad <= 64) || plain) {      // (encoded) inputs as rows, then the first layer like any other
+                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE,
+                                                                                                                  plain ? 64 : a.K0_pad);
                 if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
                 FwdLayerArgs f;
-                f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = a.K0_pad; f.rows_total = total;
+                f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = plain ? 64 : a.K0_pad; f.rows_total = total;
                 f.off_in = offE; f.off_out = 0; f.out_act = a.out_act; f.off_bits = off_bits(0);
                 if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
@@ -1053,6 +1147,14 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
                 staged = true;
             }
         }
+        if constexpr (H == 256 || H == 128) {
+            // plain inputs staged as 64 rows by the training forward (Cobafa's 36 features): same kernel, 128 x 64 / 256 x 64
+            if (!staged && w.first && stashed && lay.rowsE == 64 && plain_x_rows(H, L, a.enc, a.K0_pad, a.out_dim) && w.N == H) {
+                if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)cur * 32, (int64_t)lay.total * 32, H, stash + (int64_t)offE * 32,
+                                               (int64_t)lay.total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
+                staged = true;
+            }
+        }
         if constexpr (H == 256) {
             // first layer of the width-256 stack on positional-encoding inputs (<= 64 slots, all of them E rows of this workspace):
             // the row-operand kernel of mlp_wgrad_rows.hip (LDS-direct tiles, 2 x 1 accumulator tiles per wave) instead of
@@ -1104,8 +1206,17 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             }
             std::swap(cur, nxt);
         } else if (gx != nullptr && a.enc != TN_ENC_POSENC) {
-            dgrad_layer_kernel<H, true, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, gx);
-            if (int rc = tn::check_launch("dgrad_layer_kernel(first)")) return rc;
+            bool done = false;
+            if constexpr (H == 128 || H == 256) {
+                if (a.enc == TN_ENC_NONE && a.in_dim <= 64 && a.N[0] == H) {      // d loss / d x of a narrow plain input: W_0^T in LDS
+                    if (int rc = launch_dgrad_first<H>(d, n, stash, gx, s)) return rc;
+                    done = true;
+                }
+            }
+            if (!done) {
+                dgrad_layer_kernel<H, true, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, gx);
+                if (int rc = tn::check_launch("dgrad_layer_kernel(first)")) return rc;
+            }
         }
     }
     return TN_OK;
@@ -1175,7 +1286,9 @@ extern "C" int64_t tn_mlp_fwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n
     const int L = desc->n_layers;
     if (L < 2 || L > TN_MLP_MAX_LAYERS) return 0;
     const int H = desc->dims[1], out = desc->dims[L];
-    if ((H != 128 && H != 256) || !layer_kernel_path(H, L, out) || desc->encoding != TN_ENC_POSENC || ((desc->dims[0] + 7) & ~7) > 64) return 0;
+    const int K0p = (desc->dims[0] + 7) & ~7;         // positional-encoding inputs, or plain inputs staged as rows (Cobafa's 36 features)
+    if ((H != 128 && H != 256) || !layer_kernel_path(H, L, out) || K0p > 64 ||
+        !(desc->encoding == TN_ENC_POSENC || plain_x_rows(H, L, desc->encoding, K0p, out))) return 0;
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
     const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, out);
     return ((n + 31) / 32) * (int64_t)infer_rows_total(H, lay) * 32 * (int64_t)sizeof(float);

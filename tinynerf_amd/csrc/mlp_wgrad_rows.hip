@@ -157,7 +157,8 @@ int launch_rows(const WgradRowsArgs &w, int64_t n, hipStream_t s)
 
 // internal entry point (mlp_bwd2.hip, mlp_bwd_layers.hip): dW[NG][col0 + k] += G[NG][s] A[NA][s]^T for k < kmax, db[NG] += sum_s G
 //   (64, 256) / (64, 128): first layer of a width-64 head over the x columns it reads from a 256- / 128-wide stack;
-//   (256, 64): first layer of the width-256 stack itself over its <= 64 positional-encoding slots (E rows of its workspace)
+//   (256, 64) / (128, 64): first layer of a wide stack itself over its <= 64 input slots staged as rows of its workspace (the
+//   positional-encoding slots of the Vanilla stack; Cobafa's 36 plain features, zero padded)
 extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows,
                                                                       int64_t a_stride, int na, float *gW, int ldw, int col0, int kmax,
                                                                       float *gB, int64_t n, void *stream)
@@ -169,5 +170,6 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const flo
     if (ng == 64 && na == 256) return launch_rows<64, 256, 2, 1>(w, n, s);       // 2 x 8 tiles: wave = one k block, both row blocks
     if (ng == 64 && na == 128) return launch_rows<64, 128, 1, 1>(w, n, s);       // 2 x 4 tiles
     if (ng == 256 && na == 64) return launch_rows<256, 64, 2, 1>(w, n, s);       // 8 x 2 tiles: wave = two row blocks, one k block
-    return tn::fail(TN_E_CONFIG, "mlp_bwd: row-operand weight gradient is built for 64 x 256, 64 x 128 and 256 x 64");
+    if (ng == 128 && na == 64) return launch_rows<128, 64, 1, 1>(w, n, s);       // 4 x 2 tiles: one per wave
+    return tn::fail(TN_E_CONFIG, "mlp_bwd: row-operand weight gradient is built for 64 x 256, 64 x 128, 256 x 64 and 128 x 64");
 }

@@ -701,14 +701,18 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const 
     constexpr int R0 = (NH - 1) * H;                      // first staged row of a tile
     const int Rt = stash_rows(H, NH, 0);
     constexpr int g_chunks = RG * 8;
-    const int x_chunks = (32 * a.in_dim) / 4;
+    // tk_skip > 0 (round 4): the first layer's x tiles -- k tiles below in_dim / 32 -- are computed by the row-operand kernel
+    // from the feature stack's workspace (mlp_wgrad_rows.hip); here only its table columns are left and no x rows are staged
+    const int xw = a.tk_skip > 0 ? 0 : a.in_dim;          // staged x columns per sample
+    const int x_chunks = (32 * xw) / 4;
     const int aw = AUX ? a.K0_pad - a.in_dim : 0;
-    const int buf_floats = RG * RS + 32 * a.in_dim + 32 * aw;
+    const int buf_floats = RG * RS + 32 * xw + 32 * aw;
     // ownership (wave-uniform): kind 0 = first layer (tk), 1 = hidden layer l (tk), 2 = last layer, -1 = idle
+    const int T0 = a.Tk0 - a.tk_skip;
     int kind = -1, l = 0, tk = 0;
-    if (wave < a.Tk0) { kind = 0; tk = wave; }
-    else if (wave < a.Tk0 + (NH - 1) * T) { const int q = wave - a.Tk0; kind = 1; l = 1 + q / T; tk = q - (l - 1) * T; }
-    else if (wave == a.Tk0 + (NH - 1) * T) { kind = 2; l = NH; }
+    if (wave < T0) { kind = 0; tk = wave + a.tk_skip; }
+    else if (wave < T0 + (NH - 1) * T) { const int q = wave - T0; kind = 1; l = 1 + q / T; tk = q - (l - 1) * T; }
+    else if (wave == T0 + (NH - 1) * T) { kind = 2; l = NH; }
     f32x16 acc[2];
     float dbacc[2] = {0.f, 0.f};
 #pragma unroll
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const 
     };
     float *dummy = lds + 2 * buf_floats;
     auto commit = [&](float *buf) {
-        float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+        float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * xw;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = threadIdx.x + k * NW * 64;
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) hc[e] = hn[e];
         fetch_h(t1 < last ? t1 : last);
-        const float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * a.in_dim;
+        const float *ldsX = buf + RG * RS, *ldsA = ldsX + 32 * xw;
         if (kind >= 0) {
             // staged rows: [0, H): H_NH   [H + l*H, ...): G_l   [H + NH*H, +4): g_pre
             const f32x4 *g0, *g1;          // G-side operands of the two tiles
@@ -980,12 +984,13 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     const int chunks = wp.chunks;
     const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * (wlds * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1));
     const int extra_rows_ = extra_rows(a.enc, a.in_dim, a.K0_pad);
-    if (extra_rows_ == 0 && wp.xs > 0 && NH >= 2) {        // double-buffered, paired form (measured slower for the 2-layer sigma head)
+    if (extra_rows_ == 0 && (wp.xs > 0 || (x_rows && a.enc == TN_ENC_AUX_CAT)) && NH >= 2) {   // double-buffered, paired form (measured slower for the 2-layer sigma head)
         if constexpr (H == 64 && NH >= 2) {                // paired ownership: one wave per shared operand
             constexpr int RG4 = H + NH * H + 4;
-            const size_t lds4 = 2 * ((size_t)RG4 * RS + 32 * (size_t)a.in_dim + 32 * (size_t)wp.aw) * 4 + 32 * 16;
-            const int chunks4 = RG4 * 8 + 8 * a.in_dim;
-            if (lds4 <= (size_t)LDS_LIMIT_BYTES && w.Tk0 + (NH - 1) * 2 + 1 <= 12 && chunks4 <= 5 * 768) {
+            const int xw4 = x_rows ? 0 : a.in_dim;         // (x tiles from row views: nothing of x is staged)
+            const size_t lds4 = 2 * ((size_t)RG4 * RS + 32 * (size_t)xw4 + 32 * (size_t)wp.aw) * 4 + 32 * 16;
+            const int chunks4 = RG4 * 8 + 8 * xw4;
+            if (lds4 <= (size_t)LDS_LIMIT_BYTES && w.Tk0 - w.tk_skip + (NH - 1) * 2 + 1 <= 12 && chunks4 <= 5 * 768) {
                 auto wk = a.enc == TN_ENC_AUX_CAT ? mlp_wgrad4_kernel<NH, 12, 5, true> : mlp_wgrad4_kernel<NH, 12, 5, false>;
                 hipError_t we = hipFuncSetAttribute((const void *)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
                 if (we != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds4, hipGetErrorString(we)); return (int)we; }

@@ -9,6 +9,7 @@ never unscaled loss) -- on the synthetic scene for N_STEPS steps and several see
 
     python oracle/make_psnr_curve.py [--seeds 0 1 2] [--steps 300] [--out tests/golden/G17_psnr_curve.json]
     python oracle/make_psnr_curve.py --replay --seeds 0 1 --out tests/golden/G18_psnr_replay.json
+    python oracle/make_psnr_curve.py --replay --seeds 0 --method vanilla --lr 1e-3 --steps 200     (G19; cobafa: G20)
 
 ``--replay``: every random choice (ray order, sampling jitter, refresh jitter) comes from the streams the HIP harness defines for
 ``TrainConfig(seed, host_shuffle=True)`` (restated in ``reference_training(replay=...)``), so the GPU run walks the same rays with the
@@ -44,10 +45,10 @@ def scene():
     return (o[:n_train], d[:n_train], rgbs[:n_train]), (o[n_train:], d[n_train:], rgbs[n_train:])
 
 
-def initial_state(seed: int):
+def initial_state(seed: int, method: str = None):
     """the parameters ``run.Trainer(cfg(seed=seed))`` starts from: torch.manual_seed(seed) + the reference's constructors"""
     from tinynerf_amd.run import TrainConfig, build_renderer
-    cfg = TrainConfig(method=CONFIG["method"], scene_type="aabb", batch_size=CONFIG["batch_size"], n_samples=CONFIG["n_samples"],
+    cfg = TrainConfig(method=method or CONFIG["method"], scene_type="aabb", batch_size=CONFIG["batch_size"], n_samples=CONFIG["n_samples"],
                       seed=seed, occupancy_res=CONFIG["occupancy_res"])
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
@@ -60,9 +61,18 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--replay", action="store_true")
+    ap.add_argument("--method", default=CONFIG["method"], choices=["kplanes", "vanilla", "cobafa"])
+    ap.add_argument("--lr", type=float, default=1e-2, help="run.py:110 has 1e-2; the two deep stacks fall into the all-masked branch "
+                    "with it on this scene within a few steps (in the port as on the GPU): their curves use 1e-3")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    args.out = args.out or os.path.join(ROOT, "tests", "golden", "G18_psnr_replay.json" if args.replay else "G17_psnr_curve.json")
+    cfg = dict(CONFIG, method=args.method)
+    if args.lr != 1e-2:
+        cfg["lr"] = args.lr
+    default = {"kplanes": "G18_psnr_replay.json", "vanilla": "G19_psnr_replay_vanilla.json", "cobafa": "G20_psnr_replay_cobafa.json"}[args.method]
+    args.out = args.out or os.path.join(ROOT, "tests", "golden", default if args.replay else "G17_psnr_curve.json")
+    vf = 10 if args.method == "vanilla" else 0
+    cf = torch.linspace(2., 8., 6).tolist() if args.method == "cobafa" else None      # run.py:144 (Dropout(0.01) off on both sides)
     (o, d, rgbs), (ho, hd, hrgb) = scene()
     o, d, rgbs = o.numpy(), d.numpy(), rgbs.numpy()
     ho, hd = ho.numpy(), hd.numpy()
@@ -77,17 +87,18 @@ def main():
             packed, info = orc.ray_provider(ho, hd, marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
                                             n_samples=CONFIG["n_samples"], near=0.1, aabb=aabb)        # training=False: no jitter
             with torch.no_grad():
-                img = tp.render({k: v.detach() for k, v in sd.items()}, torch.from_numpy(packed), torch.from_numpy(info), bg)
+                img = tp.render({k: v.detach() for k, v in sd.items()}, torch.from_numpy(packed), torch.from_numpy(info), bg,
+                                vanilla_freqs=vf, cobafa_freqs=cf)
             curve[step] = float(-10.0 * torch.log10(torch.mean((img - hrgb) ** 2)))
             print(f"seed {seed} step {step}: held-out psnr {curve[step]:.3f} dB ({time.perf_counter() - t0:.0f} s)", flush=True)
         t0 = time.perf_counter()
-        losses, _, counts = tp.reference_training(initial_state(seed), o, d, rgbs, method=CONFIG["method"], batch_size=CONFIG["batch_size"],
+        losses, _, counts = tp.reference_training(initial_state(seed, args.method), o, d, rgbs, method=args.method, batch_size=CONFIG["batch_size"],
                                                   n_samples=CONFIG["n_samples"], n_steps=args.steps, occupancy_res=CONFIG["occupancy_res"],
-                                                  eval_at=eval_at, eval_fn=eval_fn,
+                                                  eval_at=eval_at, eval_fn=eval_fn, lr=args.lr, cobafa_freqs=cf,
                                                   **({"replay": {"seed": seed, "rank": 0}} if args.replay else {"stochastic_seed": 1000 + seed}))
         runs.append({"seed": seed, "psnr": {str(k): v for k, v in sorted(curve.items())}, "loss": losses,
                      "samples_per_step": [c[0] for c in counts], "rays_per_step": [c[1] for c in counts]})
-        json.dump({"config": CONFIG, "eval_at": eval_at, "steps": args.steps, "torch": torch.__version__, "runs": runs, "replay": bool(args.replay),
+        json.dump({"config": cfg, "eval_at": eval_at, "steps": args.steps, "torch": torch.__version__, "runs": runs, "replay": bool(args.replay),
                    "made_by": "oracle/make_psnr_curve.py (CPU port of the reference's train(), stochastic mode)"},
                   open(args.out, "w"), indent=1)
 

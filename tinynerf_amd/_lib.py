@@ -63,6 +63,7 @@ MLP_CHAIN_ONLY = 4
 MLP_WGRAD_ONLY = 8
 MLP_GRAD_Y_ROWS = 16
 MLP_BF16X3 = 32
+MLP_F16X2 = 64
 
 
 class PlaneRegItem(C.Structure):

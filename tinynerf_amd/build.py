@@ -38,6 +38,7 @@ SOURCES = {
     "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_wgrad_rows.hip": FAST + ["-munsafe-fp-atomics"],
     "linear.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_f2_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_b3_layers.hip": FAST + ["-munsafe-fp-atomics"] + (["-DTN_B3_ABLATE=" + os.environ["TN_B3_ABLATE"]] if os.environ.get("TN_B3_ABLATE") else [])
                          + os.environ.get("TN_B3_EXTRA_FLAGS", "").split(),        # (timing experiments: extra hipcc flags for this file)
 }

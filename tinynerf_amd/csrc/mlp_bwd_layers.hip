@@ -1096,7 +1096,8 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act; f.off_bits = off_bits(l);
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
                 int rc;
-                if (a.b3) rc = launch_fwd_b3(H, l + 1 == L, f, n, stash, y, s);        // bf16 matrix cores, exact 3-way splits
+                if (a.f2) rc = launch_fwd_f2(H, l + 1 == L, f, n, stash, y, s);        // fp16 matrix cores, two-term splits, scaled
+                else if (a.b3) rc = launch_fwd_b3(H, l + 1 == L, f, n, stash, y, s);   // bf16 matrix cores, exact 3-way splits
                 else rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;
             }
@@ -1183,7 +1184,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             bool done = false;
             if constexpr (H >= 128) {
                 if (a.K[l] == H && a.N[l] == H) {
-                    if (a.b3 && d.off_bits >= 0) { if (int rc = launch_dgrad_b3(H, d, n, stash, s)) return rc; }
+                    if (a.f2 && d.off_bits >= 0) { if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc; }
+                    else if (a.b3 && d.off_bits >= 0) { if (int rc = launch_dgrad_b3(H, d, n, stash, s)) return rc; }
                     else if (int rc = launch_dgrad_wreg<H>(d, n, stash, s)) return rc;
                     done = true;
                 } else if (a.K[l] == H && a.N[l] <= H) {          // weights of this layer's column group in LDS

@@ -1,0 +1,489 @@
+// Forward and data gradient of the wide stacks' hidden layers (Vanilla 256 x 10, reference models.py:59-68, run.py:131;
+// Cobafa 128 x 6) on the fp16 matrix cores with TWO-term operand splits and power-of-two scaling ("f16x2", TN_MLP_F16X2).
+//
+// bf16x3 (mlp_b3_layers.hip) represents every fp32 operand exactly as three bf16 terms and pays six MFMAs per 32 x 32 x 16 block.
+// An fp16 term carries 11 significand bits instead of 8: x s = hi + lo + r with hi = fp16(x s), lo = fp16(x s - hi) (both
+// round-to-nearest; x s - hi is exact in fp32) leaves |r| <= 2^-23 |x s| -- 22 of fp32's 24 bits -- and THREE products (lo hi,
+// hi lo, hi hi; lo lo is below 2^-22 of the product) per block: half the matrix time, 8 instead of 11 VALU instructions per
+// converted value pair, two LDS planes instead of three.  What fp16 lacks is range, hence the scales s (powers of two: exact):
+//   * B operand (activations / incoming gradients [feature][32 samples]): one scale PER SAMPLE, 2^(9 - e) with e the exponent of the
+//     largest |value| of that sample's column -- no overflow whatever the data, and a column's small entries keep an absolute
+//     error of 2^-35 of its largest one.  The column maxima of tile t + 2 are taken by the wave that staged the rows (its 32
+//     rows), published in LDS behind the tile barrier the kernel has anyway, and combined by the waves that convert it a tile
+//     later -- no extra barrier; the second staging buffer this needs is what the third LDS plane used to occupy.
+//   * A operand (weights, in registers for the whole launch): one scale per layer from the largest |weight| (prologue).
+//   * the accumulators are unscaled in the epilogue (D x 2^-(e_W + e_j) [+ bias]): one multiply-add per value, exact.
+// Measured against an fp64 evaluation (scratch experiment in DESIGN 4.2): the ten-layer forward is as far from it as the fp32
+// MFMA's (5e-7 of the largest output; bf16x3: 2e-7).  The weight gradient -- whose reduction runs over samples, so that no
+// per-tile scale can factor out of its accumulators -- stays on bf16x3.
+//
+// Structure, geometry and instruction scheduling follow mlp_b3_layers.hip (a wave owns one 32-row block of the output with its
+// weights in registers, eight waves per stream at H = 256 / four at H = 128, LDS-direct staging, conversion micro-steps pinned
+// behind the MFMAs of the first half of the k loop).
+#include "mlp_layers.h"
+#include "b3_device.h"
+#include <algorithm>
+
+namespace {
+
+using namespace tn::layers;
+using namespace tn::mlp;
+using tn::b3::u32x4;
+using tn::f32x16;
+using tn::f32x4;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct Op2 { u32x4 hi, lo; };            // 8 values as two packed-fp16 operands
+
+__device__ __forceinline__ void glds16(const float *src, float *dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_h(const u32x4 &a, const u32x4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// two (already scaled) fp32 values -> packed fp16 pairs of their two terms (low half = first value)
+__device__ __forceinline__ void split2h(float a, float b, unsigned &hi, unsigned &lo) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h[0], rb = b - (float)h[1];            // exact
+    const f16x2 l = {(_Float16)ra, (_Float16)rb};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// 2^(9 - e) and 2^(e - 9) for a column / layer maximum m >= 0 (e = its exponent); m = 0 or denormal: the largest scale (0 s = 0)
+__device__ __forceinline__ void pow2_scales(float m, float &s, float &inv) {
+    int e = (int)(__float_as_uint(m) >> 23);                    // biased
+    int se = 263 - e;                                            // biased exponent of 2^(9 - (e - 127))
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    s = __uint_as_float((unsigned)se << 23);
+    inv = __uint_as_float((unsigned)(254 - se) << 23);           // 2^-(se - 127); se = 254 -> 0: the true values are below 2^-118
+}
+
+template <int H> struct F2Geom {
+    static constexpr int T = H / 32;
+    static constexpr int WPS = T;                   // waves per tile stream: one 32-row block each
+    static constexpr int STREAMS = H == 256 ? 1 : 2;
+    static constexpr int THREADS = STREAMS * WPS * 64;
+    static constexpr int KS = H / 16;               // k steps
+    static constexpr int CONV = KS / 2;             // steps that carry the conversion of the next tile
+    static constexpr int SB = H + 8;                // fp16 elements per LDS tile row
+    static constexpr int PLANE = 32 * SB;
+    static constexpr int TILE_B = 2 * PLANE * 2;    // bytes per tile buffer (two planes)
+    static constexpr int STAGE_F = 32 * H;          // floats per staging buffer ([row][32 samples])
+    static constexpr int PM_F = 32 * WPS;           // floats per column-maximum slot ([sample][wave])
+    static constexpr int STREAM_B = 2 * TILE_B + 2 * STAGE_F * 4 + 2 * PM_F * 4;
+    static constexpr size_t lds_bytes = (size_t)STREAMS * STREAM_B + H * 4 + 64;
+};
+
+template <int SB>
+__device__ __forceinline__ Op2 read_b2(const unsigned short *tile, int j, int h, int s) {
+    constexpr int PLANE = 32 * SB;
+    const unsigned short *p = tile + j * SB + 16 * s + 8 * h;
+    Op2 o;
+    o.hi = *reinterpret_cast<const u32x4 *>(p);
+    o.lo = *reinterpret_cast<const u32x4 *>(p + PLANE);
+    return o;
+}
+
+template <int NROWS>
+__device__ __forceinline__ void request_rows(const float *rows, int r0, float *stage, int lane) {
+    const float *src = rows + r0 * 32 + 4 * lane;            // 16 B per lane: one instruction = 8 rows x 128 B
+#pragma unroll
+    for (int e = 0; e < NROWS / 8; ++e) glds16(src + e * 256, stage + e * 256);
+}
+
+// A operands of one 32-row block, all KS steps, scaled by `s` (a power of two)
+template <int KS>
+__device__ __forceinline__ void split_weights(const float (&v)[KS][8], float s, Op2 (&A)[KS]) {
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned a, b;
+            split2h(v[st][2 * p] * s, v[st][2 * p + 1] * s, a, b);
+            A[st].hi[p] = a; A[st].lo[p] = b;
+        }
+}
+
+template <int H>
+struct Stream2 {
+    using G = F2Geom<H>;
+    static constexpr int KS = G::KS, SB = G::SB, PLANE = G::PLANE;
+    int lane, j, h, wave, stream, wib;
+    unsigned short *tiles;
+    float *stage0;                              // this stream's two staging buffers
+    float *pm;                                  // this stream's two column-maximum slots
+    float *red;                                 // workgroup scratch (prologue: layer maximum)
+    int64_t n_tiles, stride, first, iters;
+
+    __device__ __forceinline__ void init(unsigned char *lds_raw, int64_t n) {
+        lane = tn::lane_id(); j = lane & 31; h = lane >> 5;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        stream = wave / G::WPS; wib = wave % G::WPS;
+        unsigned char *sbase = lds_raw + stream * G::STREAM_B;
+        tiles = reinterpret_cast<unsigned short *>(sbase);
+        stage0 = reinterpret_cast<float *>(sbase + 2 * G::TILE_B);
+        pm = stage0 + 2 * G::STAGE_F;
+        red = reinterpret_cast<float *>(lds_raw + G::STREAMS * G::STREAM_B + H * 4);
+        n_tiles = (n + 31) >> 5;
+        stride = (int64_t)gridDim.x * G::STREAMS;
+        first = (int64_t)blockIdx.x * G::STREAMS;
+        iters = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    }
+    __device__ __forceinline__ int64_t tile_of(int64_t it) const { const int64_t t = first + stream + it * stride; return t < n_tiles ? t : n_tiles - 1; }
+    __device__ __forceinline__ float *stage(int sbuf) const { return stage0 + sbuf * G::STAGE_F + (32 * wib) * 32; }      // this wave's 32 rows
+    __device__ __forceinline__ const float *sp(int sbuf) const { return stage(sbuf) + (16 * h) * 32 + j; }
+    __device__ __forceinline__ unsigned short *np(int buf) const { return tiles + buf * (2 * PLANE) + j * SB + 32 * wib + 16 * h; }
+    __device__ __forceinline__ void request(const float *stash, int64_t tile, int rows_total, int off, int sbuf) const {
+        request_rows<32>(urow(stash, tile * rows_total + off), 32 * wib, stage(sbuf), lane);
+    }
+    // largest |value| of this wave's 32 staged rows per sample -> pm[slot][sample][wave]
+    __device__ __forceinline__ void publish_max(int sbuf) const {
+        const float *s_ = sp(sbuf);
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(s_[e * 32]));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (h == 0) pm[sbuf * G::PM_F + j * G::WPS + wib] = m;
+    }
+    // scale of sample j for the tile whose maxima sit in slot `sbuf` (all waves' partial maxima)
+    __device__ __forceinline__ void sample_scale(int sbuf, float &s, float &inv) const {
+        const float *p = pm + sbuf * G::PM_F + j * G::WPS;
+        float m = 0.0f;
+#pragma unroll
+        for (int q = 0; q < G::WPS / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
+        pow2_scales(m, s, inv);
+    }
+    // value pair p (0 .. 7) of the wave's staged rows -> the two fp16 planes of a tile buffer (see mlp_b3_layers.hip convert_pair)
+    __device__ __forceinline__ void convert_pair(const float *sp_, unsigned short *np_, int p, float s) const {
+        const float v0 = sp_[(2 * p) * 32] * s, v1 = sp_[(2 * p + 1) * 32] * s;
+        unsigned hi, lo;
+        split2h(v0, v1, hi, lo);
+        unsigned short *d = np_ + 2 * p;
+        *reinterpret_cast<unsigned *>(d) = hi;
+        *reinterpret_cast<unsigned *>(d + PLANE) = lo;
+    }
+    // tiles 0 and 1 staged, tile 0 converted, the maxima of tile 1 published, tile 2 requested; returns 1 / scale of tile 0
+    __device__ __forceinline__ float prologue(const float *stash, int rows_total, int off) {
+        request(stash, tile_of(0), rows_total, off, 0);
+        request(stash, tile_of(1), rows_total, off, 1);
+        __syncthreads();                                     // (vmcnt(0): the wave's own rows have landed)
+        publish_max(0);
+        publish_max(1);
+        __syncthreads();
+        float s, inv;
+        sample_scale(0, s, inv);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) convert_pair(sp(0), np(0), p, s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next request overwrites the area
+        request(stash, tile_of(2), rows_total, off, 0);
+        __syncthreads();
+        return inv;
+    }
+    // acc += (W s_W) (x s_j) for the wave's block from tile buffer `cur`; converts the staged tile it + 1 (staging buffer, maxima slot
+    // `nb` = (it + 1) & 1) into buffer cur ^ 1 during the first CONV steps.  Returns through `inv_next` 1 / scale of tile it + 1.
+    __device__ __forceinline__ void k_loop(const Op2 (&A)[KS], f32x16 &acc, int cur, int nb, float &inv_next) const {
+        const unsigned short *tc = tiles + cur * (2 * PLANE);
+        const float *s_ = sp(nb);
+        unsigned short *n_ = np(cur ^ 1);
+        constexpr int CONV = G::CONV;
+        constexpr int PPS = 8 / CONV;                        // pairs per conversion step (1 at H = 256, 2 at H = 128)
+        float sc;
+        sample_scale(nb, sc, inv_next);
+        Op2 b = read_b2<SB>(tc, j, h, 0);
+        float cv[2 * PPS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Op2 bn = b;
+            if (s + 1 < KS) bn = read_b2<SB>(tc, j, h, s + 1);
+            float cn[2 * PPS];
+            if (s < CONV) {
+#pragma unroll
+                for (int u = 0; u < PPS; ++u) {
+                    const int p = PPS * s + u;
+                    cn[2 * u] = s_[(2 * p) * 32];
+                    cn[2 * u + 1] = s_[(2 * p + 1) * 32];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool conv = s >= 1 && s <= CONV;
+            constexpr int NMS = 3 * PPS;                     // micro-steps per step: scale + hi | residual + lo | two LDS writes
+            unsigned cu[2];
+            float cf[2];
+            auto micro = [&](int m) {
+                if (!conv || m >= NMS) return;
+                const int u = m / 3, mm = m % 3;
+                if (mm == 0) {
+                    cf[0] = cv[2 * u] * sc; cf[1] = cv[2 * u + 1] * sc;
+                    const f16x2 hh = {(_Float16)cf[0], (_Float16)cf[1]};
+                    cu[0] = __builtin_bit_cast(unsigned, hh);
+                } else if (mm == 1) {
+                    const f16x2 hh = __builtin_bit_cast(f16x2, cu[0]);
+                    const f16x2 ll = {(_Float16)(cf[0] - (float)hh[0]), (_Float16)(cf[1] - (float)hh[1])};
+                    cu[1] = __builtin_bit_cast(unsigned, ll);
+                } else {
+                    const int p = PPS * (s - 1) + u;
+                    unsigned short *d = n_ + 2 * p;
+                    *reinterpret_cast<unsigned *>(d) = cu[0];
+                    *reinterpret_cast<unsigned *>(d + PLANE) = cu[1];
+                }
+            };
+            // three partial products, small terms first; one conversion micro-step (two at H = 128) behind every MFMA
+            acc = mfma_h(A[s].lo, b.hi, acc);
+#pragma unroll
+            for (int e = 0; e < PPS; ++e) micro(0 * PPS + e);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma_h(A[s].hi, b.lo, acc);
+#pragma unroll
+            for (int e = 0; e < PPS; ++e) micro(1 * PPS + e);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma_h(A[s].hi, b.hi, acc);
+#pragma unroll
+            for (int e = 0; e < PPS; ++e) micro(2 * PPS + e);
+            __builtin_amdgcn_sched_barrier(0);
+            b = bn;
+#pragma unroll
+            for (int u = 0; u < 2 * PPS; ++u) cv[u] = cn[u];
+        }
+    }
+    // behind the k loop of iteration `it`: the rows of tile it + 2 (requested at the top of the iteration into staging buffer
+    // it & 1) have landed -- nothing younger is in flight, the tile's own stores are issued afterwards -- and their maxima go out
+    __device__ __forceinline__ void finish_staging(int sbuf) const {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_max(sbuf);
+    }
+    __device__ __forceinline__ void tile_barrier() const {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // conversion writes + maxima retired; the row stores may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // the layer's weight scale from every wave's largest |weight| (prologue)
+    __device__ __forceinline__ void layer_scale(float wmax, float &s, float &inv) const {
+        float m = wmax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        float g = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) g = fmaxf(g, red[w]);
+        pow2_scales(g, s, inv);
+    }
+};
+
+// weights of output rows 32 ob + i: step s, lane (i, h): W[row][16 s + 8 h + 0..7]   (forward)
+template <int KS>
+__device__ __forceinline__ float load_rows(const float *__restrict__ W, int ldw, int row, bool ok, int h, float (&v)[KS][8]) {
+    const float *wr = W + (int64_t)(ok ? row : 0) * ldw + 8 * h;
+    float m = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wr + 16 * s), w1 = *reinterpret_cast<const f32x4 *>(wr + 16 * s + 4);
+        const float t[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[s][e] = ok ? t[e] : 0.0f; m = fmaxf(m, fabsf(v[s][e])); }
+    }
+    return m;
+}
+// ... of W^T: A[i = column 32 kb + i][k = row n]: step s, lane (i, h): W[16 s + 8 h + e][col]   (data gradient)
+template <int KS>
+__device__ __forceinline__ float load_cols(const float *__restrict__ W, int ldw, int col, int h, float (&v)[KS][8]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[s][e] = W[(int64_t)(16 * s + 8 * h + e) * ldw + col]; m = fmaxf(m, fabsf(v[s][e])); }
+    return m;
+}
+
+template <int H, bool LAST>
+__global__ __launch_bounds__(F2Geom<H>::THREADS) void fwd_f2_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash, float *__restrict__ y)
+{
+    using G = F2Geom<H>;
+    constexpr int KS = G::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Stream2<H> st;
+    st.init(lds_raw, n);
+    float *bias_s = reinterpret_cast<float *>(lds_raw + G::STREAMS * G::STREAM_B);
+    for (int e = threadIdx.x; e < H; e += blockDim.x) bias_s[e] = e < a.N ? a.B[e] : 0.0f;
+    const int j = st.j, h = st.h, lane = st.lane;
+    const int ob = st.wib;
+    Op2 A[KS];
+    float inv_w;
+    {
+        float v[KS][8];
+        const int row = 32 * ob + j;
+        const float wmax = load_rows<KS>(a.W, a.K, row, row < a.N, h, v);
+        float s_w;
+        st.layer_scale(wmax, s_w, inv_w);                    // (carries the barrier behind the bias staging)
+        split_weights<KS>(v, s_w, A);
+    }
+    if (st.iters == 0) return;
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = bias_s[32 * ob + frow(r, h)];
+    float inv_cur = st.prologue(stash, a.rows_total, a.off_in);
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < st.iters; ++it) {
+        const int par = (int)(it & 1);
+        if (it > 0) st.request(stash, st.tile_of(it + 2), a.rows_total, a.off_in, par);     // (tile 2 was requested by the prologue)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        float inv_next;
+        st.k_loop(A, acc, cur, par ^ 1, inv_next);
+        st.finish_staging(par);
+        const int64_t tile = st.tile_of(it);
+        tn::pin16(acc);
+        const float c = inv_w * inv_cur;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], c, bias[r]);
+        if constexpr (!LAST) {
+            acc = tn::relu16(acc);
+            wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc);
+            if (a.off_bits >= 0) {
+                unsigned *bits = reinterpret_cast<unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * ob));
+                bits[lane] = relu_bits(acc);
+            }
+        } else if (a.N == H) {
+            const int64_t row = tile * 32 + j;
+            const bool valid = row < n;
+            f32x16 pre;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pre[r] = valid ? acc[r] : 0.0f;
+            wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, pre);
+            float *yr = y + (valid ? row : 0) * H + 32 * ob + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = tn::apply_act(acc[4 * q + u], a.out_act);
+                if (valid) *reinterpret_cast<f32x4 *>(yr + 8 * q) = v;
+            }
+        } else if (32 * ob < a.N) {
+            float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;
+            const int64_t row = tile * 32 + j;
+            const bool valid = row < n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 32 * ob + 8 * q + 4 * h;
+                f32x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = valid && f + u < a.N;
+                    outp[(u + 8 * q) * 32] = ok ? acc[4 * q + u] : 0.0f;
+                    v[u] = tn::apply_act(acc[4 * q + u], a.out_act);
+                }
+                if (valid) {
+                    if ((a.N & 3) == 0) { if (f < a.N) *reinterpret_cast<f32x4 *>(y + row * a.N + f) = v; }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (f + u < a.N) y[row * a.N + f + u] = v[u];
+                    }
+                }
+            }
+        }
+        st.tile_barrier();
+        inv_cur = inv_next;
+        cur ^= 1;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(F2Geom<H>::THREADS) void dgrad_f2_kernel(DgradArgs a, int64_t n, float *__restrict__ stash)
+{
+    using G = F2Geom<H>;
+    constexpr int KS = G::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Stream2<H> st;
+    st.init(lds_raw, n);
+    const int j = st.j, h = st.h, lane = st.lane;
+    const int kb = st.wib;
+    Op2 A[KS];
+    float inv_w;
+    {
+        float v[KS][8];
+        const float wmax = load_cols<KS>(a.W, a.K, 32 * kb + j, h, v);
+        float s_w;
+        st.layer_scale(wmax, s_w, inv_w);
+        split_weights<KS>(v, s_w, A);
+    }
+    if (st.iters == 0) return;
+    float inv_cur = st.prologue(stash, a.rows_total, a.off_gin);
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it < st.iters; ++it) {
+        const int par = (int)(it & 1);
+        const int64_t tile = st.tile_of(it);
+        const unsigned mbits = reinterpret_cast<const unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * kb))[lane];
+        if (it > 0) st.request(stash, st.tile_of(it + 2), a.rows_total, a.off_gin, par);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        float inv_next;
+        st.k_loop(A, acc, cur, par ^ 1, inv_next);
+        st.finish_staging(par);
+        tn::pin16(acc);
+        const float c = inv_w * inv_cur;
+        f32x16 res;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = mask_keep(acc[r] * c, mbits, r);
+        wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), kb, j, h, res);
+        st.tile_barrier();
+        inv_cur = inv_next;
+        cur ^= 1;
+    }
+}
+
+template <int H, bool LAST>
+int launch_fwd(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    using G = F2Geom<H>;
+    auto kern = fwd_f2_kernel<H, LAST>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_fwd(f16x2): cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(G::THREADS), G::lds_bytes, s>>>(f, n, stash, y);
+    return tn::check_launch("fwd_f2_kernel");
+}
+
+template <int H>
+int launch_dgrad(const DgradArgs &d, int64_t n, float *stash, hipStream_t s)
+{
+    using G = F2Geom<H>;
+    if (d.off_bits < 0) return tn::fail(TN_E_CONFIG, "mlp_bwd(f16x2): the data gradient takes its ReLU masks as bit rows");
+    auto kern = dgrad_f2_kernel<H>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd(f16x2): cannot reserve %zu B of LDS: %s", G::lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::STREAMS - 1) / G::STREAMS, 256));
+    kern<<<dim3((unsigned)bl), dim3(G::THREADS), G::lds_bytes, s>>>(d, n, stash);
+    return tn::check_launch("dgrad_f2_kernel");
+}
+
+}  // namespace
+
+namespace tn {
+namespace layers {
+
+__attribute__((visibility("hidden"))) int launch_fwd_f2(int H, bool last, const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
+{
+    if (H == 256) return last ? launch_fwd<256, true>(f, n, stash, y, s) : launch_fwd<256, false>(f, n, stash, y, s);
+    if (H == 128) return last ? launch_fwd<128, true>(f, n, stash, y, s) : launch_fwd<128, false>(f, n, stash, y, s);
+    return tn::fail(TN_E_CONFIG, "mlp_fwd(f16x2): width 128 or 256");
+}
+
+__attribute__((visibility("hidden"))) int launch_dgrad_f2(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s)
+{
+    if (H == 256) return launch_dgrad<256>(d, n, stash, s);
+    if (H == 128) return launch_dgrad<128>(d, n, stash, s);
+    return tn::fail(TN_E_CONFIG, "mlp_bwd(f16x2): width 128 or 256");
+}
+
+}  // namespace layers
+}  // namespace tn

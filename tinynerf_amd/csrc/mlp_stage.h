@@ -25,7 +25,8 @@ struct MlpArgs {
     const float *x_rows;
     float *gx_rows;
     int64_t x_rows_stride, gx_rows_stride;
-    int b3;                // TN_MLP_BF16X3
+    int b3;                // TN_MLP_BF16X3 (or TN_MLP_F16X2, which implies it for the weight gradients)
+    int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)
@@ -199,7 +200,8 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     a.n_layers = L; a.in_dim = d->in_dim; a.K0 = d->dims[0]; a.K0_pad = (a.K0 + 7) & ~7;
     a.enc = d->encoding; a.n_freqs = d->n_freqs; a.out_act = d->out_activation; a.out_dim = d->dims[L]; a.accum_gx = d->flags & TN_MLP_ACCUM_GRAD_X;
     a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride; a.row_gate = d->row_gate;
-    a.b3 = (d->flags & TN_MLP_BF16X3) != 0;
+    a.b3 = (d->flags & (TN_MLP_BF16X3 | TN_MLP_F16X2)) != 0;
+    a.f2 = (d->flags & TN_MLP_F16X2) != 0;
     a.x_rows = d->x_rows; a.gx_rows = d->grad_x_rows; a.x_rows_stride = d->x_rows_tile_stride; a.gx_rows_stride = d->grad_x_rows_tile_stride;
     TN_REQUIRE((!a.x_rows && !a.gx_rows) || ((a.in_dim & 31) == 0 && a.enc != TN_ENC_POSENC), TN_E_CONFIG,
                "mlp: x_rows / grad_x_rows need in_dim % 32 == 0 and an encoding that keeps x as input columns");

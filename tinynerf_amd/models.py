@@ -27,7 +27,11 @@ from . import _lib as L
 # Matrix products of the wide stacks (Vanilla 256 x 10, Cobafa 128 x 6): "bf16x3" = bf16 matrix cores with exact three-way
 # operand splits (TN_MLP_BF16X3: results equal to fp32 rounding, 2.67 x the fp32 matrix rate), "fp32" = v_mfma_f32_32x32x2_f32.
 # TN_MATMUL=fp32 in the environment (or assigning "fp32" here) selects the plain fp32 instructions.
-MATMUL = "fp32" if os.environ.get("TN_MATMUL", "bf16x3").lower() == "fp32" else "bf16x3"
+# "f16x2" (TN_MLP_F16X2, round 4) = forward and data-gradient layers on the fp16 matrix cores with two-term splits and power-of-two
+# scales (three products instead of six), weight gradients on bf16x3.
+MATMUL = os.environ.get("TN_MATMUL", "bf16x3").lower()
+if MATMUL not in ("fp32", "bf16x3", "f16x2"):
+    raise RuntimeError(f"TN_MATMUL={MATMUL}: fp32, bf16x3 or f16x2")
 
 
 def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,
@@ -41,7 +45,7 @@ def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freq
     d.encoding = encoding
     d.n_freqs = n_freqs
     d.out_activation = out_act
-    d.flags = flags | (L.MLP_BF16X3 if MATMUL == "bf16x3" else 0)
+    d.flags = flags | {"bf16x3": L.MLP_BF16X3, "f16x2": L.MLP_F16X2}.get(MATMUL, 0)
     d.aux_index = aux_index.data_ptr() if aux_index is not None else None
     d.aux_stride = aux_stride
     d.freqs = freqs.data_ptr() if freqs is not None else None

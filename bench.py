@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the exact 3-way split: six bf16 products per fp32 product
+PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0    # ... of the two-term fp16 split: three fp16 products (v_mfma_f32_32x32x16_f16 runs at the bf16 rate)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
 # counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
@@ -286,7 +287,13 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
         out["flop_per_sample_step"] = flop
         out["tflops_fp32_equivalent"] = tf
         out["matmul"] = mode
-        if mode == "bf16x3":
+        if mode == "f16x2":
+            # hidden layers as two-term fp16 splits with power-of-two scales (TN_MLP_F16X2): THREE fp16 MFMAs per fp32 product block;
+            # the width-64 heads stay on the fp32 MFMA
+            out["mfma_frac"] = tf / PEAK_F16X2_TFLOPS
+            out["mfma_peak"] = {"tflops": PEAK_F16X2_TFLOPS, "what": "dense fp16 MFMA peak / 3 products per fp32 product (f16x2)"}
+            out["vs_fp32_mfma_peak"] = tf / PEAK_FP32_MFMA_TFLOPS
+        elif mode == "bf16x3":
             # wide-stack layers on the bf16 matrix cores with exact 3-way operand splits (TN_MLP_BF16X3): fp32-accurate products
             # at six bf16 MFMAs each; the width-64 heads stay on the fp32 MFMA
             out["mfma_frac"] = tf / PEAK_BF16X3_TFLOPS
@@ -505,7 +512,8 @@ def main():
     others = None
     if rank == 0 and world == 1 and not args.no_stages:
         others = {}
-        for key, method, matmul in (("vanilla", "vanilla", None), ("cobafa", "cobafa", None), ("vanilla_fp32_mfma", "vanilla", "fp32")):
+        for key, method, matmul in (("vanilla", "vanilla", None), ("cobafa", "cobafa", None), ("vanilla_bf16x3", "vanilla", "bf16x3"),
+                                    ("vanilla_fp32_mfma", "vanilla", "fp32")):
             try:
                 others[key] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows, matmul)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed

@@ -190,11 +190,13 @@ enum { TN_ENC_NONE = 0,
                                  * of v_mfma_f32_32x32x2_f32 -- 2.67 x the matrix rate, results equal to fp32 rounding.  Ignored by
                                  * configurations without such a form. */
 
-#define TN_MLP_F16X2 64         /* as TN_MLP_BF16X3 (implied for the weight gradients), with the FORWARD and DATA-GRADIENT layers on the fp16
-                                 * matrix cores instead: two-term operand splits (x s = hi + lo in fp16, 22 of fp32's 24 significand
-                                 * bits), three partial products, power-of-two scales per sample column and per layer that are taken
-                                 * out of the fp32 accumulators again -- no overflow whatever the data, the same distance from an
-                                 * fp64 evaluation as the fp32 MFMA, half the matrix time of bf16x3 (csrc/mlp_f2_layers.hip). */
+#define TN_MLP_F16X2 64         /* as TN_MLP_BF16X3, with the hidden layers on the fp16 matrix cores instead: two-term operand splits
+                                 * (x s = hi + lo in fp16: 22 of fp32's 24 significand bits), three partial products, power-of-two scales
+                                 * -- per sample column and per layer in the forward / data gradient, per operand and launch in the
+                                 * weight gradient -- that are taken out of the fp32 accumulators again: no overflow whatever the
+                                 * data, the same distance from an fp64 evaluation as the fp32 MFMA, half the matrix time of bf16x3
+                                 * (csrc/mlp_f2_layers.hip).  The workspace's last 256 bytes carry the per-layer maxima between
+                                 * the launches of a step.  Default of tinynerf_amd.models. */
 
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */

@@ -34,6 +34,11 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
     for (int r = 0; r < 16; ++r) rows[(32 * ob + frow(r, h)) * 32 + j] = t[r];
 }
 
+// behind the last tile of a training workspace: the largest |value| of every layer's input rows ([0, 16): activations, reported
+// by the f16x2 forward of layer l; [16, 32): gradients, by its data gradient) -- the scales of the f16x2 weight gradient
+constexpr int64_t WS_TAIL_BYTES = 256;
+__host__ inline float *ws_tail(float *stash, int64_t n, int rows_total) { return stash + ((n + 31) / 32) * (int64_t)rows_total * 32; }
+
 __host__ __device__ inline bool plain_x_rows(int H, int n_layers, int enc, int K0_pad, int out_dim) {
     return enc == TN_ENC_NONE && K0_pad <= 64 && H >= 128 && n_layers >= 3 && out_dim > 4 && out_dim <= H;     // (= layer_kernel_path)
 }
@@ -1075,6 +1080,11 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
             auto off_out = [&](int l) { return inference ? (l & 1) * H : (l + 1 < L ? l * H : lay.rowsH + lay.rowsE); };
             const int offM = lay.rowsH + lay.rowsE + 2 * lay.rowsG;
             auto off_bits = [&](int l) { return (inference || l + 1 >= L) ? -1 : offM + 2 * (H / 32) * l; };      // activation l = output of layer l
+            float *tail = (a.f2 && !inference && L <= 16) ? ws_tail(stash, n, lay.total) : nullptr;
+            if (tail) {
+                hipError_t me = hipMemsetAsync(tail, 0, WS_TAIL_BYTES, s);
+                if (me != hipSuccess) { tn::set_error("mlp_fwd(f16x2): cannot clear the workspace tail: %s", hipGetErrorString(me)); return (int)me; }
+            }
             const bool plain = plain_x_rows(H, L, a.enc, a.K0_pad, out) && lay.rowsE == 64;
             if ((a.enc == TN_ENC_POSENC && a.K0_pad <= 64) || plain) {      // (encoded) inputs as rows, then the first layer like any other
                 enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE,
@@ -1094,6 +1104,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 FwdLayerArgs f;
                 f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = total;
                 f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act; f.off_bits = off_bits(l);
+                f.max_in = tail ? tail + l : nullptr;
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
                 int rc;
                 if (a.f2) rc = launch_fwd_f2(H, l + 1 == L, f, n, stash, y, s);        // fp16 matrix cores, two-term splits, scaled
@@ -1140,9 +1151,27 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
-        bool staged = false;
+        bool staged = false, dgrad_done = false;
         if constexpr (H == 256 || H == 128) {
-            if (!w.first && w.N == H && w.K == H) {
+            // f16x2: the layer's data gradient first -- it reports the largest |gradient| of the rows both kernels read -- then the
+            // weight gradient with that scale and the one the forward pass left for the layer's input rows
+            if (!w.first && w.N == H && w.K == H && a.f2 && stashed && layer_kernel_path(H, L, a.out_dim) && L <= 16) {
+                float *tail = ws_tail(stash, n, lay.total);
+                DgradArgs d;
+                d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
+                d.off_gin = cur; d.off_gout = nxt; d.off_mask = (l - 1) * H;
+                d.off_bits = lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * (l - 1);
+                d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
+                d.max_in = tail + 16 + l;
+                if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc;
+                dgrad_done = true;
+                w.g_max = tail + 16 + l; w.a_max = tail + l;
+                if (int rc = launch_wgrad_f2(H, w, n, stash, s)) return rc;
+                staged = true;
+            }
+        }
+        if constexpr (H == 256 || H == 128) {
+            if (!staged && !w.first && w.N == H && w.K == H) {
                 if (a.b3) { if (int rc = launch_wgrad_b3(H, w, n, stash, s)) return rc; }
                 else if (int rc = launch_wgrad_lds<H, 2, H == 256 ? 4 : 1>(w, n, stash, s)) return rc;
                 staged = true;
@@ -1181,9 +1210,10 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {
-            bool done = false;
+            bool done = dgrad_done;
             if constexpr (H >= 128) {
-                if (a.K[l] == H && a.N[l] == H) {
+                if (done) {}
+                else if (a.K[l] == H && a.N[l] == H) {
                     if (a.f2 && d.off_bits >= 0) { if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc; }
                     else if (a.b3 && d.off_bits >= 0) { if (int rc = launch_dgrad_b3(H, d, n, stash, s)) return rc; }
                     else if (int rc = launch_dgrad_wreg<H>(d, n, stash, s)) return rc;
@@ -1236,7 +1266,7 @@ extern "C" __attribute__((visibility("hidden"))) int64_t tn_mlp_bwd_layers_works
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
     if (((desc->dims[L] + 31) / 32) * (H / 32) > 64) return 0;          // weight-gradient tiling of the output layer (run_layers)
     const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L]);
-    return ((n + 31) / 32) * (int64_t)lay.total * 32 * (int64_t)sizeof(float);
+    return ((n + 31) / 32) * (int64_t)lay.total * 32 * (int64_t)sizeof(float) + WS_TAIL_BYTES;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux,

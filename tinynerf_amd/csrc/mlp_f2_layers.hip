@@ -1,5 +1,6 @@
-// Forward and data gradient of the wide stacks' hidden layers (Vanilla 256 x 10, reference models.py:59-68, run.py:131;
-// Cobafa 128 x 6) on the fp16 matrix cores with TWO-term operand splits and power-of-two scaling ("f16x2", TN_MLP_F16X2).
+// Hidden layers of the wide stacks (Vanilla 256 x 10, reference models.py:59-68, run.py:131; Cobafa 128 x 6) -- forward, data
+// gradient and weight gradient -- on the fp16 matrix cores with TWO-term operand splits and power-of-two scaling ("f16x2",
+// TN_MLP_F16X2).
 //
 // bf16x3 (mlp_b3_layers.hip) represents every fp32 operand exactly as three bf16 terms and pays six MFMAs per 32 x 32 x 16 block.
 // An fp16 term carries 11 significand bits instead of 8: x s = hi + lo + r with hi = fp16(x s), lo = fp16(x s - hi) (both
@@ -14,8 +15,8 @@
 //   * A operand (weights, in registers for the whole launch): one scale per layer from the largest |weight| (prologue).
 //   * the accumulators are unscaled in the epilogue (D x 2^-(e_W + e_j) [+ bias]): one multiply-add per value, exact.
 // Measured against an fp64 evaluation (scratch experiment in DESIGN 4.2): the ten-layer forward is as far from it as the fp32
-// MFMA's (5e-7 of the largest output; bf16x3: 2e-7).  The weight gradient -- whose reduction runs over samples, so that no
-// per-tile scale can factor out of its accumulators -- stays on bf16x3.
+// MFMA's (5e-7 of the largest output; bf16x3: 2e-7).  The weight gradient's reduction runs over samples, so no per-tile scale
+// can leave its accumulators: it takes one scale per operand and launch (see wgrad_f2_kernel).
 //
 // Structure, geometry and instruction scheduling follow mlp_b3_layers.hip (a wave owns one 32-row block of the output with its
 // weights in registers, eight waves per stream at H = 256 / four at H = 128, LDS-direct staging, conversion micro-steps pinned
@@ -23,6 +24,7 @@
 #include "mlp_layers.h"
 #include "b3_device.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -115,12 +117,14 @@ struct Stream2 {
     float *stage0;                              // this stream's two staging buffers
     float *pm;                                  // this stream's two column-maximum slots
     float *red;                                 // workgroup scratch (prologue: layer maximum)
+    float seen;                                 // largest |value| this lane has staged so far (-> the weight gradient's scale)
     int64_t n_tiles, stride, first, iters;
 
     __device__ __forceinline__ void init(unsigned char *lds_raw, int64_t n) {
         lane = tn::lane_id(); j = lane & 31; h = lane >> 5;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         stream = wave / G::WPS; wib = wave % G::WPS;
+        seen = 0.0f;
         unsigned char *sbase = lds_raw + stream * G::STREAM_B;
         tiles = reinterpret_cast<unsigned short *>(sbase);
         stage0 = reinterpret_cast<float *>(sbase + 2 * G::TILE_B);
@@ -139,11 +143,12 @@ struct Stream2 {
         request_rows<32>(urow(stash, tile * rows_total + off), 32 * wib, stage(sbuf), lane);
     }
     // largest |value| of this wave's 32 staged rows per sample -> pm[slot][sample][wave]
-    __device__ __forceinline__ void publish_max(int sbuf) const {
+    __device__ __forceinline__ void publish_max(int sbuf) {
         const float *s_ = sp(sbuf);
         float m = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(s_[e * 32]));
+        seen = fmaxf(seen, m);
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         if (h == 0) pm[sbuf * G::PM_F + j * G::WPS + wib] = m;
     }
@@ -252,7 +257,7 @@ struct Stream2 {
     }
     // behind the k loop of iteration `it`: the rows of tile it + 2 (requested at the top of the iteration into staging buffer
     // it & 1) have landed -- nothing younger is in flight, the tile's own stores are issued afterwards -- and their maxima go out
-    __device__ __forceinline__ void finish_staging(int sbuf) const {
+    __device__ __forceinline__ void finish_staging(int sbuf) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish_max(sbuf);
     }
@@ -260,6 +265,14 @@ struct Stream2 {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // conversion writes + maxima retired; the row stores may stay in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    // end of the launch: the largest |value| of every row this workgroup staged -> *dst (non-negative floats order like their bits)
+    __device__ __forceinline__ void report_max(float *dst) const {
+        if (dst == nullptr) return;
+        float m = seen;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(dst), __float_as_uint(m));
     }
     // the layer's weight scale from every wave's largest |weight| (prologue)
     __device__ __forceinline__ void layer_scale(float wmax, float &s, float &inv) const {
@@ -391,6 +404,7 @@ __global__ __launch_bounds__(F2Geom<H>::THREADS) void fwd_f2_kernel(FwdLayerArgs
         inv_cur = inv_next;
         cur ^= 1;
     }
+    st.report_max(a.max_in);
 }
 
 template <int H>
@@ -437,6 +451,209 @@ __global__ __launch_bounds__(F2Geom<H>::THREADS) void dgrad_f2_kernel(DgradArgs 
         inv_cur = inv_next;
         cur ^= 1;
     }
+    st.report_max(a.max_in);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient  dW[n][k] += sum_s G[n][s] A[k][s]  as two-term fp16 splits.  The reduction runs over the SAMPLES: a scale
+// can only leave the accumulators if it is the same for every tile of the launch, so each operand takes ONE power of two from
+// the largest |value| of all its rows -- known before the launch because the f16x2 forward / data-gradient kernels of the
+// same layer stage exactly these rows and report their maximum (FwdLayerArgs / DgradArgs::max_in); run_layers therefore runs a
+// layer's data gradient in front of its weight gradient.  An element 2^-k below the maximum keeps 22 - max(0, k - 13) bits:
+// what it contributes to a sum over all samples is that much smaller, too.  Same pipeline as wgrad_b3_kernel
+// (mlp_b3_layers.hip): half tiles of 16 samples, two LDS buffers, conversion micro-steps behind the MFMAs, one barrier.
+// ------------------------------------------------------------------------------------------------
+template <int H, int BN, int BK>
+__global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_kernel(WgradArgs a, int64_t n, const float *__restrict__ stash)
+{
+    constexpr int TH = 64 * (H / 32 / BN) * (H / 32 / BK);
+    constexpr int NR = 2 * H;                          // rows per half tile: G rows [0, H), A rows [H, 2 H)
+    constexpr int RS = 24;                             // fp16 elements per LDS row: 16 samples + 8 pad
+    constexpr int PLANE = NR * RS;
+    constexpr int BUF = 2 * PLANE;
+    constexpr int NCH = (NR * 4) / TH;                 // 16-byte chunks (4 samples of a row) per thread and half tile
+    constexpr int WK = (H / 32) / BK;
+    static_assert(NCH * TH == NR * 4 && NCH >= 2 && (NCH & 1) == 0, "the waves own all tiles, every thread holds G and A chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(lds_raw);
+    const int lane = tn::lane_id(), i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int tn0 = (wave / WK) * BN, tk0 = (wave % WK) * BK;
+    float s_g, inv_g, s_a, inv_a;
+    pow2_scales(*a.g_max, s_g, inv_g);
+    pow2_scales(*a.a_max, s_a, inv_a);
+    f32x16 acc[BN][BK];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bn][bk][r] = 0.0f;
+    const int qd = threadIdx.x & 3;
+    int src_off[NCH], dst_off[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int row = (threadIdx.x + TH * c) >> 2;
+        src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
+        dst_off[c] = row * RS + 4 * qd;
+    }
+    float dbacc[NCH / 2];
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) dbacc[c] = 0.0f;
+    const int64_t stride = gridDim.x;
+    auto half_src = [&](int64_t it) {
+        int64_t tile = blockIdx.x + (it >> 1) * stride;
+        tile = tile < n_tiles ? tile : n_tiles - 1;
+        return stash + tile * (int64_t)a.rows_total * 32 + 16 * (it & 1);
+    };
+    const int64_t my_tiles = (int64_t)blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + stride - 1) / stride : 0;
+    const int64_t iters = 2 * my_tiles;
+    if (iters == 0) return;
+    typedef const __attribute__((address_space(1))) char gchar;
+    auto uniform_global = [](const float *p) {
+        const uint64_t v = (uint64_t)p;
+        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        return (gchar *)u;
+    };
+    f32x4 st[NCH];
+    unsigned src_boff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) src_boff[c] = (unsigned)src_off[c] * 4u;
+    auto load_chunk = [&](gchar *base, int c) {
+        unsigned off = src_boff[c];
+        asm volatile("" : "+v"(off));
+        st[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(base + off);
+    };
+    // conversion of chunk c in six micro-steps (0 / 2: scale + hi of a value pair, 1 / 3: residual + lo, 4: the two 8-byte LDS
+    // writes, 5: bias sum + request of the chunk's successor); G chunks come first (c < NCH / 2)
+    unsigned cu[4];
+    float cf[2];
+    auto micro = [&](int c, int m, unsigned short *buf, gchar *nb) {
+        const float sc = c < NCH / 2 ? s_g : s_a;
+        if (m < 4) {
+            const int e = m >= 2 ? 2 : 0;
+            if ((m & 1) == 0) {
+                cf[0] = st[c][e] * sc; cf[1] = st[c][e + 1] * sc;
+                const f16x2 hh = {(_Float16)cf[0], (_Float16)cf[1]};
+                cu[e] = __builtin_bit_cast(unsigned, hh);
+            } else {
+                const f16x2 hh = __builtin_bit_cast(f16x2, cu[e]);
+                const f16x2 ll = {(_Float16)(cf[0] - (float)hh[0]), (_Float16)(cf[1] - (float)hh[1])};
+                cu[e + 1] = __builtin_bit_cast(unsigned, ll);
+            }
+        } else if (m == 4) {
+            unsigned short *d = buf + dst_off[c];
+            *reinterpret_cast<uint2 *>(d) = make_uint2(cu[0], cu[2]);
+            *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(cu[1], cu[3]);
+        } else {
+            if (c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
+            load_chunk(nb, c);
+        }
+    };
+    {
+        gchar *b0 = uniform_global(half_src(0)), *b1 = uniform_global(half_src(1));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) load_chunk(b0, c);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) micro(c, m, lds, b1);
+        }
+    }
+    __syncthreads();
+    int g_off[BN], a_off[BK];
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn) g_off[bn] = (32 * (tn0 + bn) + i) * RS + 8 * h;
+#pragma unroll
+    for (int bk = 0; bk < BK; ++bk) a_off[bk] = (H + 32 * (tk0 + bk) + i) * RS + 8 * h;
+    auto read_op = [&](const unsigned short *buf, int off) {
+        Op2 o;
+        o.hi = *reinterpret_cast<const u32x4 *>(buf + off);
+        o.lo = *reinterpret_cast<const u32x4 *>(buf + off + PLANE);
+        return o;
+    };
+    auto half_step = [&](int64_t it, int cur, auto convert_tag) {
+        constexpr bool CONVERT = decltype(convert_tag)::value;
+        const unsigned short *bc = lds + cur * BUF;
+        unsigned short *bnx = lds + (cur ^ 1) * BUF;
+        gchar *nb = uniform_global(half_src(it + 2 < iters ? it + 2 : it));
+        Op2 gop[BN];
+#pragma unroll
+        for (int bn = 0; bn < BN; ++bn) gop[bn] = read_op(bc, g_off[bn]);
+        Op2 aop = read_op(bc, a_off[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            Op2 anx = aop;
+            if (bk + 1 < BK) anx = read_op(bc, a_off[bk + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = BN * BK * 3, MS = NCH * 6, PER = MS / NM;
+            static_assert(PER * NM == MS, "micro-steps divide evenly over the MFMAs");
+            auto term = [&](int t, const u32x4 &(*ga)(const Op2 &), const u32x4 &(*ab)(const Op2 &)) {
+#pragma unroll
+                for (int bn = 0; bn < BN; ++bn) {
+                    acc[bn][bk] = mfma_h(ga(gop[bn]), ab(aop), acc[bn][bk]);
+                    if constexpr (CONVERT) {
+#pragma unroll
+                        for (int u = 0; u < PER; ++u) {
+                            const int m = ((bk * 3 + t) * BN + bn) * PER + u;
+                            micro(m / 6, m % 6, bnx, nb);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            term(0, [](const Op2 &o) -> const u32x4 & { return o.lo; }, [](const Op2 &o) -> const u32x4 & { return o.hi; });
+            term(1, [](const Op2 &o) -> const u32x4 & { return o.hi; }, [](const Op2 &o) -> const u32x4 & { return o.lo; });
+            term(2, [](const Op2 &o) -> const u32x4 & { return o.hi; }, [](const Op2 &o) -> const u32x4 & { return o.hi; });
+            aop = anx;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int cur = 0;
+#pragma clang loop unroll(disable)
+    for (int64_t it = 0; it + 1 < iters; ++it) {
+        half_step(it, cur, std::true_type{});
+        cur ^= 1;
+    }
+    half_step(iters - 1, cur, std::false_type{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const float c_out = inv_g * inv_a;
+#pragma unroll
+    for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < BK; ++bk) {
+            const int k = 32 * (tk0 + bk) + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * (tn0 + bn) + frow(r, h);
+                atomicAdd(&a.gW[(int64_t)nn * a.K + k], acc[bn][bk][r] * c_out);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) {
+        float sgm = dbacc[c];
+        sgm += __shfl_xor(sgm, 1, 64);
+        sgm += __shfl_xor(sgm, 2, 64);
+        const int row = (threadIdx.x + TH * c) >> 2;
+        if (qd == 0) atomicAdd(&a.gB[row], sgm);
+    }
+}
+
+template <int H, int BN, int BK>
+int launch_wgrad(const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
+{
+    constexpr size_t lds_bytes = (size_t)2 * 2 * (2 * H) * 24 * 2;
+    auto kern = wgrad_f2_kernel<H, BN, BK>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd(f16x2): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int per_cu = lds_bytes * 2 <= (size_t)LDS_LIMIT_BYTES ? 2 : 1;
+    kern<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * per_cu)), dim3(64 * (H / 32 / BN) * (H / 32 / BK)), lds_bytes, s>>>(w, n, stash);
+    return tn::check_launch("wgrad_f2_kernel");
 }
 
 template <int H, bool LAST>
@@ -482,6 +699,14 @@ __attribute__((visibility("hidden"))) int launch_dgrad_f2(int H, const DgradArgs
 {
     if (H == 256) return launch_dgrad<256>(d, n, stash, s);
     if (H == 128) return launch_dgrad<128>(d, n, stash, s);
+    return tn::fail(TN_E_CONFIG, "mlp_bwd(f16x2): width 128 or 256");
+}
+
+__attribute__((visibility("hidden"))) int launch_wgrad_f2(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s)
+{
+    if (w.first || w.N != H || w.K != H || !w.g_max || !w.a_max) return tn::fail(TN_E_CONFIG, "mlp_bwd(f16x2): square hidden layers with both maxima");
+    if (H == 256) return launch_wgrad<256, 4, 2>(w, n, stash, s);
+    if (H == 128) return launch_wgrad<128, 2, 2>(w, n, stash, s);
     return tn::fail(TN_E_CONFIG, "mlp_bwd(f16x2): width 128 or 256");
 }
 

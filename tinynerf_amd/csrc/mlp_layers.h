@@ -20,6 +20,7 @@ struct DgradArgs {
     int off_bits;                       // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
     int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
     int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
+    float *max_in = nullptr;            // f16x2: receives the largest |value| of the rows at off_gin (atomic max; scale of the layer's weight gradient)
 };
 
 // forward of one layer on workspace rows
@@ -30,6 +31,7 @@ struct FwdLayerArgs {
     int rows_total, off_in, off_out;
     int out_act;
     int off_bits;         // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
+    float *max_in = nullptr;            // f16x2: receives the largest |value| of the rows at off_in (see DgradArgs)
 };
 
 // weight gradient of one layer: dW[N][K] += G[N][s] A[K][s]^T over all samples; db[N] += sum_s G
@@ -38,6 +40,7 @@ struct WgradArgs {
     int N, K, K_pad;
     int rows_total, off_g, off_a, off_e;
     int first, enc, in_dim, n_freqs, xs;
+    const float *g_max = nullptr, *a_max = nullptr;       // f16x2: largest |value| of the G rows / of the A rows over ALL tiles
 };
 
 // Vector-memory instructions of these kernels use the SGPR-base form (wave-uniform 64-bit base + one 32-bit lane offset +
@@ -88,6 +91,7 @@ int launch_wgrad_b3(int H, const WgradArgs &w, int64_t n, const float *stash, hi
 // ---- f16x2 forms of the forward / data gradient (mlp_f2_layers.hip): two-term fp16 splits with power-of-two scales ----
 int launch_fwd_f2(int H, bool last, const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s);
 int launch_dgrad_f2(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s);
+int launch_wgrad_f2(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
 
 }  // namespace layers
 }  // namespace tn

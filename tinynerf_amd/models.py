@@ -26,10 +26,10 @@ from . import _lib as L
 # --------------------------------------------------------------------------------------------
 # Matrix products of the wide stacks (Vanilla 256 x 10, Cobafa 128 x 6): "bf16x3" = bf16 matrix cores with exact three-way
 # operand splits (TN_MLP_BF16X3: results equal to fp32 rounding, 2.67 x the fp32 matrix rate), "fp32" = v_mfma_f32_32x32x2_f32.
-# TN_MATMUL=fp32 in the environment (or assigning "fp32" here) selects the plain fp32 instructions.
-# "f16x2" (TN_MLP_F16X2, round 4) = forward and data-gradient layers on the fp16 matrix cores with two-term splits and power-of-two
-# scales (three products instead of six), weight gradients on bf16x3.
-MATMUL = os.environ.get("TN_MATMUL", "bf16x3").lower()
+# TN_MATMUL=fp32 / bf16x3 in the environment (or assigning here) selects them; the default is
+# "f16x2" (TN_MLP_F16X2, round 4) = all three passes of the hidden layers on the fp16 matrix cores with two-term operand splits and
+# power-of-two scales (three products instead of six; csrc/mlp_f2_layers.hip).
+MATMUL = os.environ.get("TN_MATMUL", "f16x2").lower()
 if MATMUL not in ("fp32", "bf16x3", "f16x2"):
     raise RuntimeError(f"TN_MATMUL={MATMUL}: fp32, bf16x3 or f16x2")
 

@@ -9,6 +9,6 @@ python3 - /tmp/ks_$tag <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
-    for r in rows[:12]:
+    for r in rows[:int(__import__("os").environ.get("KS_TOP", "12"))]:
         print("%9.3f ms %5s calls %9.1f us avg  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "")[:100]))
 PY

@@ -14,6 +14,7 @@
 //   TN_ENC_DIR_CAT : enc(x, d) = cat[PE_F(d), d, x]          (models.py:79-89, VanillaColorDecoder)
 // Output activations: exp(y-1) (models.py:74) and sigmoid (models.py:85).
 #include "mlp_stage.h"
+#include "mlp_f2_heads.h"
 #include "kplanes_device.h"
 #include <algorithm>
 
@@ -48,16 +49,25 @@ struct KpFwd {
 // FAST: every head takes the plain-column first layer (TN_ENC_NONE with in_dim % 4 == 0, or TN_ENC_AUX_CAT).  Compiled
 // separately because the generic first layer drags the sin / cos range reduction of the fused encodings into the kernel
 // (14 k VALU instructions, ~120 KB of code against a 64 KB instruction cache shared by two CUs).
-template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false>
+// F2 (with FAST, WLDS, H = 64, <= 4 outputs): the layers on the fp16 matrix cores as two-term splits with power-of-two scales
+// (mlp_f2_heads.h) -- same inputs, same outputs, same workspace rows.
+#ifndef TN_F2_KP_WAVES
+#define TN_F2_KP_WAVES 8
+#endif
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false, bool F2 = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
                                                            const float *__restrict__ aux0, int64_t n,
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
                                                            float *__restrict__ stash0, FwdPair pr, KpFwd kp = KpFwd())
 {
     static_assert(!KP || (FAST && H == 64), "the fused gather feeds the plain-column first layer of the width-64 heads");
+    static_assert(!F2 || (FAST && WLDS && H == 64), "f16x2 heads: plain-column first layer, weights in LDS, width 64");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
-    if constexpr (WLDS) {
+    if constexpr (F2) {
+        stage_weights_f2(a0, lds);
+        if constexpr (PAIR) stage_weights_f2(pr.b, lds + a0.lds_floats);
+    } else if constexpr (WLDS) {
         stage_weights(a0, lds);
         if constexpr (PAIR) stage_weights(pr.b, lds + a0.lds_floats);
         __syncthreads();
@@ -96,6 +106,179 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             }
         }
       }
+      // F2 + KP: the gathered features as fp16 B operands, converted once for both heads (k block b = groups 2 b, 2 b + 1)
+      u32x4h xbh[(F2 && KP) ? 6 : 1], xbl[(F2 && KP) ? 6 : 1];
+      float inv_x = 1.0f;
+      if constexpr (F2 && KP) {
+          float m = 0.0f;
+#pragma unroll
+          for (int g = 0; g < 12; ++g)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) m = fmaxf(m, fabsf(fr[g][u]));
+          float s_x;
+          f2_scales(f2_xmax(m), s_x, inv_x);
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+              const float v[8] = {fr[2 * b][0], fr[2 * b][1], fr[2 * b][2], fr[2 * b][3], fr[2 * b + 1][0], fr[2 * b + 1][1], fr[2 * b + 1][2], fr[2 * b + 1][3]};
+              f2_split8(v, s_x, xbh[b], xbl[b]);
+          }
+      }
+      auto head2 = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
+                       float *__restrict__ pre_act, float *__restrict__ stash) {
+        if constexpr (F2) {
+        const int L = a.n_layers;
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        const int64_t row = tile * 32 + j;
+        const bool valid = row < n;
+        if constexpr (!STASH) {
+            if (a.row_gate != nullptr) {
+                const float gate = valid ? a.row_gate[row] : 0.0f;
+                if (!__any(gate != 0.0f)) {
+                    if (valid && h == 0) {
+                        for (int o = 0; o < a.out_dim; ++o) {
+                            y[row * a.out_dim + o] = 0.0f;
+                            if (pre_act) pre_act[row * a.out_dim + o] = 0.0f;
+                        }
+                    }
+                    return;
+                }
+            }
+        }
+        float *stH = nullptr, *stQ = nullptr;
+        unsigned *stM = nullptr;
+        if constexpr (STASH) {
+            const int NH = L - 1;
+            stH = stash + tile * (int64_t)(stash_rows(H, NH, 0) * 32);
+            stQ = stH + stash_rows_w(H, NH, 0) * 32;
+            stM = reinterpret_cast<unsigned *>(stQ + 4 * 32);
+        }
+        const float *scl = ldsw + a.f2_scale;
+        // ---- layer 0: x columns, then the per-ray table columns, each with its own per-sample scale ----
+        const _Float16 *W0 = reinterpret_cast<const _Float16 *>(ldsw + a.w_off[0]);
+        const int plane0 = a.f2_plane[0], st0 = a.stride[0];
+        const int nbx = a.in_dim >> 4;
+        f32x16 acc[T];
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ob][r] = 0.0f;
+        float inv0;
+        if constexpr (KP) {
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f2_block(W0, plane0, st0, j, h, b, xbh[b], xbl[b], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            inv0 = inv_x;
+        } else {
+            // (all loads unconditional from clamped rows, see the fp32 path) pass 1: the column maximum; pass 2: convert + multiply
+            const float *xr = x + (valid ? row : 0) * a.in_dim + 4 * h;
+            float m = 0.0f;
+            for (int b = 0; b < nbx; ++b) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + 16 * b), v1 = *reinterpret_cast<const f32x4 *>(xr + 16 * b + 8);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[0]), fabsf(v0[1]))), fmaxf(fmaxf(fabsf(v0[2]), fabsf(v0[3])), fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])))));
+            }
+            float s_x;
+            f2_scales(f2_xmax(m), s_x, inv0);
+            f32x4 c0 = *reinterpret_cast<const f32x4 *>(xr), c1 = *reinterpret_cast<const f32x4 *>(xr + 8);
+            for (int b = 0; b < nbx; ++b) {
+                const int bn = b + 1 < nbx ? b + 1 : b;
+                const f32x4 n0 = *reinterpret_cast<const f32x4 *>(xr + 16 * bn), n1 = *reinterpret_cast<const f32x4 *>(xr + 16 * bn + 8);
+                const float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                u32x4h bh, bl;
+                f2_split8(v, s_x, bh, bl);
+                f2_block(W0, plane0, st0, j, h, b, bh, bl, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1;
+            }
+        }
+        f32x16 act[T];
+        {
+            const float c = inv0 * scl[1];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) {
+                tn::pin16(acc[ob]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[ob][r] = acc[ob][r] * c;
+            }
+        }
+        if (a.enc == TN_ENC_AUX_CAT) {                       // (wave-uniform)
+            const float *arow = aux + (int64_t)(a.aux_index ? a.aux_index[valid ? row : 0] : (valid ? row : 0)) * a.aux_stride + 4 * h;
+            const int nga = (a.K0_pad - a.in_dim) >> 3;      // groups of 8 table columns (7 for [PE_8(d), d, 0...])
+            f32x4 av[8];
+            float m = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {                    // (groups past the table repeat the last one: their weights are zero)
+                av[g] = *reinterpret_cast<const f32x4 *>(arow + 8 * (g < nga ? g : nga - 1));
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(av[g][0]), fabsf(av[g][1]))), fmaxf(fabsf(av[g][2]), fabsf(av[g][3])));
+            }
+            float s_a, inv_a;
+            f2_scales(f2_xmax(m), s_a, inv_a);
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ob][r] = 0.0f;
+            const int nba = (a.K0_pad - a.in_dim + 15) >> 4;
+#pragma unroll
+            for (int ba = 0; ba < 4; ++ba) {
+                if (ba < nba) {
+                    const float v[8] = {av[2 * ba][0], av[2 * ba][1], av[2 * ba][2], av[2 * ba][3], av[2 * ba + 1][0], av[2 * ba + 1][1], av[2 * ba + 1][2], av[2 * ba + 1][3]};
+                    u32x4h bh, bl;
+                    f2_split8(v, s_a, bh, bl);
+                    f2_block(W0, plane0, st0, j, h, nbx + ba, bh, bl, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const float c = inv_a * scl[1];
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) {
+                tn::pin16(acc[ob]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[ob][r] = fmaf(acc[ob][r], c, act[ob][r]);
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < T; ++ob) {
+            const f32x16 bias = tn::bias_tile(ldsw + a.b_off[0], ob, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[ob][r] += bias[r];
+            act[ob] = tn::relu16(act[ob]);
+            if constexpr (STASH) { stM[ob * 64 + lane] = relu_bits(act[ob]); store_rows(stH, act[ob], ob, j, h); }
+        }
+        // ---- hidden layers ----
+        for (int l = 1; l + 1 < L; ++l) {
+            hidden_layer_f2(ldsw, a, l, act, j, h);
+            if constexpr (STASH) {
+#pragma unroll
+                for (int ob = 0; ob < T; ++ob) {
+                    stM[(l * T + ob) * 64 + lane] = relu_bits(act[ob]);
+                    store_rows(stH + l * H * 32, act[ob], ob, j, h);
+                }
+            }
+        }
+        // ---- output layer (<= 4 outputs: fp32 dot products on the VALU, as in the fp32 path) ----
+        const float *Wf = ldsw + a.w_off[L - 1];
+        const float *Bf = ldsw + a.b_off[L - 1];
+        const int sf = a.stride[L - 1];
+        const int out = a.out_dim;
+        float o4[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            o4[o] = 0.f;
+            if (o < out) o4[o] = tn::small_out<H>(Wf + o * sf, Bf[o], act, h);
+            if constexpr (STASH) { if (h == 0) stQ[o * 32 + j] = o4[o]; }
+        }
+        if (valid && h == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < out) {
+                    if (pre_act) pre_act[row * out + o] = o4[o];
+                    y[row * out + o] = tn::apply_act(o4[o], a.out_act);
+                }
+        }
+        }
+      };
       auto head = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
                       float *__restrict__ pre_act, float *__restrict__ stash) {
         const int L = a.n_layers;
@@ -323,8 +506,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             }
         }
       };
-      head(a0, lds, aux0, y0, pre_act0, stash0);
-      if constexpr (PAIR) head(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
+      if constexpr (F2) {
+          head2(a0, lds, aux0, y0, pre_act0, stash0);
+          if constexpr (PAIR) head2(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
+      } else {
+          head(a0, lds, aux0, y0, pre_act0, stash0);
+          if constexpr (PAIR) head(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
+      }
     }
 }
 
@@ -346,14 +534,26 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t n, int C, con
 }
 
 template <int H>
-int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s,
+int launch_fwd(const MlpArgs &a_in, const float *x, const float *aux, int64_t n, float *y, float *pre_act, float *stash, hipStream_t s,
                const FwdPair *pair = nullptr, const KpFwd *kp = nullptr)
 {
     const int64_t n_tiles = (n + 31) / 32;
-    size_t lds_bytes = (size_t)a.lds_floats * 4;
+    MlpArgs a = a_in;
     FwdPair pr;
     pr.aux = nullptr; pr.y = nullptr; pr.stash = nullptr;
-    if (pair) { pr = *pair; lds_bytes += (size_t)pr.b.lds_floats * 4; } else pr.b = a;
+    if (pair) pr = *pair;
+    // f16x2 heads (TN_MLP_F16X2, mlp_f2_heads.h): same launch, the weights staged as fp16 hi / lo planes
+    bool f2 = false;
+    if constexpr (H == 64) {
+        f2 = f2_head_ok(a, H) && (!pair || f2_head_ok(pr.b, H)) && (!kp || a.in_dim == 96);
+        if (f2) { plan_f2(a, H); if (pair) plan_f2(pr.b, H); }
+    }
+    size_t lds_bytes = (size_t)a.lds_floats * 4;
+    if (pair) lds_bytes += (size_t)pr.b.lds_floats * 4; else pr.b = a;
+    if (f2 && lds_bytes > (size_t)LDS_LIMIT_BYTES) {       // (cannot happen for the reference's heads; keep the fp32 form otherwise)
+        f2 = false; a = a_in; if (pair) pr = *pair; else pr.b = a;
+        lds_bytes = (size_t)a.lds_floats * 4 + (pair ? (size_t)pr.b.lds_floats * 4 : 0);
+    }
     const bool wlds = lds_bytes <= (size_t)LDS_LIMIT_BYTES && a.enc != -1;
     auto plain_cols = [](const MlpArgs &m) { return m.enc == TN_ENC_AUX_CAT || (m.enc == TN_ENC_NONE && (m.in_dim & 3) == 0); };
     const bool fast = wlds && plain_cols(a) && (!pair || plain_cols(pr.b));
@@ -372,31 +572,46 @@ int launch_fwd(const MlpArgs &a, const float *x, const float *aux, int64_t n, fl
             int rc;
             if (kp) {                   // gather fused in: 12 waves (170-VGPR budget: 48 registers hold the tile's features)
                 if (!(fast && pair)) return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd_pair: both heads must take the plain-column first layer");
-                constexpr int wv = 12;       // (8 waves x 256 VGPRs measured the same: 0.86 ms)
-                auto kern = mlp_fwd_kernel<H, true, wv, true, true, true, true>;
-                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-                const int64_t blocks = std::min<int64_t>((n_tiles + wv - 1) / wv, 256);
-                kern<<<dim3((unsigned)blocks), dim3(wv * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+                auto go = [&](auto kern, int wv) -> int {
+                    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                    if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+                    const int64_t blocks = std::min<int64_t>((n_tiles + wv - 1) / wv, 256);
+                    kern<<<dim3((unsigned)blocks), dim3(wv * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+                    return TN_OK;
+                };
+                // fp32 heads: 12 waves (8 waves x 256 VGPRs measured the same: 0.86 ms)
+                const int rc = f2 ? go(mlp_fwd_kernel<H, true, TN_F2_KP_WAVES, true, true, true, true, true>, TN_F2_KP_WAVES)
+                                  : go(mlp_fwd_kernel<H, true, 12, true, true, true, true>, 12);
+                if (rc) return rc;
                 return tn::check_launch("mlp_fwd_kernel(kplanes)");
             }
-            if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
+            if (f2) rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true>, 12);
+            else if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
             else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
             if (rc) return rc;
         } else return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: the register-resident training forward is built for width 64");
     } else if (wlds && kp) {      // inference: gather + one head (the sigma head; the colour head then reads the feature rows where w > 0)
         if constexpr (H == 64) {          // ... or gather + BOTH heads, nothing stashed, no feature rows (pair != nullptr)
             if (!fast) return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd: the head must take the plain-column first layer");
-            auto kern = pair ? mlp_fwd_kernel<H, true, 12, false, true, true, true> : mlp_fwd_kernel<H, true, 12, false, false, true, true>;
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (12 * 64)));
-            const int64_t blocks = std::min<int64_t>((n_tiles + 11) / 12, 256 * per_cu);
-            kern<<<dim3((unsigned)blocks), dim3(12 * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+            auto go = [&](auto kern, int wv) -> int {
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wv * 64)));
+                const int64_t blocks = std::min<int64_t>((n_tiles + wv - 1) / wv, 256 * per_cu);
+                kern<<<dim3((unsigned)blocks), dim3(wv * 64), lds_bytes, s>>>(a, x, aux, n, y, pre_act, stash, pr, *kp);
+                return TN_OK;
+            };
+            // (the f16x2 pair holds the fp16 features beside both heads' tiles: 8 waves x 256 VGPRs, as in training)
+            const int rc = f2 ? (pair ? go(mlp_fwd_kernel<H, true, TN_F2_KP_WAVES, false, true, true, true, true>, TN_F2_KP_WAVES)
+                                      : go(mlp_fwd_kernel<H, true, 12, false, false, true, true, true>, 12))
+                              : (pair ? go(mlp_fwd_kernel<H, true, 12, false, true, true, true>, 12)
+                                      : go(mlp_fwd_kernel<H, true, 12, false, false, true, true>, 12));
+            if (rc) return rc;
             return tn::check_launch("mlp_fwd_kernel(kplanes, inference)");
         } else return tn::fail(TN_E_CONFIG, "tn_kplanes_mlp_fwd: width-64 heads only");
     } else if (wlds) {
         auto kern = fast ? mlp_fwd_kernel<H, true, WPB, false, false, true> : mlp_fwd_kernel<H, true, WPB, false, false, false>;
+        if constexpr (H == 64) { if (f2) kern = mlp_fwd_kernel<H, true, WPB, false, false, true, false, true>; }
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { tn::set_error("mlp: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPB * 64)));

@@ -27,6 +27,7 @@ struct MlpArgs {
     int64_t x_rows_stride, gx_rows_stride;
     int b3;                // TN_MLP_BF16X3 (or TN_MLP_F16X2, which implies it for the weight gradients)
     int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
+    int f2_plane[TN_MLP_MAX_LAYERS], f2_scale;     // f16x2 heads (mlp_f2_heads.h): halfs per weight plane, float index of the (s, 1 / s) pairs
 };
 
 // column of the torch weight matrix that feeds first-layer slot q (slot order: see fetch_input)

@@ -46,11 +46,20 @@ def golden():
 
 @pytest.fixture(params=["bf16x3", "fp32", "f16x2"])
 def matmul(request, monkeypatch):
-    """Both matrix modes of the wide stacks (tinynerf_amd.models.MATMUL): "bf16x3" -- the default: exact three-way bf16 splits on
-    v_mfma_f32_32x32x16_bf16 --, "fp32" (v_mfma_f32_32x32x2_f32) and "f16x2" (round 4: forward / data gradient as two-term fp16 splits
-    with power-of-two scales on v_mfma_f32_32x32x16_f16, weight gradients on bf16x3).  Every golden / oracle comparison that runs a 128- or 256-wide
-    stack takes this fixture, so that BOTH kernel families are held against the reference directly (round-3 verdict: the fp32-MFMA
-    layer kernels were only covered transitively, HIP against HIP)."""
+    """The three matrix modes of the wide stacks (tinynerf_amd.models.MATMUL): "f16x2" -- the default since round 4: two-term fp16
+    splits with power-of-two scales on v_mfma_f32_32x32x16_f16 in the forward, data-gradient and weight-gradient layer kernels --,
+    "bf16x3" (exact three-way bf16 splits on v_mfma_f32_32x32x16_bf16) and "fp32" (v_mfma_f32_32x32x2_f32).  Every golden / oracle
+    comparison that runs a 128- or 256-wide stack takes this fixture, so that ALL kernel families are held against the reference
+    directly (round-3 verdict: the fp32-MFMA layer kernels were only covered transitively, HIP against HIP)."""
+    from tinynerf_amd import models
+    monkeypatch.setattr(models, "MATMUL", request.param)
+    return request.param
+
+
+@pytest.fixture(params=["f16x2", "fp32"])
+def heads(request, monkeypatch):
+    """Both arithmetic forms of the width-64 heads' forward (mlp_f2_heads.h: f16x2 under MATMUL == "f16x2", the fp32 MFMA otherwise):
+    the K-Planes golden / oracle comparisons take this fixture."""
     from tinynerf_amd import models
     monkeypatch.setattr(models, "MATMUL", request.param)
     return request.param

@@ -28,7 +28,7 @@ def build_renderer(g, bg=True):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_renderer_forward_backward_vs_reference(fused):
+def test_renderer_forward_backward_vs_reference(fused, heads):
     """fused = one autograd node over the C-ABI kernels; not fused = module-by-module like the reference."""
     g = load_golden("G9_renderer_kplanes")
     r = build_renderer(g)
@@ -60,7 +60,7 @@ def test_renderer_forward_backward_vs_reference(fused):
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["rendered_nobg"], rtol=0, atol=TOL)
 
 
-def test_renderer_intermediates():
+def test_renderer_intermediates(heads):
     from tinynerf_amd import core
     g = load_golden("G9_renderer_kplanes")
     r = build_renderer(g)
@@ -114,7 +114,7 @@ def test_fused_accumulates_into_existing_grads():
 
 
 @pytest.mark.parametrize("n_rays,per_ray", [(37, 29), (300, 113)])
-def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypatch):
+def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypatch, heads):
     """tn_kplanes_mlp_fwd_pair / tn_kplanes_mlp_bwd_pair (gather / scatter inside the MLP launches, north star) against
     tn_kplanes_fwd + tn_mlp_fwd_stash_pair and tn_mlp_bwd_pair + tn_kplanes_bwd:
     same arithmetic in the same order -> identical bits for the rendered colours (gradients: the same terms through fp32
@@ -149,7 +149,7 @@ def test_fused_gather_is_bit_identical_to_two_launches(n_rays, per_ray, monkeypa
 
 
 @pytest.mark.parametrize("n_rays,per_ray,sigma_bias", [(37, 29, 0.0), (300, 113, 0.0), (300, 113, 6.0), (1, 1, 0.0)])
-def test_inference_pair_form_is_bit_identical_to_the_gated_form(n_rays, per_ray, sigma_bias, monkeypatch):
+def test_inference_pair_form_is_bit_identical_to_the_gated_form(n_rays, per_ray, sigma_bias, monkeypatch, heads):
     """Round 4: the inference render has two forms -- gather + sigma head -> weights -> colour head on the live tiles -> composite
     (core.py:239-265 as the reference runs it), and gather + BOTH heads of every sample in one launch (tn_kplanes_mlp_fwd_pair with
     NULL workspaces) -> weights + composite.  A sample with w == 0 contributes exactly 0 in both, every other sample runs the same

@@ -55,7 +55,7 @@ def test_vanilla_training_matches_cpu_port():
     assert abs(p_hip - p_ref) < 0.1, (p_hip, p_ref)
 
 
-def test_kplanes_training_matches_cpu_port():
+def test_kplanes_training_matches_cpu_port(heads):
     """K-Planes recipe (fused render path, TV regulariser, plane-gradient scatter, Adam on channel-last planes)
     with 16/32/64 planes so the CPU port finishes in seconds."""
     from tinynerf_amd.run import TrainConfig, Trainer, psnr
@@ -189,7 +189,7 @@ def test_train_entry_point_on_a_scene_on_disk(tmp_path):
 
 
 @pytest.mark.parametrize("method", ["vanilla", "kplanes", "cobafa"])
-def test_inference_chunking_and_no_training_state(method):
+def test_inference_chunking_and_no_training_state(method, heads):
     """infer(): rays are independent, so the chunk size must not change one output bit (the default walks an image in 2^16-ray
     chunks instead of the reference's training batch size, run.py:35-43); and inside torch.no_grad() no module may take its
     training forward (the wide stacks' activation workspace is 10 KB per sample)."""

@@ -18,6 +18,23 @@
 #include "kplanes_device.h"
 #include <algorithm>
 
+#ifdef TN_PHASE_TIMERS
+__device__ unsigned long long tn_phase_cycles[16];
+#define TN_PT_BEGIN unsigned long long pt_ = __builtin_amdgcn_s_memtime();
+#define TN_PTG_BEGIN unsigned long long ptg_ = __builtin_amdgcn_s_memtime();
+#define TN_PTG(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&tn_phase_cycles[k], n_ - ptg_); ptg_ = n_; }
+#define TN_PT(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&tn_phase_cycles[k], n_ - pt_); pt_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int tn_debug_phase_cycles(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(tn_phase_cycles), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(tn_phase_cycles), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define TN_PT_BEGIN
+#define TN_PT(k)
+#define TN_PTG_BEGIN
+#define TN_PTG(k)
+#endif
 namespace {
 
 using tn::f32x16;
@@ -54,7 +71,10 @@ struct KpFwd {
 #ifndef TN_F2_KP_WAVES
 #define TN_F2_KP_WAVES 8
 #endif
-template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false, bool F2 = false>
+// XB (F2 without KP): the first layer's 16 XB x columns of a sample stay in registers between the column maximum and the products
+// (in_dim == 16 XB): ONE round of loads per tile instead of two dependent passes over the row -- at 256 inputs and 12 waves per
+// CU the two passes were the launch (0.56 ms for 0.55 M samples: ~32 exposed L2 round trips per tile and wave).
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false, bool F2 = false, int XB = 0>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
                                                            const float *__restrict__ aux0, int64_t n,
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
@@ -77,6 +97,24 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
     const int64_t n_tiles = (n + 31) >> 5;
 
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+      // F2: the per-ray table columns of the TN_ENC_AUX_CAT head (ray index -> table row: two dependent round trips) are requested
+      // before the gather / the x columns instead of in the middle of the first layer, where nothing hides them
+      constexpr bool PREF = F2 && (STASH || WPB <= 8);      // (the 12- / 16-wave inference forms have no registers to spare)
+      f32x4 avp[PREF ? 8 : 1];
+      const bool pref_second = PAIR && pr.b.enc == TN_ENC_AUX_CAT;
+      if constexpr (PREF) {
+          const MlpArgs &ax = pref_second ? pr.b : a0;
+          if (ax.enc == TN_ENC_AUX_CAT) {                       // (wave-uniform)
+              const float *auxp = pref_second ? pr.aux : aux0;
+              const int64_t row = tile * 32 + j_;
+              const int64_t rc = row < n ? row : 0;
+              const float *arow = auxp + (int64_t)(ax.aux_index ? ax.aux_index[rc] : rc) * ax.aux_stride + 4 * h_;
+              const int nga = (ax.K0_pad - ax.in_dim) >> 3;
+#pragma unroll
+              for (int g = 0; g < 8; ++g) avp[g] = *reinterpret_cast<const f32x4 *>(arow + 8 * (g < nga ? g : nga - 1));
+          }
+      }
+      TN_PTG_BEGIN
       f32x4 fr[KP ? 12 : 1];                 // KP: the tile's feature rows as first-layer operands (slots 8g + 4h .. +3)
       if constexpr (KP) {
         int j = j_, h = h_;
@@ -123,8 +161,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
               f2_split8(v, s_x, xbh[b], xbl[b]);
           }
       }
+      TN_PTG(8)
       auto head2 = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
-                       float *__restrict__ pre_act, float *__restrict__ stash) {
+                       float *__restrict__ pre_act, float *__restrict__ stash, bool prefetched) {
         if constexpr (F2) {
         const int L = a.n_layers;
         int j = j_, h = h_;
@@ -154,6 +193,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             stM = reinterpret_cast<unsigned *>(stQ + 4 * 32);
         }
         const float *scl = ldsw + a.f2_scale;
+        TN_PT_BEGIN
         // ---- layer 0: x columns, then the per-ray table columns, each with its own per-sample scale ----
         const _Float16 *W0 = reinterpret_cast<const _Float16 *>(ldsw + a.w_off[0]);
         const int plane0 = a.f2_plane[0], st0 = a.stride[0];
@@ -172,14 +212,35 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             }
             inv0 = inv_x;
         } else {
-            // (all loads unconditional from clamped rows, see the fp32 path) pass 1: the column maximum; pass 2: convert + multiply
+            // (all loads unconditional from clamped rows, see the fp32 path)
             const float *xr = x + (valid ? row : 0) * a.in_dim + 4 * h;
+            float s_x;
+            if constexpr (XB > 0) {
+                f32x4 xv[2 * XB];
+#pragma unroll
+                for (int b = 0; b < XB; ++b) {
+                    xv[2 * b] = *reinterpret_cast<const f32x4 *>(xr + 16 * b);
+                    xv[2 * b + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * b + 8);
+                }
+                float m = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 2 * XB; ++e) m = fmaxf(fmaxf(m, fmaxf(fabsf(xv[e][0]), fabsf(xv[e][1]))), fmaxf(fabsf(xv[e][2]), fabsf(xv[e][3])));
+                f2_scales(f2_xmax(m), s_x, inv0);
+#pragma unroll
+                for (int b = 0; b < XB; ++b) {
+                    const float v[8] = {xv[2 * b][0], xv[2 * b][1], xv[2 * b][2], xv[2 * b][3], xv[2 * b + 1][0], xv[2 * b + 1][1], xv[2 * b + 1][2], xv[2 * b + 1][3]};
+                    u32x4h bh, bl;
+                    f2_split8(v, s_x, bh, bl);
+                    f2_block(W0, plane0, st0, j, h, b, bh, bl, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+            // pass 1: the column maximum; pass 2: convert + multiply
             float m = 0.0f;
             for (int b = 0; b < nbx; ++b) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + 16 * b), v1 = *reinterpret_cast<const f32x4 *>(xr + 16 * b + 8);
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[0]), fabsf(v0[1]))), fmaxf(fmaxf(fabsf(v0[2]), fabsf(v0[3])), fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])))));
             }
-            float s_x;
             f2_scales(f2_xmax(m), s_x, inv0);
             f32x4 c0 = *reinterpret_cast<const f32x4 *>(xr), c1 = *reinterpret_cast<const f32x4 *>(xr + 8);
             for (int b = 0; b < nbx; ++b) {
@@ -192,7 +253,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                 __builtin_amdgcn_sched_barrier(0);
                 c0 = n0; c1 = n1;
             }
+            }
         }
+        TN_PT(0)
         f32x16 act[T];
         {
             const float c = inv0 * scl[1];
@@ -203,6 +266,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                 for (int r = 0; r < 16; ++r) act[ob][r] = acc[ob][r] * c;
             }
         }
+        TN_PT(1)
         if (a.enc == TN_ENC_AUX_CAT) {                       // (wave-uniform)
             const float *arow = aux + (int64_t)(a.aux_index ? a.aux_index[valid ? row : 0] : (valid ? row : 0)) * a.aux_stride + 4 * h;
             const int nga = (a.K0_pad - a.in_dim) >> 3;      // groups of 8 table columns (7 for [PE_8(d), d, 0...])
@@ -210,7 +274,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             float m = 0.0f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {                    // (groups past the table repeat the last one: their weights are zero)
-                av[g] = *reinterpret_cast<const f32x4 *>(arow + 8 * (g < nga ? g : nga - 1));
+                if (PREF && prefetched) av[g] = avp[PREF ? g : 0];
+                else av[g] = *reinterpret_cast<const f32x4 *>(arow + 8 * (g < nga ? g : nga - 1));
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(av[g][0]), fabsf(av[g][1]))), fmaxf(fabsf(av[g][2]), fabsf(av[g][3])));
             }
             float s_a, inv_a;
@@ -246,9 +311,11 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             act[ob] = tn::relu16(act[ob]);
             if constexpr (STASH) { stM[ob * 64 + lane] = relu_bits(act[ob]); store_rows(stH, act[ob], ob, j, h); }
         }
+        TN_PT(3)
         // ---- hidden layers ----
         for (int l = 1; l + 1 < L; ++l) {
             hidden_layer_f2(ldsw, a, l, act, j, h);
+            TN_PT(4)
             if constexpr (STASH) {
 #pragma unroll
                 for (int ob = 0; ob < T; ++ob) {
@@ -257,6 +324,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                 }
             }
         }
+        TN_PT(5)
         // ---- output layer (<= 4 outputs: fp32 dot products on the VALU, as in the fp32 path) ----
         const float *Wf = ldsw + a.w_off[L - 1];
         const float *Bf = ldsw + a.b_off[L - 1];
@@ -277,6 +345,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
                     y[row * out + o] = tn::apply_act(o4[o], a.out_act);
                 }
         }
+        TN_PT(6)
         }
       };
       auto head = [&](const MlpArgs &a, const float *ldsw, const float *__restrict__ aux, float *__restrict__ y,
@@ -507,8 +576,9 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
         }
       };
       if constexpr (F2) {
-          head2(a0, lds, aux0, y0, pre_act0, stash0);
-          if constexpr (PAIR) head2(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
+          head2(a0, lds, aux0, y0, pre_act0, stash0, !pref_second);
+          if constexpr (PAIR) head2(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash, pref_second);
+          TN_PTG(9)
       } else {
           head(a0, lds, aux0, y0, pre_act0, stash0);
           if constexpr (PAIR) head(pr.b, lds + a0.lds_floats, pr.aux, pr.y, nullptr, pr.stash);
@@ -585,7 +655,9 @@ int launch_fwd(const MlpArgs &a_in, const float *x, const float *aux, int64_t n,
                 if (rc) return rc;
                 return tn::check_launch("mlp_fwd_kernel(kplanes)");
             }
-            if (f2) rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true>, 12);
+            if (f2 && !pair && a.in_dim == 256) rc = launch(mlp_fwd_kernel<H, true, 8, true, false, true, false, true, 16>, 8);      // (x: 128 VGPRs)
+            else if (f2 && !pair && a.in_dim == 128) rc = launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true, 8>, 12);
+            else if (f2) rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true>, 12);
             else if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);
             else rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, false>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, false>, 12);
             if (rc) return rc;

@@ -198,6 +198,15 @@ enum { TN_ENC_NONE = 0,
                                  * (csrc/mlp_f2_layers.hip).  The workspace's last 256 bytes carry the per-layer maxima between
                                  * the launches of a step.  Default of tinynerf_amd.models. */
 
+#define TN_MLP_ROWS_ONLY 128    /* tn_mlp_fwd_stash of a layer-by-layer stack that offers row views (tn_mlp_rows_view) under TN_MLP_F16X2:
+                                 * y is NOT written -- the output exists only as the workspace's [feature][32-sample] rows, which the
+                                 * consumer reads through tn_mlp_desc::x_rows (TN_MLP_X_FROM_ROWS).  Saves the 4 * out bytes per
+                                 * sample of the row-major copy.  `y` must still be a valid pointer. */
+#define TN_MLP_X_FROM_ROWS 256  /* tn_mlp_fwd_stash of a width-64 head: x is read from x_rows ONLY (the producer ran with
+                                 * TN_MLP_ROWS_ONLY; `x` is not dereferenced).  TN_E_CONFIG unless the launch is one that reads the row
+                                 * view: TN_MLP_F16X2, in_dim 128 or 256, <= 4 outputs.  Without the flag such a launch still
+                                 * prefers x_rows when they are set (coalesced 128-byte rows instead of 16 bytes per lane and sample). */
+
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
     int32_t in_dim;                           /* width of x (before encoding)                 */
@@ -223,7 +232,8 @@ typedef struct tn_mlp_desc {
      * exchange both with it without a row-major round trip:
      *   x_rows       value of feature f of sample 32 t + j at x_rows[t * x_rows_tile_stride + 32 f + j] (samples >= n: 0).
      *                tn_mlp_bwd (two-pass form, TN_MLP_STASHED) then takes the first layer's weight gradient over the x
-     *                columns from these rows; needs in_dim % 32 == 0.  x itself is still required.
+     *                columns from these rows; needs in_dim % 32 == 0.  tn_mlp_fwd_stash (f16x2 heads, in_dim 128 / 256) reads
+     *                its first-layer operands from them.  x itself is still required unless TN_MLP_X_FROM_ROWS says otherwise.
      *   grad_x_rows  tn_mlp_bwd writes (TN_MLP_ACCUM_GRAD_X: adds) d loss / d x there, same layout, INSTEAD of grad_x. */
     const float *x_rows;
     float *grad_x_rows;

@@ -435,3 +435,52 @@ def test_gradients_along_the_reference_trajectory(method, res, n_steps, matmul):
     # here; with 1e-3 the trajectory keeps real gradients.  The HIP optimizer plays no part: parameters come from the port.)
     assert len(checked) == n_steps and sum(1 for _, f in checked if f >= 0) >= 4, checked       # steps with a real gradient
     np.testing.assert_allclose(hip_losses, ref_losses, rtol=2e-5)     # every step's loss (MSE + TV), on identical parameters
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vanilla", "cobafa"])
+def test_heads_read_the_stack_output_from_workspace_rows(method, monkeypatch):
+    """Round 4: behind a 256- / 128-wide stack the f16x2 heads take their first-layer operands from the stack's workspace rows
+    (tn_mlp_desc::x_rows in tn_mlp_fwd_stash) and, from the second forward on, the stack no longer writes the row-major copy
+    (TN_MLP_ROWS_ONLY + TN_MLP_X_FROM_ROWS).  Same values through the same arithmetic: the loss of every step equals the
+    row-major run's (TN_ROWS_HANDOFF=0) up to the order of the gradient atomics behind the earlier updates; the row-major
+    tensor really stays unwritten (poisoned with NaN here: nothing may read it)."""
+    from tinynerf_amd import fused, models
+    from tinynerf_amd.run import TrainConfig, Trainer
+    if models.MATMUL != "f16x2":
+        pytest.skip("row handoff is the f16x2 heads' path")
+    o, d, rgb = _scene()
+    losses = {}
+    for handoff in (False, True):
+        monkeypatch.setattr(fused, "ROWS_HANDOFF", handoff)
+        cfg = TrainConfig(method=method, scene_type="aabb", batch_size=256, n_samples=32, seed=3, occupancy_res=32, deterministic=True)
+        tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+        for group in tr.optimizer.param_groups:          # (the recipe's 1e-2 masks every sample of this scene within two steps)
+            group["lr"] = 1e-3
+        if method == "cobafa":
+            tr.renderer.feature_module.dropout.p = 0.0
+        seen = []
+        if handoff:
+            real = models._empty_rows
+
+            def poisoned(n, cols, dev):                    # the stack's y comes from here: reading it would spread NaN
+                t = real(n, cols, dev)
+                if cols in (128, 256):
+                    t.fill_(float("nan"))
+                return t
+            monkeypatch.setattr(models, "_empty_rows", poisoned)
+        ls = []
+        for _ in range(4):
+            tr.step()
+            ls.append(tr.loss_value())
+            prod = tr.renderer.__dict__.get("_rows_producer")
+            seen.append(bool(prod is not None and prod.__dict__["scratch"][2].get("rows_only")))
+        losses[handoff] = ls
+        if handoff:
+            assert seen == [False, True, True, True], seen          # the first forward discovers the producer
+            monkeypatch.setattr(models, "_empty_rows", real)
+        else:
+            assert not any(seen)
+    assert all(np.isfinite(losses[True])), losses
+    np.testing.assert_allclose(losses[True][0], losses[False][0], rtol=1e-6)
+    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-4)

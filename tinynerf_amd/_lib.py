@@ -64,6 +64,8 @@ MLP_WGRAD_ONLY = 8
 MLP_GRAD_Y_ROWS = 16
 MLP_BF16X3 = 32
 MLP_F16X2 = 64
+MLP_ROWS_ONLY = 128
+MLP_X_FROM_ROWS = 256
 
 
 class PlaneRegItem(C.Structure):

@@ -217,10 +217,22 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
             float s_x;
             if constexpr (XB > 0) {
                 f32x4 xv[2 * XB];
+                if (a.x_rows != nullptr) {                   // (wave-uniform) row view of the producer's workspace: feature f of the
+                    // tile's sample j at [32 f + j] -- every load one 128-byte row per half-wave (samples >= n: zeros)
+                    const float *xt = a.x_rows + tile * a.x_rows_stride + (4 * h) * 32 + j;
+#pragma unroll
+                    for (int b = 0; b < XB; ++b)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            xv[2 * b][u] = xt[(16 * b + u) * 32];
+                            xv[2 * b + 1][u] = xt[(16 * b + 8 + u) * 32];
+                        }
+                } else {
 #pragma unroll
                 for (int b = 0; b < XB; ++b) {
                     xv[2 * b] = *reinterpret_cast<const f32x4 *>(xr + 16 * b);
                     xv[2 * b + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * b + 8);
+                }
                 }
                 float m = 0.0f;
 #pragma unroll
@@ -628,6 +640,8 @@ int launch_fwd(const MlpArgs &a_in, const float *x, const float *aux, int64_t n,
     auto plain_cols = [](const MlpArgs &m) { return m.enc == TN_ENC_AUX_CAT || (m.enc == TN_ENC_NONE && (m.in_dim & 3) == 0); };
     const bool fast = wlds && plain_cols(a) && (!pair || plain_cols(pr.b));
     constexpr int WPB = H <= 64 ? 16 : 4;     // 16 waves share one LDS copy of the weights: 4 waves per SIMD
+    if (a.x_from_rows && !(wlds && stash && H == 64 && !kp))
+        return tn::fail(TN_E_CONFIG, "mlp forward: TN_MLP_X_FROM_ROWS is only read by tn_mlp_fwd_stash of a width-64 f16x2 head");
     if (wlds && stash) {
         if constexpr (H == 64) {
             // stash variants: 12 waves (170-VGPR budget) for the generic first layer, 16 for the plain-column one (119 VGPRs)
@@ -655,6 +669,8 @@ int launch_fwd(const MlpArgs &a_in, const float *x, const float *aux, int64_t n,
                 if (rc) return rc;
                 return tn::check_launch("mlp_fwd_kernel(kplanes)");
             }
+            if (a.x_from_rows && !(f2 && !pair && a.x_rows != nullptr && (a.in_dim == 256 || a.in_dim == 128)))
+                return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: TN_MLP_X_FROM_ROWS needs an f16x2 head with 128 or 256 inputs and x_rows");
             if (f2 && !pair && a.in_dim == 256) rc = launch(mlp_fwd_kernel<H, true, 8, true, false, true, false, true, 16>, 8);      // (x: 128 VGPRs)
             else if (f2 && !pair && a.in_dim == 128) rc = launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true, 8>, 12);
             else if (f2) rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true>, 12);

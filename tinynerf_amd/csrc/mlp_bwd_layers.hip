@@ -1107,7 +1107,10 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 f.max_in = tail ? tail + l : nullptr;
                 // hidden layers (K == N == H) and the output layer (K == H, N <= H): weights in registers
                 int rc;
-                if (a.f2) rc = launch_fwd_f2(H, l + 1 == L, f, n, stash, y, s);        // fp16 matrix cores, two-term splits, scaled
+                // TN_MLP_ROWS_ONLY: the last layer leaves its output as workspace rows only (out == H, no output activation: the
+                // rows ARE y -- the conditions of tn_mlp_rows_view)
+                float *y_l = (l + 1 == L && a.rows_only && !inference && a.f2 && out == H && a.out_act == TN_ACT_NONE) ? nullptr : y;
+                if (a.f2) rc = launch_fwd_f2(H, l + 1 == L, f, n, stash, y_l, s);      // fp16 matrix cores, two-term splits, scaled
                 else if (a.b3) rc = launch_fwd_b3(H, l + 1 == L, f, n, stash, y, s);   // bf16 matrix cores, exact 3-way splits
                 else rc = l + 1 < L ? launch_fwd_wreg<H, false>(f, n, stash, y, s) : launch_fwd_wreg<H, true>(f, n, stash, y, s);
                 if (rc) return rc;

@@ -369,13 +369,15 @@ __global__ __launch_bounds__(F2Geom<H>::THREADS) void fwd_f2_kernel(FwdLayerArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) pre[r] = valid ? acc[r] : 0.0f;
             wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, pre);
-            float *yr = y + (valid ? row : 0) * H + 32 * ob + 4 * h;
+            if (y != nullptr) {                      // (TN_MLP_ROWS_ONLY: the consumer reads the rows)
+                float *yr = y + (valid ? row : 0) * H + 32 * ob + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = tn::apply_act(acc[4 * q + u], a.out_act);
-                if (valid) *reinterpret_cast<f32x4 *>(yr + 8 * q) = v;
+                    for (int u = 0; u < 4; ++u) v[u] = tn::apply_act(acc[4 * q + u], a.out_act);
+                    if (valid) *reinterpret_cast<f32x4 *>(yr + 8 * q) = v;
+                }
             }
         } else if (32 * ob < a.N) {
             float *outp = stash + (tile * a.rows_total + a.off_out + 32 * ob + 4 * h) * 32 + j;

@@ -27,6 +27,8 @@ struct MlpArgs {
     int64_t x_rows_stride, gx_rows_stride;
     int b3;                // TN_MLP_BF16X3 (or TN_MLP_F16X2, which implies it for the weight gradients)
     int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
+    int rows_only;         // TN_MLP_ROWS_ONLY (producer: no row-major y)
+    int x_from_rows;       // TN_MLP_X_FROM_ROWS (consumer: x only exists as x_rows)
     int f2_plane[TN_MLP_MAX_LAYERS], f2_scale;     // f16x2 heads (mlp_f2_heads.h): halfs per weight plane, float index of the (s, 1 / s) pairs
 };
 
@@ -203,6 +205,8 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     a.freqs = d->freqs; a.aux_index = d->aux_index; a.aux_stride = d->aux_stride; a.row_gate = d->row_gate;
     a.b3 = (d->flags & (TN_MLP_BF16X3 | TN_MLP_F16X2)) != 0;
     a.f2 = (d->flags & TN_MLP_F16X2) != 0;
+    a.rows_only = (d->flags & TN_MLP_ROWS_ONLY) != 0;
+    a.x_from_rows = (d->flags & TN_MLP_X_FROM_ROWS) != 0;
     a.x_rows = d->x_rows; a.gx_rows = d->grad_x_rows; a.x_rows_stride = d->x_rows_tile_stride; a.gx_rows_stride = d->grad_x_rows_tile_stride;
     TN_REQUIRE((!a.x_rows && !a.gx_rows) || ((a.in_dim & 31) == 0 && a.enc != TN_ENC_POSENC), TN_E_CONFIG,
                "mlp: x_rows / grad_x_rows need in_dim % 32 == 0 and an encoding that keeps x as input columns");

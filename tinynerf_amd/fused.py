@@ -24,6 +24,16 @@ from .arena import Arena
 from .models import _empty_rows, _hwc, _kplanes_desc, _mlp_desc
 
 
+# Heads behind a wide stack take their first-layer operands from the stack's workspace rows, and the stack stops writing the row-major
+# copy (TN_MLP_ROWS_ONLY / TN_MLP_X_FROM_ROWS; f16x2 heads only).  TN_ROWS_HANDOFF=0: row-major as before (A/B runs, tests).
+ROWS_HANDOFF = os.environ.get("TN_ROWS_HANDOFF", "1") != "0"
+
+
+def MATMUL_F16X2() -> bool:
+    from . import models
+    return ROWS_HANDOFF and models.MATMUL == "f16x2"
+
+
 PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_fwd_stash_pair)
 FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
 FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient chain launch (tn_kplanes_mlp_bwd_pair)
@@ -359,9 +369,13 @@ class _RenderHeads(Function):
         feat = feat.contiguous()
         # `link`: row views of the wide stack that produced `feat` (models._FusedMLP.forward, harness only): feat^T as
         # [feature][32-sample] rows in that stack's workspace and the slot where it takes d loss / d feat in the same layout
+        offered = link
         if not (link and train and link.get("n") == feat.size(0) and link.get("y_ptr") == feat.data_ptr() and link.get("width") == feat.size(1)
                 and feat.size(1) in (128, 256)):
             link = None
+        if link is None and offered and offered.get("rows_only"):
+            raise RuntimeError("tinynerf_amd: the feature stack left its output as workspace rows only (TN_MLP_ROWS_ONLY) but this render "
+                               "node cannot read them")
         ctx.link = link
         dev = L.require_cuda(feat, packed, info, *sig_p, *rgb_p)
         n, R = packed.size(0), info.size(0)
@@ -386,6 +400,9 @@ class _RenderHeads(Function):
             rdesc = _mlp_desc(rgb_p, F, L.ENC_DIR_CAT, n_freqs, L.ACT_SIGMOID, freqs)
         ws_s = ws_r = None
         sb = rb = 0
+        # f16x2 heads read their first-layer operands from the stack's row view (128-byte rows instead of 16 bytes per lane and
+        # sample); once a forward has done so the stack stops writing the row-major feat (TN_MLP_ROWS_ONLY / TN_MLP_X_FROM_ROWS)
+        rows_fwd = link is not None and MATMUL_F16X2()
         if train:
             ws_s, sb = _workspace(sdesc, n, dev, arena, "ws_sigma")
             ws_r, rb = _workspace(rdesc, n, dev, arena, "ws_rgb")
@@ -393,6 +410,11 @@ class _RenderHeads(Function):
                 raise RuntimeError("tinynerf_amd: these decoder shapes are outside the fused render node (use renderer.fused = False)")
         sigma = _alloc(arena, "sigma", (n,), dev)
         rgbs = _alloc(arena, "rgbs", (n, 3), dev)
+        if rows_fwd:
+            for d in (rdesc, sdesc):
+                d.x_rows, d.x_rows_tile_stride = link["y_rows"], link["stride"]
+                if link.get("rows_only"):
+                    d.flags |= L.MLP_X_FROM_ROWS
         if train:
             L.call("tn_mlp_fwd_stash", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), C.c_int64(n), L.ptr(sigma), L.ptr(ws_s), C.c_int64(sb))
         else:
@@ -516,6 +538,13 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
         train = torch.is_grad_enabled() and any(p.requires_grad for p in (*planes, *sig_p, *rgb_p))
         return _RenderKPlanes.apply(packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(planes),
                                     len(sig_p), accumulate_into_grad, arena, train, hint, stats, *planes, *sig_p, *rgb_p)
+    # harness: the stack whose row view this node matched last time may leave its output as rows only (TN_MLP_ROWS_ONLY) -- armed for
+    # exactly this forward; _RenderHeads fails loudly if it then cannot read the rows
+    producer = renderer.__dict__.get("_rows_producer")
+    if producer is not None and arena is not None and torch.is_grad_enabled() and MATMUL_F16X2():
+        sc = producer.__dict__.get("scratch")
+        if sc is not None and len(sc) > 4:
+            sc[4]["rows_only"] = True
     feat = fm(packed[:, :3])
     train = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in (*sig_p, *rgb_p)))
     link = None
@@ -525,5 +554,7 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
             sc = mod.__dict__.get("scratch") if isinstance(mod, MLP) else None
             if sc is not None and len(sc) > 2 and sc[2].get("y_ptr") == feat.data_ptr():
                 link = sc[2]
+                if feat.size(1) in (128, 256) and sc[2].get("n") == feat.size(0):
+                    renderer.__dict__["_rows_producer"] = mod
     return _RenderHeads.apply(feat, packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(sig_p),
                               accumulate_into_grad, arena, train, hint, stats, link, *sig_p, *rgb_p)

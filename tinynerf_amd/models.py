@@ -92,6 +92,10 @@ class _FusedMLP(Function):
         n = x2.size(0)
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
         y = _empty_rows(n, ps[-1].numel(), dev)
+        # harness: fused.render_heads arms scratch[4]["rows_only"] for ONE forward when the render node it is about to run reads
+        # this stack's output from the workspace rows (it has matched the row-view link before): the row-major y is then
+        # allocated but never written
+        rows_only = bool(scratch is not None and len(scratch) > 4 and scratch[4].pop("rows_only", False) and MATMUL == "f16x2")
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
         # `recording` = torch.is_grad_enabled() at the call site: inside torch.no_grad() (infer(), the occupancy refresh)
@@ -104,8 +108,10 @@ class _FusedMLP(Function):
             # harness: a capacity-based arena (arena.Arena) instead of the caching allocator -- the training loop runs each
             # forward's backward before the next forward of the module, so one buffer per module is enough
             ws = scratch[0].get(scratch[1], (ws_bytes // 4,), dev) if scratch is not None else torch.empty(ws_bytes // 4, device=dev)
-            L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
             link = scratch[2] if scratch is not None and len(scratch) > 2 else None
+            if rows_only and link is not None:
+                desc.flags |= L.MLP_ROWS_ONLY
+            L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
             if link is not None:
                 # harness: wide stacks evaluated layer by layer keep y as [feature][32-sample] rows in their workspace and take
                 # d loss / d y in that layout (tn_mlp_rows_view): the render node behind this stack (fused._RenderHeads) reads
@@ -114,7 +120,10 @@ class _FusedMLP(Function):
                 y_off, g_off, stride = C.c_int64(0), C.c_int64(0), C.c_int64(0)
                 if L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(n), C.byref(y_off), C.byref(g_off), C.byref(stride)) == 0:
                     link.update(ws=ws, y_rows=ws.data_ptr() + 4 * y_off.value, grad_rows=ws.data_ptr() + 4 * g_off.value,
-                                stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(), delivered=False)
+                                stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(), delivered=False,
+                                rows_only=bool(desc.flags & L.MLP_ROWS_ONLY))
+                elif desc.flags & L.MLP_ROWS_ONLY:
+                    raise RuntimeError("tinynerf_amd: a stack without row views ran with TN_MLP_ROWS_ONLY")
             ctx.link = link
         else:
             # inference (infer(), the occupancy refresh): wide stacks run through the layer kernels with two ping-pong row

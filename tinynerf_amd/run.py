@@ -136,7 +136,7 @@ class Trainer:
         from .models import MLP
         self.scratch = Arena()
         for i, m in enumerate(mod for mod in self.renderer.feature_module.modules() if isinstance(mod, MLP)):
-            m.__dict__["scratch"] = (self.scratch, f"mlp_ws{i}", {}, True)
+            m.__dict__["scratch"] = (self.scratch, f"mlp_ws{i}", {}, True, {})      # arena, name, row-view link, -, persistent state
         if isinstance(self.renderer.feature_module, CobafaFeatureField):
             self.renderer.feature_module.__dict__["accumulate_into_grad"] = True
         self._arena: Dict[str, torch.Tensor] = {}

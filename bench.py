@@ -72,10 +72,15 @@ KERNEL_MODEL = {
 
 # kernel-name prefixes (scripts/pmc_mfma.sh output) behind each timed tag, for the counter-derived matrix-pipe fraction
 MFMA_KERNELS = {
-    "tn_kplanes_mlp_fwd_pair": ["mlp_fwd_kernel<64, true, 12, true, true, true, true>"],
+    "tn_kplanes_mlp_fwd_pair": ["mlp_fwd_kernel<64, true, 12, true, true, true, true", "mlp_fwd_kernel<64, true, 8, true, true, true, true"],
     "tn_kplanes_mlp_bwd_pair:chain": ["mlp_chain_kernel<64, 4, 8, true, false, true, true>"],
     "tn_kplanes_mlp_bwd_pair:wgrad": ["mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1"],
 }
+
+
+def _matmul_mode() -> str:
+    from tinynerf_amd import models
+    return models.MATMUL
 
 
 def load_first(paths):
@@ -599,6 +604,9 @@ def main():
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 storage, accumulation and results; TN_MATMUL=%s: " % _matmul_mode() + "with f16x2 (default) the heads' forward products run "
+                          "on v_mfma_f32_32x32x16_f16 as two-term fp16 splits with power-of-two scales (22 of fp32's 24 significand bits per operand, "
+                          "fp32 accumulate; parity tests at the fp32 tolerances), the backward on v_mfma_f32_32x32x2_f32",
             "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
                        "parallelism": (f"dp{world} ({args.scaling} scaling: " + ("every rank runs the recipe's batch" if args.scaling == "weak" else
                                                                                  f"the recipe's B*S samples per step split over the ranks, {1024 // world} rays per loader batch and rank")

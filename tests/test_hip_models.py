@@ -53,7 +53,7 @@ def test_posenc():
     assert m.PositionalEncoding(4).to(DEV)(torch.zeros(2, 3, 5, 3, device=DEV)).shape == tuple(g["enc4"])
 
 
-def test_vanilla_heads_forward():
+def test_vanilla_heads_forward(heads):
     m = models()
     g = load_golden("G8_vanilla_heads")
     fm = m.VanillaFeatureMLP(6, 64, 3); od = m.VanillaOpacityDecoder(64); cd = m.VanillaColorDecoder(8, 64, 64, 3)
@@ -66,7 +66,7 @@ def test_vanilla_heads_forward():
         np.testing.assert_allclose(cd(cu(g["feat"]), cu(g["dirs"])).cpu().numpy(), g["rgb"], rtol=0, atol=TOL)
 
 
-def test_decoders_96_forward():
+def test_decoders_96_forward(heads):
     m = models()
     g = load_golden("G8b_decoders_96")
     od = m.VanillaOpacityDecoder(96); cd = m.VanillaColorDecoder(8, 96, 64, 3)
@@ -244,7 +244,7 @@ def _port_leaves(sd):
     return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v) for k, v in sd.items()}
 
 
-def test_vanilla_heads_backward():
+def test_vanilla_heads_backward(heads):
     """gradients of sigma / rgb w.r.t. every parameter of the feature MLP and the decoders (G8; the golden pins the CPU port,
     tests/test_oracle_golden.py).  2e-5 of each tensor's largest element (sums over 256 samples through <= 9 layers in MFMA
     K-order vs ATen's), up to the state of fp32-tie ReLU units (tests/_ties.py)."""
@@ -285,7 +285,7 @@ def test_vanilla_heads_backward():
     assert_grads_match_up_to_relu_ties(got, ref("rgb"), 2e-5)
 
 
-def test_decoders_96_backward():
+def test_decoders_96_backward(heads):
     """K-Planes-shaped heads: grads w.r.t. parameters AND the incoming features (G8b), 2e-5 of each tensor's largest element."""
     from _ties import assert_grads_match_up_to_relu_ties
     from oracle import torch_port as tp
@@ -485,7 +485,7 @@ def test_fused_adam_matches_torch_adam():
 
 
 @pytest.mark.parametrize("head", ["sigma", "rgb"])
-def test_mlp_stashed_forward_and_ray_table_match_recompute_path(head):
+def test_mlp_stashed_forward_and_ray_table_match_recompute_path(head, heads):
     """Training forward with activation stash (tn_mlp_fwd_stash + TN_MLP_STASHED) and the per-ray aux table
     (TN_ENC_AUX_CAT + tn_dir_encode) against the recompute path with per-sample directions (TN_ENC_DIR_CAT):
     same outputs, same parameter gradients, same grad_x (incl. TN_MLP_ACCUM_GRAD_X)."""
@@ -553,7 +553,7 @@ def test_mlp_stashed_forward_and_ray_table_match_recompute_path(head):
         np.testing.assert_allclose((gx1 - (1.0 if accum else 0.0)).cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=2e-6)
 
 
-def test_mlp_bwd_pair_matches_two_single_head_backwards():
+def test_mlp_bwd_pair_matches_two_single_head_backwards(heads):
     """tn_mlp_bwd_pair (colour head + 2-layer sigma head sharing x, one data-gradient pass, grad_x written once)
     against tn_mlp_bwd of the colour head followed by tn_mlp_bwd of the sigma head with TN_MLP_ACCUM_GRAD_X."""
     import ctypes as C
@@ -827,3 +827,42 @@ def test_linear_rejects_wide_layers_and_cpu_tensors():
         m.linear(torch.zeros(4, 300, device=DEV), torch.zeros(8, 300, device=DEV))
     with pytest.raises(RuntimeError):
         m.linear(torch.zeros(4, 8), torch.zeros(8, 8))
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("in_dim", [96, 256])
+def test_f16x2_heads_keep_fp32_accuracy_across_magnitudes(training, in_dim):
+    """Round 4: the width-64 heads' forward as two-term fp16 splits (mlp_f2_heads.h).  fp16 has 5 exponent bits, so every operand
+    is scaled by a power of two per SAMPLE and layer: rows of one 32-sample tile that differ by 18 orders of magnitude (and rows
+    that are exactly zero) must each come out as accurately as the fp32 evaluation of the same row -- per sample, the error against
+    an fp64 evaluation may not exceed 4 x torch's fp32 error (plus 2e-6 of the row's own scale)."""
+    m = models()
+    if m.MATMUL != "f16x2":
+        pytest.skip("f16x2 is the default; this run selected another matrix mode")
+    torch.manual_seed(7 + in_dim)
+    net = m.MLP(in_dim, 64, 3, 3).to(DEV)                 # (the colour decoder's shape: five Linear layers)
+    n = 1000
+    mag = 10.0 ** (torch.rand(n, 1) * 18.0 - 12.0)
+    mag[::7] = 0.0
+    mag[1::31] = 1e25                                     # (x 64 inputs x weights: still far below fp32's range)
+    x = (torch.randn(n, in_dim) * mag).to(DEV)
+    ps = [p.detach().cpu().double() for p in net.params()]
+
+    def chain(v, dtype):
+        h = v.to(dtype)
+        for l in range(0, len(ps) - 2, 2):
+            h = torch.relu(h @ ps[l].to(dtype).T + ps[l + 1].to(dtype))
+        return h @ ps[-2].to(dtype).T + ps[-1].to(dtype), h
+    ref, h_last = chain(x.cpu(), torch.float64)
+    f32, _ = chain(x.cpu(), torch.float32)
+    if training:
+        y = net.fused(x.clone().requires_grad_(True))     # tn_mlp_fwd_stash
+    else:
+        with torch.no_grad():
+            y = net.fused(x)                              # tn_mlp_fwd
+    err = (y.detach().cpu().double() - ref).abs().amax(1)
+    err32 = (f32.double() - ref).abs().amax(1)
+    scale = (h_last.abs() @ ps[-2].abs().T + ps[-1].abs()).amax(1)          # what one rounding of the last layer is relative to
+    assert torch.isfinite(y).all()
+    bad = err > 4.0 * err32 + 2e-6 * scale
+    assert not bad.any(), (int(bad.sum()), float((err / scale.clamp_min(1e-300)).max()))

@@ -175,15 +175,25 @@ def test_inference_pair_form_is_bit_identical_to_the_gated_form(n_rays, per_ray,
     with torch.no_grad():
         for form in (False, True):
             monkeypatch.setattr(fused, "INFER_PAIR", form)
-            r.__dict__.pop("_stats", None)                       # a fresh renderer state: the field counts as alive
+            r.__dict__.pop("_stats", None)                       # a fresh renderer state: no measurement has landed -> the gated form
             del calls[:]
-            outs[form] = r(packed, info).clone()
-            assert ("tn_kplanes_mlp_fwd_pair" in calls) == form and ("tn_kplanes_mlp_fwd" in calls) == (not form), calls
+            first = r(packed, info).clone()
+            assert "tn_kplanes_mlp_fwd" in calls and "tn_kplanes_mlp_fwd_pair" not in calls, calls
+            if form:
+                torch.cuda.synchronize()                         # the first call's live fraction has landed
+                monkeypatch.setattr(fused, "INFER_PAIR_MIN_LIVE", 0.0)       # (whatever it is: the pair form now)
+                del calls[:]
+                outs[form] = r(packed, info).clone()
+                assert "tn_kplanes_mlp_fwd_pair" in calls and "tn_kplanes_mlp_fwd" not in calls, calls
+                monkeypatch.setattr(fused, "INFER_PAIR_MIN_LIVE", 0.6)
+                assert torch.equal(first, outs[form])
+            else:
+                outs[form] = first
         assert torch.equal(outs[True], outs[False])
-        # the switch: after a call on a dead field (live fraction below the bar) the next call takes the gated form, and back
+        # the switch: the next call follows the live fraction of the most recent call whose measurement has landed
         torch.cuda.synchronize()
-        st = r._stats["infer_live"]
-        live = float(st["pinned"][0])
+        fused._infer_prefers_pair(r._stats)
+        live = r._stats["infer_live"]["value"]
         with torch.no_grad():
             w_live = float((core.NerfWeights.apply(r.sigma_decoder(r.feature_module(packed[:, :3])).ravel(), packed[:, 6].contiguous(), info, 1e-4) > 0)
                            .float().mean()) if n else 1.0

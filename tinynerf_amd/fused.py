@@ -110,25 +110,36 @@ INFER_PAIR_MIN_LIVE = 0.6
 
 
 def _infer_prefers_pair(stats: Optional[dict]) -> bool:
-    """live-sample fraction (w > 0) of the previous inference call on this renderer, read without a host sync: the value travels
-    to pinned memory behind an event; until the first one has landed the field counts as alive"""
+    """live-sample fraction (w > 0) of the most recent inference call on this renderer whose measurement has LANDED, read without
+    a host sync: the values travel to a small ring of pinned slots, each behind its own event.  Until one has landed the gated
+    form runs: on a trained scene (most samples behind a terminated ray) it is 4 x faster than the pair form (48 against 188 ms
+    per 800 x 800 image), on a field that is alive everywhere only 1.4 x slower -- the cheap mistake is the default."""
     st = None if stats is None else stats.get("infer_live")
     if st is None:
-        return True
-    if st["event"].query():
-        st["value"] = float(st["pinned"][0])
-    return st["value"] >= INFER_PAIR_MIN_LIVE
+        return False
+    for slot in st["slots"]:
+        if slot["seq"] > st["seen"] and slot["event"].query():
+            st["seen"], st["value"] = slot["seq"], float(slot["pinned"][0])
+    return st["value"] is not None and st["value"] >= INFER_PAIR_MIN_LIVE
 
 
 def _note_live_fraction(stats: dict, weights: torch.Tensor) -> None:
     st = stats.get("infer_live")
     if st is None:
-        st = stats["infer_live"] = {"pinned": torch.ones(1, pin_memory=True), "event": torch.cuda.Event(), "value": 1.0}
-    elif not st["event"].query():
-        return                                   # the previous measurement is still in flight: keep it
-    if weights.numel():
-        st["pinned"].copy_((weights > 0).float().mean().reshape(1), non_blocking=True)
-        st["event"].record(torch.cuda.current_stream(weights.device))
+        st = stats["infer_live"] = {"slots": [{"pinned": torch.ones(1, pin_memory=True), "event": torch.cuda.Event(), "seq": 0} for _ in range(4)],
+                                    "seq": 0, "seen": 0, "value": None}
+    if not weights.numel():
+        return
+    for slot in st["slots"]:                      # a slot whose previous measurement has landed (or that was never used)
+        if slot["seq"] == 0 or (slot["seq"] <= st["seen"]) or slot["event"].query():
+            if slot["seq"] > st["seen"]:          # landed but not read yet: read it before it is overwritten
+                st["seen"], st["value"] = slot["seq"], float(slot["pinned"][0])
+            st["seq"] += 1
+            slot["seq"] = st["seq"]
+            slot["pinned"].copy_((weights > 0).float().mean().reshape(1), non_blocking=True)
+            slot["event"].record(torch.cuda.current_stream(weights.device))
+            return
+    # every slot still in flight: skip this measurement
 
 
 class _RenderKPlanes(Function):

@@ -41,7 +41,7 @@ def _batch(n_rays, per_ray, seed):
 
 
 @pytest.mark.parametrize("method,n_rays,per_ray", [("vanilla", 61, 40), ("vanilla", 700, 57), ("cobafa", 300, 33)])
-def test_row_views_equal_row_major_tensors(method, n_rays, per_ray):
+def test_row_views_equal_row_major_tensors(method, n_rays, per_ray, heads):
     from tinynerf_amd import models as m
     from tinynerf_amd.arena import Arena
     packed, info, target = _batch(n_rays, per_ray, 5)
@@ -65,9 +65,13 @@ def test_row_views_equal_row_major_tensors(method, n_rays, per_ray):
         grads[rows]["__out"] = out.detach().cpu().numpy()
     # the same forward launches up to the colour head's direction encoding (per-ray table vs per-sample sin / cos)
     np.testing.assert_allclose(grads[True]["__out"], grads[False]["__out"], rtol=0, atol=2e-6)
+    # fp32 heads: the same products, summed in another order (row tiles / atomics): 2e-5 of the largest element per tensor.
+    # f16x2 (default): the row-view path runs the colour head on the fp16 matrix cores (per-ray table, TN_ENC_AUX_CAT) while the
+    # row-major path keeps it on the fp32 MFMA (per-sample sin / cos, TN_ENC_DIR_CAT: no f16x2 form) -- two roundings of the same
+    # hidden activations, and a unit within an ulp of 0 may fall on either side: 2e-4
+    tol = 2e-5 if heads == "fp32" else 2e-4
     for k, ref in grads[False].items():
-        # same products, summed in another order (row tiles / atomics): 2e-5 of the largest element per tensor
-        np.testing.assert_allclose(grads[True][k], ref, rtol=0, atol=2e-5 * max(float(np.abs(ref).max()), 1e-30), err_msg=k)
+        np.testing.assert_allclose(grads[True][k], ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-30), err_msg=k)
 
 
 def test_rows_view_reports_only_layer_kernel_stacks():

@@ -1093,7 +1093,8 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 FwdLayerArgs f;
                 f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = plain ? 64 : a.K0_pad; f.rows_total = total;
                 f.off_in = offE; f.off_out = 0; f.out_act = a.out_act; f.off_bits = off_bits(0);
-                if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
+                if (a.f2) { if (int rc = launch_fwd_first_f2(H, f, n, stash, s)) return rc; }
+                else if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
                 if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: the layer-by-layer inference forward needs positional-encoding inputs");
                 fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(

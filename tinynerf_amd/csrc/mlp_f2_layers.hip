@@ -658,6 +658,114 @@ int launch_wgrad(const WgradArgs &w, int64_t n, const float *stash, hipStream_t 
     return tn::check_launch("wgrad_f2_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// First layer of a wide stack (<= 64 encoded or plain inputs as workspace rows, enc_rows_kernel) in the f16x2 arithmetic: the
+// fwd_lds_kernel of mlp_bwd_layers.hip with 12 fp16 MFMAs per 32 x 32 output block instead of 32 fp32 ones (0.52 ms per Vanilla
+// step at 0.50 matrix-pipe busy: the last matrix-bound launch of the stack's forward).  A workgroup stages all H weight rows once
+// as hi / lo planes (row stride 72 halfs: conflict-free b128 operand reads), scaled by the layer's largest |weight|; a wave takes
+// a tile's 64 input rows in the D layout -- registers 8 (b & 1) .. + 7 of block b >> 1 ARE the B operand of k block b (the
+// heads' layout, mlp_f2_heads.h) --, converts them once with the sample's scale, and walks the H / 32 output blocks.
+// ------------------------------------------------------------------------------------------------
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void fwd_first_f2_kernel(FwdLayerArgs a, int64_t n, float *__restrict__ stash)
+{
+    constexpr int NOT = H / 32, ST = 72, PLANE = H * ST;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    _Float16 *wh = reinterpret_cast<_Float16 *>(lds_raw), *wl = wh + PLANE;
+    float *bias_s = reinterpret_cast<float *>(lds_raw + 2 * PLANE * 2);
+    float *red = bias_s + H;
+    const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float m = 0.0f;
+    for (int e = threadIdx.x; e < a.N * a.K; e += blockDim.x) m = fmaxf(m, fabsf(a.W[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    for (int e = threadIdx.x; e < H; e += blockDim.x) bias_s[e] = e < a.N ? a.B[e] : 0.0f;
+    __syncthreads();
+    float g = 0.0f;
+    for (int w = 0; w < WPB; ++w) g = fmaxf(g, red[w]);
+    float s_w, inv_w;
+    pow2_scales(g, s_w, inv_w);
+    for (int e = threadIdx.x; e < H * 64; e += blockDim.x) {
+        const int o = e >> 6, q = e & 63;
+        const float v = (o < a.N && q < a.K) ? a.W[(int64_t)o * a.K + q] * s_w : 0.0f;
+        const _Float16 vh = (_Float16)v;
+        const int w = q & 15, pos = o * ST + (q & ~15) + ((w >> 2) & 1) * 8 + (w & 3) + ((w >> 3) << 2);      // [k block][half h][8]
+        wh[pos] = vh;
+        wl[pos] = (_Float16)(v - (float)vh);
+    }
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        int j = j_, h = h_;
+        asm volatile("" : "+v"(j), "+v"(h));
+        float *st = stash + tile * (int64_t)a.rows_total * 32;
+        const float *in = st + a.off_in * 32;
+        float x[2][16];
+        float mx = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * t + frow(r, h);
+                const float v = in[(k < a.Kp ? k : 0) * 32 + j];
+                x[t][r] = k < a.Kp ? v : 0.0f;                            // rows past Kp belong to another buffer
+                mx = fmaxf(mx, fabsf(x[t][r]));
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float s_x, inv_x;
+        pow2_scales(mx, s_x, inv_x);
+        Op2 B[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned hi, lo;
+                split2h(x[b >> 1][8 * (b & 1) + 2 * p] * s_x, x[b >> 1][8 * (b & 1) + 2 * p + 1] * s_x, hi, lo);
+                B[b].hi[p] = hi; B[b].lo[p] = lo;
+            }
+        const float c = inv_w * inv_x;
+#pragma clang loop unroll(disable)
+        for (int ot = 0; ot < NOT; ++ot) {
+            if (32 * ot >= a.N) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const _Float16 *wr = wh + (32 * ot + j) * ST + 8 * h;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const u32x4 ah = *reinterpret_cast<const u32x4 *>(wr + 16 * b), al = *reinterpret_cast<const u32x4 *>(wr + 16 * b + PLANE);
+                acc = mfma_h(al, B[b].hi, acc);
+                acc = mfma_h(ah, B[b].lo, acc);
+                acc = mfma_h(ah, B[b].hi, acc);
+            }
+            tn::pin16(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], c, bias_s[32 * ot + frow(r, h)]);
+            acc = tn::relu16(acc);
+            wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ot, j, h, acc);
+            if (a.off_bits >= 0) reinterpret_cast<unsigned *>(st + (a.off_bits + 2 * ot) * 32)[lane] = relu_bits(acc);
+        }
+    }
+}
+
+template <int H>
+int launch_first(const FwdLayerArgs &f, int64_t n, float *stash, hipStream_t s)
+{
+    constexpr int WPB = 8;
+    constexpr size_t lds_bytes = (size_t)2 * H * 72 * 2 + H * 4 + 64;
+    auto kern = fwd_first_f2_kernel<H, WPB>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_fwd(f16x2, first layer): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int per_cu = (int)std::min<size_t>(4, (size_t)LDS_LIMIT_BYTES / lds_bytes);
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * per_cu));
+    kern<<<dim3((unsigned)bl), dim3(WPB * 64), lds_bytes, s>>>(f, n, stash);
+    return tn::check_launch("fwd_first_f2_kernel");
+}
+
 template <int H, bool LAST>
 int launch_fwd(const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s)
 {
@@ -694,6 +802,15 @@ __attribute__((visibility("hidden"))) int launch_fwd_f2(int H, bool last, const 
 {
     if (H == 256) return last ? launch_fwd<256, true>(f, n, stash, y, s) : launch_fwd<256, false>(f, n, stash, y, s);
     if (H == 128) return last ? launch_fwd<128, true>(f, n, stash, y, s) : launch_fwd<128, false>(f, n, stash, y, s);
+    return tn::fail(TN_E_CONFIG, "mlp_fwd(f16x2): width 128 or 256");
+}
+
+// first layer (K <= 64 input rows, hidden output: ReLU, rows + bit rows)
+__attribute__((visibility("hidden"))) int launch_fwd_first_f2(int H, const FwdLayerArgs &f, int64_t n, float *stash, hipStream_t s)
+{
+    if (f.Kp > 64 || f.K > 64 || f.N > H) return tn::fail(TN_E_CONFIG, "mlp_fwd(f16x2, first layer): at most 64 input rows");
+    if (H == 256) return launch_first<256>(f, n, stash, s);
+    if (H == 128) return launch_first<128>(f, n, stash, s);
     return tn::fail(TN_E_CONFIG, "mlp_fwd(f16x2): width 128 or 256");
 }
 

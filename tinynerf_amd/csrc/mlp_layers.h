@@ -90,6 +90,7 @@ int launch_dgrad_b3(int H, const DgradArgs &d, int64_t n, float *stash, hipStrea
 int launch_wgrad_b3(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
 // ---- f16x2 forms of the forward / data gradient (mlp_f2_layers.hip): two-term fp16 splits with power-of-two scales ----
 int launch_fwd_f2(int H, bool last, const FwdLayerArgs &f, int64_t n, float *stash, float *y, hipStream_t s);
+int launch_fwd_first_f2(int H, const FwdLayerArgs &f, int64_t n, float *stash, hipStream_t s);
 int launch_dgrad_f2(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s);
 int launch_wgrad_f2(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
 

@@ -294,8 +294,8 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
         out["tflops_fp32_equivalent"] = tf
         out["matmul"] = mode
         if mode == "f16x2":
-            # hidden layers as two-term fp16 splits with power-of-two scales (TN_MLP_F16X2): THREE fp16 MFMAs per fp32 product block;
-            # the width-64 heads stay on the fp32 MFMA
+            # every layer of the stack and the heads' forward as two-term fp16 splits with power-of-two scales (TN_MLP_F16X2): THREE fp16
+            # MFMAs per fp32 product block; the heads' backward and the first-layer weight gradients stay on the fp32 MFMA
             out["mfma_frac"] = tf / PEAK_F16X2_TFLOPS
             out["mfma_peak"] = {"tflops": PEAK_F16X2_TFLOPS, "what": "dense fp16 MFMA peak / 3 products per fp32 product (f16x2)"}
             out["vs_fp32_mfma_peak"] = tf / PEAK_FP32_MFMA_TFLOPS

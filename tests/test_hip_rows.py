@@ -228,3 +228,76 @@ def test_plain_input_stack_through_the_layer_kernels(n, matmul):
     d0.flags = 0                                                   # (fp32 MFMA, register-resident: independent of the layer kernels)
     L.call("tn_mlp_fwd", x.device, C.byref(d0), L.ptr(x), C.c_void_p(None), C.c_int64(n), L.ptr(y_reg), C.c_void_p(None))
     np.testing.assert_allclose(y_inf.cpu().numpy(), y_reg.cpu().numpy(), rtol=0, atol=3e-6 * float(y_reg.abs().max()))
+
+
+@pytest.mark.parametrize("head,in_dim,n", [("sigma", 256, 777), ("rgb", 256, 2000), ("rgb", 128, 33), ("sigma", 128, 4096)])
+def test_head_forward_reads_x_from_row_views(head, in_dim, n):
+    """Round 4 ABI: tn_mlp_fwd_stash of a width-64 f16x2 head takes its first-layer operands from tn_mlp_desc::x_rows
+    ([feature][32-sample] rows per tile, zeros behind sample n) -- with TN_MLP_X_FROM_ROWS `x` is not dereferenced at all.
+    Same values through the same arithmetic: outputs AND the stashed workspace are bit-identical to the row-major call.  The flag
+    on a launch that cannot read rows (fp32 heads) is refused with TN_E_CONFIG instead of reading the unwritten x."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    if m.MATMUL != "f16x2":
+        pytest.skip("the row view is read by the f16x2 heads")
+    torch.manual_seed(n)
+    out = 1 if head == "sigma" else 3
+    net = m.MLP(in_dim, 64, 0 if head == "sigma" else 3, out).to(DEV)
+    x = torch.randn(n, in_dim, device=DEV) * 3.0
+    tiles = (n + 31) // 32
+    rows = torch.zeros(tiles, in_dim, 32, device=DEV)
+    xp = torch.zeros(tiles * 32, in_dim, device=DEV)
+    xp[:n] = x
+    rows.copy_(xp.view(tiles, 32, in_dim).transpose(1, 2))
+    table = idx = None
+    if head == "rgb":                                   # the colour head's per-ray table columns (TN_ENC_AUX_CAT), 56 wide
+        table = torch.randn(7, 56, device=DEV)
+        table[:, 51:] = 0.0
+        idx = torch.randint(0, 7, (n,), dtype=torch.int32, device=DEV)
+        net.net[0] = torch.nn.Linear(in_dim + 51, 64).to(DEV)
+    ps = net.params()
+
+    def desc(flags):
+        if head == "rgb":
+            d = m._mlp_desc(ps, in_dim, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, None, flags, idx, 56)
+        else:
+            d = m._mlp_desc(ps, in_dim, L.ENC_NONE, 0, L.ACT_EXP_M1, None, flags)
+        return d
+    wsfn = L.lib().tn_mlp_bwd_workspace_bytes
+    wsfn.restype = C.c_int64
+    nbytes = int(wsfn(C.byref(desc(0)), C.c_int64(n)))
+    assert nbytes > 0
+    res = {}
+    for mode in ("row-major", "rows", "rows-only"):
+        d = desc(0)
+        xin = x
+        if mode != "row-major":
+            d.x_rows, d.x_rows_tile_stride = rows.data_ptr(), in_dim * 32
+        if mode == "rows-only":
+            d.flags |= L.MLP_X_FROM_ROWS
+            xin = torch.full_like(x, float("nan"))     # must not be read
+        y = torch.empty(n, out, device=DEV)
+        ws = torch.zeros(nbytes // 4, device=DEV)
+        L.call("tn_mlp_fwd_stash", x.device, C.byref(d), L.ptr(xin), L.ptr(table), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nbytes))
+        res[mode] = (y, ws)
+    per_tile = nbytes // 4 // tiles                      # floats per tile: rows x 32 samples
+    nh_rows = 64 * (1 if head == "sigma" else 4)        # the stashed hidden activations lead the tile
+    n_last = n - 32 * (tiles - 1)
+
+    def stashed(ws):
+        t = ws[:tiles * per_tile].view(tiles, per_tile // 32, 32)
+        # (the last tile's columns behind sample n belong to nobody: the row-major call evaluates row 0 there, the row view holds zeros)
+        return t[:tiles - 1], t[tiles - 1, :nh_rows, :n_last]
+    for mode in ("rows", "rows-only"):
+        assert torch.equal(res[mode][0], res["row-major"][0]), mode
+        for got, want in zip(stashed(res[mode][1]), stashed(res["row-major"][1])):
+            assert torch.equal(got, want), mode
+    assert torch.isfinite(res["rows-only"][0]).all()
+    # a launch that cannot read the rows says so
+    d = desc(0)
+    d.flags = (d.flags & ~(L.MLP_F16X2 | L.MLP_BF16X3)) | L.MLP_X_FROM_ROWS
+    d.x_rows, d.x_rows_tile_stride = rows.data_ptr(), in_dim * 32
+    y = torch.empty(n, out, device=DEV)
+    ws = torch.zeros(nbytes // 4, device=DEV)
+    with pytest.raises(RuntimeError, match="TN_MLP_X_FROM_ROWS"):
+        L.call("tn_mlp_fwd_stash", x.device, C.byref(d), L.ptr(x), L.ptr(table), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nbytes))

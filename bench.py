@@ -475,10 +475,6 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):      # (chunks of pure background print the reference's "Empty iteration" line:
             tr.render_rays(ho, hd)                        # core.py:253 -- stdout carries the JSON line only); warm-up: scratch arenas
             torch.cuda.synchronize()
-            if os.environ.get("TN_BENCH_DEBUG_RENDER"):
-                for k in range(4):
-                    t0 = time.perf_counter(); tr.render_rays(ho, hd); torch.cuda.synchronize()
-                    sys.stderr.write("render %d: %.1f ms, live %s\n" % (k, (time.perf_counter() - t0) * 1e3, tr.renderer._stats.get("infer_live", {}).get("value")))
             t0 = time.perf_counter()
             img = tr.render_rays(ho, hd)
             torch.cuda.synchronize()

@@ -1,3 +1,10 @@
+"""Where a wave spends a 32-sample tile of the width-64 heads' forward (mlp_fwd_kernel<..., F2>): s_memtime ticks per phase, summed over
+all waves by a library built with -DTN_PHASE_TIMERS (mlp.hip; not the shipped build) and read back through tn_debug_phase_cycles.
+
+    hipcc ... -DTN_PHASE_TIMERS -c tinynerf_amd/csrc/mlp.hip -o mlp_pt.o && hipcc -shared ... -o lib_pt.so <other objects> mlp_pt.o
+    TN_LIB_PATH=$PWD/lib_pt.so python scripts/phase_time.py [kp]        (kp: one K-Planes training step as well)
+
+DESIGN 4.2 (round 4) quotes its output: gather 45 %, table rows + first-layer epilogue + stores 26 %, hidden layers 10 % of a tile."""
 import sys, os, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tinynerf_amd import models as m, _lib

@@ -15,6 +15,9 @@
 #pragma once
 #include "kplanes_device.h"
 
+#ifdef TN_PHASE_TIMERS
+extern __device__ unsigned long long tn_phase_cycles_b[16];
+#endif
 namespace tn {
 
 constexpr int KP_GS = 36;                                      // floats per tile row: conflict-free b128 writes
@@ -28,6 +31,10 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
                                                  const float (&xs)[3], bool valid, const f32x4k (&g)[NV], int c0,
                                                  float *__restrict__ wave_lds, int j, int h)
 {
+#ifdef TN_PHASE_TIMERS
+    unsigned long long pts_ = __builtin_amdgcn_s_memtime();
+#define TN_PTS(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (tn::lane_id() == 0) atomicAdd(&tn_phase_cycles_b[k], n_ - pts_); pts_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     float *tileG = wave_lds;
     int *tileO = reinterpret_cast<int *>(tileG + 32 * KP_GS);
     float *tileW = tileG + 32 * KP_GS + 4 * 32;
@@ -46,6 +53,9 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
             for (int q = 0; q < NV; ++q) val[p][q] = f32x4k{1.f, 1.f, 1.f, 1.f};
         }
     }
+#ifdef TN_PHASE_TIMERS
+    TN_PTS(8)
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         if (grads[p] == nullptr) continue;
@@ -82,6 +92,9 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
         const unsigned mv_pm = (unsigned)__ballot(dcell == -rowlen + 1), mv_mm = (unsigned)__ballot(dcell == -rowlen - 1);
         const unsigned mv_diag = mv_pp | mv_mp | mv_pm | mv_mm;
         asm volatile("" ::: "memory");         // DS ops of one wave execute in order; only the compiler must not reorder
+#ifdef TN_PHASE_TIMERS
+        TN_PTS(9)
+#endif
         // ---- phase B: lane = (tap pair h, channel c) ----
         const int c = j;                       // channel
         char *const gplane = reinterpret_cast<char *>(grads[p]);     // wave-uniform base + 32-bit byte offsets: no 64-bit VALU
@@ -159,6 +172,9 @@ __device__ __forceinline__ void kp_scatter_scale(const float *const (&planes)[3]
             }
         }
         asm volatile("" ::: "memory");
+#ifdef TN_PHASE_TIMERS
+        TN_PTS(10)
+#endif
     }
 }
 

@@ -28,6 +28,19 @@ extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const 
 extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows, int64_t a_stride, int na, float *gW,
                                  int ldw, int col0, int kmax, float *gB, int64_t n, void *stream);
 
+#ifdef TN_PHASE_TIMERS
+__device__ unsigned long long tn_phase_cycles_b[16];
+#define TN_PTB_BEGIN unsigned long long ptb_ = __builtin_amdgcn_s_memtime();
+#define TN_PTB(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (tn::lane_id() == 0) atomicAdd(&tn_phase_cycles_b[k], n_ - ptb_); ptb_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int tn_debug_phase_cycles_b(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(tn_phase_cycles_b), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(tn_phase_cycles_b), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define TN_PTB_BEGIN
+#define TN_PTB(k)
+#endif
 namespace {
 
 using tn::f32x16;
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
         asm volatile("" : "+v"(j), "+v"(h));           // keep per-lane LDS addresses out of LICM's reach
+        TN_PTB_BEGIN
         const int64_t row = tile * 32 + j;
         const bool valid = row < n;
         const int extra = extra_rows(a.enc, a.in_dim, a.K0_pad);
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             if (h == 0) stP[o * 32 + j] = gp[o];
         }
         }
+        TN_PTB(0)
         f32x16 G[T];
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) {
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
         for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
 
+        TN_PTB(1)
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
         if ((KP || gx != nullptr || (!KP && a.gx_rows != nullptr)) && a.enc != TN_ENC_POSENC) {
             f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
@@ -466,6 +482,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     }
                 }
             }
+            TN_PTB(2)
             if constexpr (KP) {
                 // ---------------- plane gradients: scatter of this tile's three 32-channel blocks ----------------
                 const float *cr = kp.coords + (valid ? row : 0) * kp.coord_stride;
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     const float *const pl[3] = {kp.planes[sc][0], kp.planes[sc][1], kp.planes[sc][2]};
                     float *const gr[3] = {kp.grads[sc][0], kp.grads[sc][1], kp.grads[sc][2]};
                     tn::kp_scatter_scale<4, 8>(pl, gr, kp.H[sc], kp.W[sc], 32, xs, valid, g4, 4 * h, wave_lds, j, h);
+                    TN_PTB(3 + sc)
                 }
             }
         }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Convergence evidence on the synthetic scene (GPU box): held-out PSNR against the step count for the three model
-configurations through the real Trainer (dynamic batches, occupancy refreshes, shuffled epochs), Vanilla in both matrix modes
-(bf16x3 = exact three-way splits on the bf16 matrix cores, fp32 = v_mfma_f32_32x32x2_f32) -- same seeds, same ray stream.
+configurations through the real Trainer (dynamic batches, occupancy refreshes, shuffled epochs), K-Planes with both head forms and Vanilla in all
+three matrix modes (f16x2 = two-term fp16 splits, the default since round 4; bf16x3 = exact three-way splits on the bf16 matrix cores;
+fp32 = v_mfma_f32_32x32x2_f32) -- same seeds, same ray stream.
 usage: scripts/convergence.py <out.json> [steps_kplanes steps_vanilla steps_cobafa]"""
 import json
 import os
@@ -27,8 +28,9 @@ LR = {"vanilla": 1e-3, "cobafa": 1e-3}        # the reference's lr 1e-2 (run.py:
                                               # tests/test_hip_training.py); the curves of these two use a smaller step
 res = {"scene": f"rays.synthetic_scene(n_views={V}, res={RES}, seed=0): {V - 1} training views, 1 held-out view",
        "lr_override": LR, "runs": {}}
-for name, method, n_steps, mode in (("kplanes", "kplanes", steps[0], "bf16x3"), ("vanilla_bf16x3", "vanilla", steps[1], "bf16x3"),
-                                    ("vanilla_fp32_mfma", "vanilla", steps[1], "fp32"), ("cobafa", "cobafa", steps[2], "bf16x3")):
+for name, method, n_steps, mode in (("kplanes", "kplanes", steps[0], "f16x2"), ("kplanes_fp32_heads", "kplanes", steps[0], "fp32"),
+                                    ("vanilla", "vanilla", steps[1], "f16x2"), ("vanilla_bf16x3", "vanilla", steps[1], "bf16x3"),
+                                    ("vanilla_fp32_mfma", "vanilla", steps[1], "fp32"), ("cobafa", "cobafa", steps[2], "f16x2")):
     models.MATMUL = mode
     torch.manual_seed(0)
     cfg = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=256, seed=0)

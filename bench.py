@@ -37,7 +37,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the exact 3-way split: six bf16 products per fp32 product
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0    # ... of the two-term fp16 split: three fp16 products (v_mfma_f32_32x32x16_f16 runs at the bf16 rate)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
-PEAK_ATOMIC_GLANES = 270.0         # scripts/microbench/atomic_patterns.hip: full-line global_atomic_add_f32, G lane-atomics/s
+PEAK_ATOMIC_GLANES = 325.0         # scripts/microbench/atomic_scaling.hip: full-line global_atomic_add_f32 from >= 4096 waves on random lines, G lane-atomics/s
+                                   # (atomic_patterns.hip: 272 on random lines with its heavier index stream, 160 on runs of neighbouring lines)
 # counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
 PMC_PROFILES = ["profiles/round4_pmc_traffic.json", "profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
 MFMA_PROFILES = ["profiles/round4_mfma_busy.json", "profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
@@ -591,8 +592,10 @@ def main():
                          co_bound={"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
                                    "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
                                    "note": "memory-side fp32 atomics of the plane scatter (full-line requests); peak = MEASURED IN THIS REPO "
-                                           "(scripts/microbench/atomic_patterns.hip; = 128 L2 channels x one dword addition per clock at "
-                                           "~2.1 GHz), not a figure of MI355X_MICROARCH.md; this is the limit the launch runs at"})
+                                           "(scripts/microbench/atomic_scaling.hip: 325 G/s on random lines from >= 4096 waves; "
+                                           "atomic_patterns.hip: 160 G/s on runs of neighbouring lines, which is what consecutive flushes of a "
+                                           "ray are), not a figure of MI355X_MICROARCH.md; with its gathers removed the launch takes the same "
+                                           "time (DESIGN 4.2): this path is the limit it runs at"})
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
             try:

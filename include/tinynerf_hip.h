@@ -40,6 +40,10 @@ enum {
 };
 
 const char *tn_last_error_string(void);
+/* Most recent performance warning of the process ("" if none): a VALID call that landed on a general-shape fallback kernel -- a wide
+ * stack whose first layer / layer shapes are not those of the reference's configurations (src/run.py:131-150) runs several times
+ * slower than they do.  Said once per fallback on stderr as well (TN_QUIET=1 silences that).  Never an error: the results are right. */
+const char *tn_last_warning_string(void);
 int tn_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------

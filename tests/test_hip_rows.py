@@ -3,6 +3,8 @@ tn_mlp_rows_view, TN_MLP_GRAD_Y_ROWS) -- the harness plumbing for reference mode
 width 256) and run.py:141-150 (Cobafa, width 128): y^T stays in the stack's workspace as [feature][32-sample] rows, the heads'
 first-layer weight gradients read it there (mlp_wgrad_rows.hip) and their data-gradient chains write d loss / d y back in the
 same layout.  Oracle: the same kernels through the row-major tensors (the module-API path that the goldens G8 / G11 / G14 pin)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -301,3 +303,35 @@ def test_head_forward_reads_x_from_row_views(head, in_dim, n):
     ws = torch.zeros(nbytes // 4, device=DEV)
     with pytest.raises(RuntimeError, match="TN_MLP_X_FROM_ROWS"):
         L.call("tn_mlp_fwd_stash", x.device, C.byref(d), L.ptr(x), L.ptr(table), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nbytes))
+
+
+def test_slow_general_shape_fallbacks_say_so_once():
+    """Round-3 verdict: a caller who lands on one of the general-shape fallback kernels of the wide stacks gets valid results several
+    times slower -- with no diagnostic.  Now: once per fallback on stderr and through tn_last_warning_string(); the reference's own
+    configurations (a fresh process running one training step of each) never trigger it."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from tinynerf_amd import _lib as L, models as m
+    L.lib().tn_last_warning_string.restype = C.c_char_p
+    net = m.MLP(100, 256, 3, 256).to(DEV)                     # 100 plain inputs: no row-operand first layer for that
+    x = torch.randn(500, 100, device=DEV, requires_grad=True)
+    net(x).sum().backward()
+    msg = L.lib().tn_last_warning_string().decode()
+    assert "general-shape" in msg and "256" in msg, msg
+    code = ("import torch, ctypes\n"
+            "from tinynerf_amd import rays, _lib as L\n"
+            "from tinynerf_amd.run import TrainConfig, Trainer\n"
+            "o, d, rgb, K, _ = rays.synthetic_scene(n_views=2, res=64, seed=0, device='cuda')\n"
+            "for method in ('kplanes', 'vanilla', 'cobafa'):\n"
+            "    tr = Trainer(TrainConfig(method=method, scene_type='aabb', batch_size=256, n_samples=32, seed=1, occupancy_res=32), o, d, rgb,\n"
+            "                 torch.ones(3, device='cuda'), torch.device('cuda'))\n"
+            "    tr.step(); tr.step()\n"
+            "    with torch.no_grad():\n"
+            "        tr.render_rays(o[:2048], d[:2048])\n"
+            "torch.cuda.synchronize()\n"
+            "L.lib().tn_last_warning_string.restype = ctypes.c_char_p\n"
+            "print('WARNING=[' + L.lib().tn_last_warning_string().decode() + ']')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "WARNING=[]" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

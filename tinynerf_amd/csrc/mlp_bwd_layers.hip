@@ -1097,6 +1097,8 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 else if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
                 if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: the layer-by-layer inference forward needs positional-encoding inputs");
+                tn::warn_once(0, "mlp forward: the first layer of this width-%d stack (encoding %d, %d inputs) runs on the general-shape kernel "
+                              "(fast forms: positional encoding with <= 64 slots, or <= 64 plain inputs)", H, a.enc, a.in_dim);
                 fwd_stash_kernel<H, WPB, true, true><<<dim3((unsigned)std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4)), dim3(WPB * 64), 0, s>>>(
                     a, x, aux, nullptr, n, stash, y);
                 if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
@@ -1120,6 +1122,8 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
         }
     }
     if (inference) return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_ws: configuration without a layer-by-layer inference forward");
+    if (H >= 128) tn::warn_once(1, "mlp forward: this width-%d stack (%d layers, %d outputs) is outside the layer-by-layer kernels and runs on "
+                                   "the general-shape kernel", H, a.n_layers, a.out_dim);
     fwd_stash_kernel<H, WPB, true><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, nullptr, n, stash, y);
     return tn::check_launch("fwd_stash_kernel(forward)");
 }
@@ -1201,7 +1205,10 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         }
         if (staged) {}
         else if (tiles <= 16) wgrad_layer_kernel<2><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
-        else if (tiles <= 64) wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
+        else if (tiles <= 64) {
+            if (H >= 128) tn::warn_once(2, "mlp backward: weight gradient of a %d x %d layer on the general-shape kernel (8 tiles per wave, spills)", w.N, w.K);
+            wgrad_layer_kernel<8><<<dim3((unsigned)wblocks), dim3(512), 0, s>>>(w, x, n, stash);
+        }
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: layer too large for the wgrad tiling");
         if (int rc = tn::check_launch("wgrad_layer_kernel")) return rc;
 
@@ -1237,6 +1244,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
                 }
             }
             if (!done) {
+                if (H >= 128) tn::warn_once(3, "mlp backward: data gradient of a %d x %d layer of a width-%d stack on the general-shape kernel", d.N, d.K, H);
                 dgrad_layer_kernel<H, false, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, nullptr);
                 if (int rc = tn::check_launch("dgrad_layer_kernel")) return rc;
             }
@@ -1250,6 +1258,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
                 }
             }
             if (!done) {
+                if (H >= 128) tn::warn_once(4, "mlp backward: d loss / d x of a width-%d stack with %d inputs (encoding %d) on the general-shape kernel", H, a.in_dim, a.enc);
                 dgrad_layer_kernel<H, true, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(d, n, stash, gx);
                 if (int rc = tn::check_launch("dgrad_layer_kernel(first)")) return rc;
             }

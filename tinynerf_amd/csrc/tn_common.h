@@ -10,6 +10,7 @@
 namespace tn {
 
 void set_error(const char *fmt, ...);
+void warn_once(int id, const char *fmt, ...);      // (common.hip) a valid call on a slow general-shape fallback: said once per id
 
 inline int fail(int code, const char *what) {
     set_error("%s", what);

@@ -57,7 +57,7 @@ def _digest(paths, flags=None) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode()); h.update(f.read())
+            h.update(os.path.basename(p).encode()); h.update(f.read())      # (names, not paths: the tree is copied to the GPU box)
     for k in sorted(flags or {}):
         h.update(("%s: %s\n" % (k, " ".join(COMMON + flags[k]))).encode())
     return h.hexdigest()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TN_ABI_VERSION 3
+#define TN_ABI_VERSION 4
 
 enum {
     TN_OK = 0,
@@ -211,6 +211,17 @@ enum { TN_ENC_NONE = 0,
                                  * view: TN_MLP_F16X2, in_dim 128 or 256, <= 4 outputs.  Without the flag such a launch still
                                  * prefers x_rows when they are set (coalesced 128-byte rows instead of 16 bytes per lane and sample). */
 
+#define TN_MLP_LEAN 512        /* the paired width-64 heads (tn_mlp_fwd_stash_pair / tn_kplanes_mlp_fwd_pair and their backward twins), round 5:
+                                 * the training forward writes only the ReLU bit masks, the last pre-activation and the feature rows --
+                                 * NOT the hidden activations H_l (1.3 KB per sample that crossed HBM twice) -- and the weight-gradient
+                                 * half of the backward (TN_MLP_WGRAD_ONLY or the full call) rebuilds them from the feature row: a
+                                 * wave recomputes its 32 samples' forward on the fp16 matrix cores (the f16x2 arithmetic of the
+                                 * forward) in BOTH operand orientations -- out[feature][sample] to feed the next layer,
+                                 * out[sample][feature] as the weight gradient's MFMA operand: no transposition through memory --
+                                 * and multiplies with the G rows of the data-gradient chain as exact three-way bf16 splits
+                                 * (csrc/mlp_wgrad_rc.hip).  Set on BOTH descriptors of BOTH calls; the workspace layout is unchanged
+                                 * (its H rows stay unwritten).  Reference: the autograd of src/models.py:7-28,70-89. */
+
 typedef struct tn_mlp_desc {
     int32_t n_layers;                         /* number of Linear layers (>= 1)               */
     int32_t in_dim;                           /* width of x (before encoding)                 */
@@ -311,6 +322,11 @@ int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const f
                     float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,
                     float *grad_x, void *workspace, int64_t workspace_bytes, void *partner_workspace,
                     int64_t partner_workspace_bytes, void *stream);
+
+/* 1 when the pair (`desc` = the 5-layer head, `partner` = the 2-layer head on the same x) can run under TN_MLP_LEAN: the reference's
+ * decoders as f16x2 heads (src/run.py:133-139 + TN_MLP_F16X2: colour 147 -> 64 x 4 -> 3 on [PE_8(d), d, x (96)] through a per-ray table,
+ * sigma 96 -> 64 -> 1), else 0.  Callers choose the training forward's form with it. */
+int tn_mlp_lean_supported(const tn_mlp_desc *desc, const tn_mlp_desc *partner);
 
 /* ------------------------------------------------------------------------------------------
  * a15/a16  K-Planes feature field                              (reference models.py:93-163)

@@ -10,6 +10,13 @@ never unscaled loss) -- on the synthetic scene for N_STEPS steps and several see
     python oracle/make_psnr_curve.py [--seeds 0 1 2] [--steps 300] [--out tests/golden/G17_psnr_curve.json]
     python oracle/make_psnr_curve.py --replay --seeds 0 1 --out tests/golden/G18_psnr_replay.json
     python oracle/make_psnr_curve.py --replay --seeds 0 --method vanilla --lr 1e-3 --steps 200     (G19; cobafa: G20)
+    python oracle/make_psnr_curve.py --bench                                                        (G21: the bench's own configuration)
+
+``--bench`` (round 5): the replay run on the configuration BASELINE.json's metric is quoted on -- bench.py's 20 synthetic 800 x 800
+training cameras (12.8 M rays), B = 1024, S = 1024, its occupancy ball as the initial grid, seed 0, 70 steps -- with the held-out PSNR of
+bench.py's 800 x 800 test camera (``rays.synthetic_scene(n_views=1, seed=10007)``) at the step counts the bench ends on (65 with the
+driver's ``--warmup 5 --steps 20``, 70 with the defaults).  ~45 min on 8 cores -> tests/golden/G21_psnr_bench.json;
+``bench.py`` reports ``psnr_at_step.reference`` / ``delta_db`` from it and tests/test_hip_psnr.py holds the HIP trainer against it.
 
 ``--replay``: every random choice (ray order, sampling jitter, refresh jitter) comes from the streams the HIP harness defines for
 ``TrainConfig(seed, host_shuffle=True)`` (restated in ``reference_training(replay=...)``), so the GPU run walks the same rays with the
@@ -35,6 +42,63 @@ from oracle import torch_port as tp                 # noqa: E402
 CONFIG = dict(n_views=21, res=100, batch_size=1024, n_samples=128, occupancy_res=128, method="kplanes", scene_seed=0)
 EVAL_AT = (0, 50, 100, 150, 200, 250, 300)
 EVAL_AT_REPLAY = (0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 125, 150, 200, 250, 300)
+# the bench's own workload (bench.py main(): TrainConfig(kplanes, aabb, 1024, 1024, seed 0), 20 views, occupancy ball)
+BENCH_CONFIG = dict(n_views=20, res=800, batch_size=1024, n_samples=1024, occupancy_res=128, method="kplanes", scene_seed=0,
+                    heldout_seed=10_007, grid0="ball(0.5) / decay^20")
+BENCH_EVAL_AT = (0, 30, 65, 70)
+
+
+def bench_grid0(res: int = 128) -> np.ndarray:
+    """bench.py's initial occupancy grid: 1 inside the centred ball of radius 0.5 (normalised coordinates), decay^20 elsewhere --
+    built with torch's CPU kernels on both sides (bench.py uploads this very array)"""
+    decay = 0.01 ** (1 / 16)
+    lin = torch.linspace(-1, 1, res)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    return torch.where(xx * xx + yy * yy + zz * zz < 0.25, 1.0, decay ** 20).to(torch.float32).numpy()
+
+
+def bench_main(args):
+    """G21: see the module docstring"""
+    from tinynerf_amd import rays
+    c = BENCH_CONFIG
+    torch.set_num_threads(args.threads)
+    o, d, rgbs, _, _ = rays.synthetic_scene(n_views=c["n_views"], res=c["res"], seed=c["scene_seed"], device="cpu")
+    ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=c["res"], seed=c["heldout_seed"], device="cpu")
+    o, d, rgbs, ho, hd = o.numpy(), d.numpy(), rgbs.numpy(), ho.numpy(), hd.numpy()
+    aabb = np.array([[-1.5] * 3, [1.5] * 3], np.float32)
+    bg = torch.ones(3)
+    steps = args.steps if args.steps != 300 else 70
+    eval_at = [e for e in BENCH_EVAL_AT if e <= steps]
+    out = args.out or os.path.join(ROOT, "tests", "golden", "G21_psnr_bench.json")
+    curve, t0 = {}, time.perf_counter()
+
+    def eval_fn(step, sd, grid, thr):
+        sdd = {k: v.detach() for k, v in sd.items()}
+        parts, n_s = [], 0
+        for k in range(0, ho.shape[0], 8192):               # (the numpy sampler materialises [R, S, 3] arrays: chunks of 8192 rays)
+            packed, info = orc.ray_provider(ho[k:k + 8192], hd[k:k + 8192], marcher="aabb", contraction="aabb", grid=grid, threshold=thr,
+                                            n_samples=c["n_samples"], near=0.1, aabb=aabb)
+            n_s += packed.shape[0]
+            with torch.no_grad():
+                parts.append(tp.render(sdd, torch.from_numpy(packed), torch.from_numpy(info), bg))
+        img = torch.cat(parts, 0)
+        curve[step] = float(-10.0 * torch.log10(torch.mean((img - hrgb) ** 2)))
+        print(f"step {step}: held-out psnr {curve[step]:.4f} dB, {n_s} samples ({time.perf_counter() - t0:.0f} s)", flush=True)
+        json.dump(curve, open(out + ".partial", "w"))
+
+    def on_step(step, sd, packed, info, target):
+        print(f"step {step}: {packed.shape[0]} samples / {info.shape[0]} rays ({time.perf_counter() - t0:.0f} s)", flush=True)
+    sd0 = initial_state(0, c["method"], batch_size=c["batch_size"], n_samples=c["n_samples"])
+    losses, _, counts = tp.reference_training(sd0, o, d, rgbs, method=c["method"], batch_size=c["batch_size"], n_samples=c["n_samples"],
+                                              n_steps=steps, occupancy_res=c["occupancy_res"], grid0=bench_grid0(c["occupancy_res"]),
+                                              eval_at=eval_at, eval_fn=eval_fn, on_step=on_step, replay={"seed": 0, "rank": 0})
+    json.dump({"config": c, "eval_at": eval_at, "steps": steps, "torch": torch.__version__, "replay": True,
+               "runs": [{"seed": 0, "psnr": {str(k): v for k, v in sorted(curve.items())}, "loss": losses,
+                         "samples_per_step": [cn[0] for cn in counts], "rays_per_step": [cn[1] for cn in counts]}],
+               "made_by": "oracle/make_psnr_curve.py --bench (CPU port of the reference's train() on bench.py's configuration, replay streams)"},
+              open(out, "w"), indent=1)
+    if os.path.exists(out + ".partial"):
+        os.remove(out + ".partial")
 
 
 def scene():
@@ -45,11 +109,11 @@ def scene():
     return (o[:n_train], d[:n_train], rgbs[:n_train]), (o[n_train:], d[n_train:], rgbs[n_train:])
 
 
-def initial_state(seed: int, method: str = None):
+def initial_state(seed: int, method: str = None, batch_size: int = None, n_samples: int = None):
     """the parameters ``run.Trainer(cfg(seed=seed))`` starts from: torch.manual_seed(seed) + the reference's constructors"""
     from tinynerf_amd.run import TrainConfig, build_renderer
-    cfg = TrainConfig(method=method or CONFIG["method"], scene_type="aabb", batch_size=CONFIG["batch_size"], n_samples=CONFIG["n_samples"],
-                      seed=seed, occupancy_res=CONFIG["occupancy_res"])
+    cfg = TrainConfig(method=method or CONFIG["method"], scene_type="aabb", batch_size=batch_size or CONFIG["batch_size"],
+                      n_samples=n_samples or CONFIG["n_samples"], seed=seed, occupancy_res=CONFIG["occupancy_res"])
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
         renderer, _, _ = build_renderer(cfg, torch.ones(3), torch.device("cpu"))
@@ -65,7 +129,11 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-2, help="run.py:110 has 1e-2; the two deep stacks fall into the all-masked branch "
                     "with it on this scene within a few steps (in the port as on the GPU): their curves use 1e-3")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--bench", action="store_true", help="G21: the replay run on bench.py's own configuration (800 x 800, B = S = 1024)")
+    ap.add_argument("--threads", type=int, default=torch.get_num_threads())
     args = ap.parse_args()
+    if args.bench:
+        return bench_main(args)
     cfg = dict(CONFIG, method=args.method)
     if args.lr != 1e-2:
         cfg["lr"] = args.lr

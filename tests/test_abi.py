@@ -34,7 +34,8 @@ def test_header_declares_the_reference_boundary():
 def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.tn_abi_version() == 3
+    from tinynerf_amd import _lib as L
+    assert lib.tn_abi_version() == L.ABI_VERSION == 4          # (header TN_ABI_VERSION; _lib.lib() refuses any other library)
 
 
 def test_integration_guide_covers_every_entry_point():

@@ -66,6 +66,8 @@ MLP_BF16X3 = 32
 MLP_F16X2 = 64
 MLP_ROWS_ONLY = 128
 MLP_X_FROM_ROWS = 256
+MLP_LEAN = 512
+ABI_VERSION = 4            # include/tinynerf_hip.h TN_ABI_VERSION: a stale library (TN_LIB_PATH, a forgotten rebuild) fails at load, not in a kernel
 
 
 class PlaneRegItem(C.Structure):
@@ -106,6 +108,10 @@ def lib() -> C.CDLL:
                 "(needs hipcc). tinynerf_amd has no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
         _lib.tn_last_error_string.restype = C.c_char_p
+        got = int(_lib.tn_abi_version())
+        if got != ABI_VERSION:
+            _lib = None
+            raise RuntimeError(f"{LIB_PATH} has ABI version {got}, tinynerf_amd expects {ABI_VERSION}: rebuild it (`python -m tinynerf_amd.build`)")
     return _lib
 
 

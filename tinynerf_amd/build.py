@@ -37,6 +37,7 @@ SOURCES = {
     "mlp_bwd2.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_bwd_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_wgrad_rows.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_wgrad_rc.hip": FAST + ["-munsafe-fp-atomics"],
     "linear.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_f2_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_b3_layers.hip": FAST + ["-munsafe-fp-atomics"] + (["-DTN_B3_ABLATE=" + os.environ["TN_B3_ABLATE"]] if os.environ.get("TN_B3_ABLATE") else [])

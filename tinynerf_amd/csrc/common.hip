@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
+#include <string.h>
 
 namespace tn {
 static thread_local char g_err[512] = "";
@@ -33,5 +34,12 @@ void warn_once(int id, const char *fmt, ...) {
 }  // namespace tn
 
 extern "C" const char *tn_last_error_string(void) { return tn::g_err; }
-extern "C" const char *tn_last_warning_string(void) { return tn::g_warn; }
+extern "C" const char *tn_last_warning_string(void) {
+    // a copy taken under the writer's mutex into a buffer of the calling thread: warn_once() may rewrite g_warn at any time
+    static thread_local char copy[sizeof(tn::g_warn)];
+    std::lock_guard<std::mutex> lk(tn::g_warn_mu);
+    memcpy(copy, tn::g_warn, sizeof(copy));
+    copy[sizeof(copy) - 1] = 0;
+    return copy;
+}
 extern "C" int tn_abi_version(void) { return TN_ABI_VERSION; }

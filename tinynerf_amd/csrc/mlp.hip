@@ -74,7 +74,9 @@ struct KpFwd {
 // XB (F2 without KP): the first layer's 16 XB x columns of a sample stay in registers between the column maximum and the products
 // (in_dim == 16 XB): ONE round of loads per tile instead of two dependent passes over the row -- at 256 inputs and 12 waves per
 // CU the two passes were the launch (0.56 ms for 0.55 M samples: ~32 exposed L2 round trips per tile and wave).
-template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false, bool F2 = false, int XB = 0>
+// LEAN (with F2, STASH, PAIR; TN_MLP_LEAN): the hidden activations are NOT written to the workspace -- masks, the last pre-activation and
+// the feature rows are; the weight-gradient kernels rebuild H from the feature rows (mlp_wgrad_rc.hip).
+template <int H, bool WLDS, int WPB, bool STASH, bool PAIR = false, bool FAST = false, bool KP = false, bool F2 = false, int XB = 0, bool LEAN = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const float *__restrict__ x,
                                                            const float *__restrict__ aux0, int64_t n,
                                                            float *__restrict__ y0, float *__restrict__ pre_act0,
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
 {
     static_assert(!KP || (FAST && H == 64), "the fused gather feeds the plain-column first layer of the width-64 heads");
     static_assert(!F2 || (FAST && WLDS && H == 64), "f16x2 heads: plain-column first layer, weights in LDS, width 64");
+    static_assert(!LEAN || (F2 && STASH && PAIR), "TN_MLP_LEAN: the paired f16x2 training forward");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     if constexpr (F2) {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) act[ob][r] += bias[r];
             act[ob] = tn::relu16(act[ob]);
-            if constexpr (STASH) { stM[ob * 64 + lane] = relu_bits(act[ob]); store_rows(stH, act[ob], ob, j, h); }
+            if constexpr (STASH) { stM[ob * 64 + lane] = relu_bits(act[ob]); if constexpr (!LEAN) store_rows(stH, act[ob], ob, j, h); }
         }
         TN_PT(3)
         // ---- hidden layers ----
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_fwd_kernel(MlpArgs a0, const flo
 #pragma unroll
                 for (int ob = 0; ob < T; ++ob) {
                     stM[(l * T + ob) * 64 + lane] = relu_bits(act[ob]);
-                    store_rows(stH + l * H * 32, act[ob], ob, j, h);
+                    if constexpr (!LEAN) store_rows(stH + l * H * 32, act[ob], ob, j, h);       // (TN_MLP_LEAN leaves the H rows out)
                 }
             }
         }
@@ -664,14 +667,18 @@ int launch_fwd(const MlpArgs &a_in, const float *x, const float *aux, int64_t n,
                     return TN_OK;
                 };
                 // fp32 heads: 12 waves (8 waves x 256 VGPRs measured the same: 0.86 ms)
-                const int rc = f2 ? go(mlp_fwd_kernel<H, true, TN_F2_KP_WAVES, true, true, true, true, true>, TN_F2_KP_WAVES)
+                if (a.lean && !f2) return tn::fail(TN_E_CONFIG, "TN_MLP_LEAN needs the f16x2 heads (TN_MLP_F16X2)");
+                const int rc = f2 ? (a.lean ? go(mlp_fwd_kernel<H, true, TN_F2_KP_WAVES, true, true, true, true, true, 0, true>, TN_F2_KP_WAVES)
+                                            : go(mlp_fwd_kernel<H, true, TN_F2_KP_WAVES, true, true, true, true, true>, TN_F2_KP_WAVES))
                                   : go(mlp_fwd_kernel<H, true, 12, true, true, true, true>, 12);
                 if (rc) return rc;
                 return tn::check_launch("mlp_fwd_kernel(kplanes)");
             }
             if (a.x_from_rows && !(f2 && !pair && a.x_rows != nullptr && (a.in_dim == 256 || a.in_dim == 128)))
                 return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: TN_MLP_X_FROM_ROWS needs an f16x2 head with 128 or 256 inputs and x_rows");
-            if (f2 && !pair && a.in_dim == 256) rc = launch(mlp_fwd_kernel<H, true, 8, true, false, true, false, true, 16>, 8);      // (x: 128 VGPRs)
+            if (a.lean && !(f2 && pair)) return tn::fail(TN_E_CONFIG, "TN_MLP_LEAN needs the paired f16x2 heads (TN_MLP_F16X2, tn_mlp_fwd_stash_pair)");
+            if (a.lean) rc = launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true, 0, true>, 12);
+            else if (f2 && !pair && a.in_dim == 256) rc = launch(mlp_fwd_kernel<H, true, 8, true, false, true, false, true, 16>, 8);      // (x: 128 VGPRs)
             else if (f2 && !pair && a.in_dim == 128) rc = launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true, 8>, 12);
             else if (f2) rc = pair ? launch(mlp_fwd_kernel<H, true, 12, true, true, true, false, true>, 12) : launch(mlp_fwd_kernel<H, true, 12, true, false, true, false, true>, 12);
             else if (fast) rc = pair ? launch(mlp_fwd_kernel<H, true, 16, true, true, true>, 16) : launch(mlp_fwd_kernel<H, true, 16, true, false, true>, 16);

@@ -25,6 +25,9 @@
 extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
+extern "C" int tn_mlp_wgrad_lean_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux, int64_t n,
+                                      float *const *gw, float *const *gb, float *const *gws, float *const *gbs, const float *ws_a,
+                                      const float *ws_b, void *stream);
 extern "C" int tn_mlp_wgrad_rows(const float *g_rows, int64_t g_stride, int ng, const float *a_rows, int64_t a_stride, int na, float *gW,
                                  int ldw, int col0, int kmax, float *gB, int64_t n, void *stream);
 
@@ -1140,6 +1143,17 @@ static int bwd_pair_common(const tn_mlp_desc *desc, const tn_mlp_desc *partner, 
     a.accum_gx = 0;
     const bool chain = !(desc->flags & TN_MLP_WGRAD_ONLY), wgrad = !(desc->flags & TN_MLP_CHAIN_ONLY);
     TN_REQUIRE(chain || wgrad, TN_E_CONFIG, "tn_mlp_bwd_pair: TN_MLP_CHAIN_ONLY and TN_MLP_WGRAD_ONLY exclude each other");
+    const bool lean = (desc->flags & TN_MLP_LEAN) != 0;
+    TN_REQUIRE(lean == ((partner->flags & TN_MLP_LEAN) != 0), TN_E_CONFIG, "tn_mlp_bwd_pair: TN_MLP_LEAN must be set on both heads or on neither");
+    if (lean) {
+        // the workspaces hold no H rows (the forward ran with TN_MLP_LEAN): the chain half needs none; the weight-gradient half
+        // rebuilds them from the feature rows (mlp_wgrad_rc.hip)
+        if (chain)
+            if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr, 1, kpb)) return rc;
+        if (!wgrad) return TN_OK;
+        return tn_mlp_wgrad_lean_pair(desc, partner, x, aux, n, grad_weights, grad_biases, partner_grad_weights, partner_grad_biases,
+                                      (const float *)workspace, (const float *)partner_workspace, stream);
+    }
     if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr,
                                  (chain ? 1 : 0) | (wgrad ? 2 : 0), kpb)) return rc;
     if (!wgrad) return TN_OK;

@@ -29,6 +29,7 @@ struct MlpArgs {
     int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
     int rows_only;         // TN_MLP_ROWS_ONLY (producer: no row-major y)
     int x_from_rows;       // TN_MLP_X_FROM_ROWS (consumer: x only exists as x_rows)
+    int lean;              // TN_MLP_LEAN: the training forward leaves the H rows of the workspace unwritten (mlp_wgrad_rc.hip rebuilds them)
     int f2_plane[TN_MLP_MAX_LAYERS], f2_scale;     // f16x2 heads (mlp_f2_heads.h): halfs per weight plane, float index of the (s, 1 / s) pairs
 };
 
@@ -207,6 +208,7 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     a.f2 = (d->flags & TN_MLP_F16X2) != 0;
     a.rows_only = (d->flags & TN_MLP_ROWS_ONLY) != 0;
     a.x_from_rows = (d->flags & TN_MLP_X_FROM_ROWS) != 0;
+    a.lean = (d->flags & TN_MLP_LEAN) != 0;
     a.x_rows = d->x_rows; a.gx_rows = d->grad_x_rows; a.x_rows_stride = d->x_rows_tile_stride; a.gx_rows_stride = d->grad_x_rows_tile_stride;
     TN_REQUIRE((!a.x_rows && !a.gx_rows) || ((a.in_dim & 31) == 0 && a.enc != TN_ENC_POSENC), TN_E_CONFIG,
                "mlp: x_rows / grad_x_rows need in_dim % 32 == 0 and an encoding that keeps x as input columns");

@@ -42,6 +42,10 @@ PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd
 # stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
 # second stream BESIDE the weight-gradient kernels (bound by HBM)
 BWD_SCHEDULE = os.environ.get("TN_BWD_SCHEDULE", "fused")
+# round 5 (TN_MLP_LEAN): the paired f16x2 training forward writes masks / pre-activations / feature rows only, the weight-gradient launches
+# rebuild the hidden activations from the feature rows (csrc/mlp_wgrad_rc.hip) -- 2.7 GB less workspace traffic per K-Planes step.
+# TN_KP_LEAN=0: the stash-everything form of rounds 1-4 (A/B runs; always taken by the fp32 / bf16x3 head forms)
+KP_LEAN = os.environ.get("TN_KP_LEAN", "1") != "0"
 _side_streams: dict = {}
 
 
@@ -166,6 +170,11 @@ class _RenderKPlanes(Function):
         sigma = _alloc(arena, "sigma", (n,), dev)
         rgbs = _alloc(arena, "rgbs", (n, 3), dev)
         pair = (ws_s is not None and ws_r is not None and PAIR_FORWARD and F % 4 == 0 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64)
+        # TN_MLP_LEAN: no hidden activations in the workspace, the weight-gradient launches rebuild them (csrc/mlp_wgrad_rc.hip)
+        lean = bool(pair and KP_LEAN and PAIR_BACKWARD and L.lib().tn_mlp_lean_supported(C.byref(rdesc), C.byref(sdesc)))
+        if lean:
+            rdesc.flags |= L.MLP_LEAN
+            sdesc.flags |= L.MLP_LEAN
         gather_fused = pair and FUSE_GATHER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
         gather_sigma = (not train and FUSE_GATHER and F % 4 == 0 and sig_p[0].size(0) == 64 and kdesc.n_scales == 3 and kdesc.channels == 32
                         and len(keep) == 9)
@@ -238,6 +247,7 @@ class _RenderKPlanes(Function):
             stats["upstream_gated"] = False
         ctx.save_for_backward(packed, info, bg, freqs, feat, sigma, steps, table, ray_ids, weights, rgbs, ws_s, ws_r, *params)
         ctx.cfg = (n_freqs, n_planes, n_sigma, accumulate, stride, sb, rb, covered)
+        ctx.lean = lean
         ctx.arena = arena
         ctx.param_refs = params if accumulate else None
         ctx.planes_ready = hint.get("planes_ready") if (hint is not None and accumulate) else None
@@ -293,13 +303,15 @@ class _RenderKPlanes(Function):
             L.call("tn_kplanes_bwd", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), C.c_int64(n), L.ptr(g_feat), gp)
         if ws_r is not None and ws_s is not None and PAIR_BACKWARD and F % 32 == 0 and ns == 2 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
             # both heads in one data-gradient pass: d/d feat is written once as the sum of the two
-            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED, ray_ids, stride)
-            sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_STASHED)
+            lean_bit = L.MLP_LEAN if ctx.lean else 0
+            rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, L.MLP_STASHED | lean_bit, ray_ids, stride)
+            sdesc = _mlp_desc(sig_p, F, L.ENC_NONE, 0, L.ACT_EXP_M1, None, L.MLP_STASHED | lean_bit)
+            base_flags = rdesc.flags                    # (STASHED + the matrix-mode bit + LEAN: the phase bits are OR-ed in, nothing is dropped)
             pair_args = (C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
                          C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
             scatter_fused = FUSE_SCATTER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
             if BWD_SCHEDULE in ("split", "overlap"):
-                rdesc.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
+                rdesc.flags = base_flags | L.MLP_CHAIN_ONLY
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
                 if BWD_SCHEDULE == "overlap":
                     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
@@ -311,7 +323,7 @@ class _RenderKPlanes(Function):
                 scattered = True
                 if ctx.planes_ready is not None and BWD_SCHEDULE == "split":
                     ctx.planes_ready(g_planes)
-                rdesc.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
+                rdesc.flags = base_flags | L.MLP_WGRAD_ONLY
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
                 if BWD_SCHEDULE == "overlap":
                     main.wait_stream(side)
@@ -320,7 +332,7 @@ class _RenderKPlanes(Function):
             elif scatter_fused:
                 # data gradients of both heads AND the plane scatter in one launch: d loss / d features stays in registers
                 def chain_and_weights(flags):
-                    rdesc.flags = L.MLP_STASHED | flags
+                    rdesc.flags = base_flags | flags
                     L.call("tn_kplanes_mlp_bwd_pair", dev, C.byref(kdesc), L.ptr(packed), C.c_int64(7), gp, C.byref(rdesc), C.byref(sdesc),
                            L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma), C.c_int64(n), gw_r, gb_r, gw_s, gb_s, C.c_void_p(None),
                            L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
@@ -335,16 +347,19 @@ class _RenderKPlanes(Function):
             elif ctx.planes_ready is not None:
                 # N > 1: data gradients -> plane scatter -> hand the finished plane gradients to the caller (it starts their
                 # all-reduce) -> weight gradients of the heads, which run while the planes are on the wire
-                rdesc.flags = L.MLP_STASHED | L.MLP_CHAIN_ONLY
+                rdesc.flags = base_flags | L.MLP_CHAIN_ONLY
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
                 scatter()
                 scattered = True
                 ctx.planes_ready(g_planes)
-                rdesc.flags = L.MLP_STASHED | L.MLP_WGRAD_ONLY
+                rdesc.flags = base_flags | L.MLP_WGRAD_ONLY
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
             else:
                 L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
         else:
+            if ctx.lean:
+                raise RuntimeError("tinynerf_amd: the forward ran with TN_MLP_LEAN (no hidden activations in the workspace) but this backward "
+                                   "is not the paired form that rebuilds them")
             stashed = L.MLP_STASHED if ws_r is not None else 0
             rdesc = _mlp_desc(rgb_p, F, L.ENC_AUX_CAT, n_freqs, L.ACT_SIGMOID, freqs, stashed, ray_ids, stride)
             if ws_r is None:

@@ -35,6 +35,19 @@
 #ifndef TN_RC_SB
 #define TN_RC_SB
 #endif
+#ifdef TN_PHASE_TIMERS            // dev build: where a tile's cycles go (scripts/phase_time_rc.py)
+__device__ unsigned long long tn_phase_cycles_rc[16];
+#define TN_PTR_BEGIN unsigned long long ptr_ = __builtin_amdgcn_s_memtime();
+#define TN_PTR(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (tn::lane_id() == 0) atomicAdd(&tn_phase_cycles_rc[k], n_ - ptr_); ptr_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int tn_debug_phase_cycles_rc(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(tn_phase_cycles_rc), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(tn_phase_cycles_rc), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define TN_PTR_BEGIN
+#define TN_PTR(k)
+#endif
 namespace {
 
 using tn::f32x16;
@@ -89,14 +102,17 @@ __device__ __forceinline__ WOp load_w(const _Float16 *__restrict__ Wh, int plane
     w.a1h = *reinterpret_cast<const u32x4h *>(p1); w.a1l = *reinterpret_cast<const u32x4h *>(p1 + plane);
     return w;
 }
+// `first`: the k block that opens an accumulation -- its MFMAs take the inline constant 0 as C operand instead of a zeroed register tile
+// (16 v_accvgpr_write per tile and chain: 300 instructions per 32 samples)
 template <bool S>
-__device__ __forceinline__ void mma_sf(const WOp &w, const u32x4h &bh, const u32x4h &bl, f32x16 (&accS)[2], f32x16 (&accF)[2]) {
+__device__ __forceinline__ void mma_sf(const WOp &w, const u32x4h &bh, const u32x4h &bl, f32x16 (&accS)[2], f32x16 (&accF)[2], bool first = false) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (S) {
-        accS[0] = mfma_f16(w.a0l, bh, accS[0]);
-        accS[1] = mfma_f16(w.a1l, bh, accS[1]);
+        accS[0] = mfma_f16(w.a0l, bh, first ? z : accS[0]);
+        accS[1] = mfma_f16(w.a1l, bh, first ? z : accS[1]);
     }
-    accF[0] = mfma_f16(bh, w.a0l, accF[0]);
-    accF[1] = mfma_f16(bh, w.a1l, accF[1]);
+    accF[0] = mfma_f16(bh, w.a0l, first ? z : accF[0]);
+    accF[1] = mfma_f16(bh, w.a1l, first ? z : accF[1]);
     if constexpr (S) {
         accS[0] = mfma_f16(w.a0h, bl, accS[0]);
         accS[1] = mfma_f16(w.a1h, bl, accS[1]);
@@ -129,13 +145,16 @@ struct RcArgs {
 
 // compile-time shape (the reference's decoders, src/run.py:133-139: colour head 3 outputs on [PE_8(d) (48), d (3), x (96)], sigma head 1):
 // OA / OB = output rows of the two heads, NGA / NBA = groups of 8 / k blocks of 16 table columns
+// (The body is a function of __restrict__ pointers: no store of the kernel aliases a load.)  Tried for the G rows and measured, not kept:
+// LDS-direct requests (global_load_lds_dwordx4 into a wave-private 8 KB buffer: no staging registers).  Through the builtin hipcc's waitcnt
+// pass serialises them completely -- vmcnt(0) in front of every request and of every ds_read behind one: 0.64 ms against 0.54 --, through
+// inline assembly the requests overlap, but the 16 address registers per stage brought 19 spills back, and a scratch reload drains the
+// queue like any other vmcnt(0).  The register form below (two sets in turn, requested a stage + a layer ahead) has none.
 template <int WPB, bool AUX, int OA, int OB, int NGA, int NBA>
-__global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
+__device__ __forceinline__ void wgrad_rc_body(const RcArgs &p, const float *__restrict__ ldsa, const float *__restrict__ ldsb, float *__restrict__ /*unused*/,
+                                              const float *__restrict__ px, const float *__restrict__ paux, const int *__restrict__ paidx,
+                                              const float *__restrict__ pws_a, const float *__restrict__ pws_b)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights_f2(p.a, lds);
-    stage_weights_f2(p.b, lds + p.a.lds_floats);
-    const float *ldsa = lds, *ldsb = lds + p.a.lds_floats;
     const int lane = tn::lane_id(), j_ = lane & 31, h_ = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n = p.n, n_tiles = (n + 31) >> 5;
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
     auto fetch_x = [&](int64_t t) {
         int64_t r = t * 32 + j_;
         r = r < n ? r : n - 1;
-        const float *xr = p.x + r * 96 + 4 * h_;
+        const float *xr = px + r * 96 + 4 * h_;
 #pragma unroll
         for (int g = 0; g < 12; ++g) fr[g] = *reinterpret_cast<const f32x4 *>(xr + 8 * g);
     };
@@ -175,11 +194,11 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
     auto fetch_aidx = [&](int64_t t) {
         int64_t r = t * 32 + j_;
         r = r < n ? r : n - 1;
-        if constexpr (has_aux) aidx = p.a.aux_index[r];
+        if constexpr (has_aux) aidx = paidx[r];
     };
     auto fetch_aux = [&]() {
         if constexpr (has_aux) {
-            const float *arow = p.aux + (int64_t)aidx * p.a.aux_stride + 4 * h_;
+            const float *arow = paux + (int64_t)aidx * p.a.aux_stride + 4 * h_;
 #pragma unroll
             for (int g = 0; g < 8; ++g) av[g] = *reinterpret_cast<const f32x4 *>(arow + 8 * (g < nga ? g : nga - 1));
         }
@@ -190,16 +209,18 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
         fetch_aux();
         fetch_x(t0 < n_tiles ? t0 : n_tiles - 1);
     }
-    float gq[2][16];              // the G rows of the NEXT weight-gradient stage (both row blocks), requested one layer ahead
+    // G rows of the weight-gradient stages: two register sets in turn, each requested a whole stage + layer ahead of its use
+    float gqa[2][16], gqb[2][16];
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         int j = j_, h = h_;
         asm volatile("" : "+v"(j), "+v"(h));
-        const float *wsa = p.ws_a + tile * (int64_t)(Rta * 32);
-        const float *wsb = p.ws_b + tile * (int64_t)(Rtb * 32);
+        const float *wsa = pws_a + tile * (int64_t)(Rta * 32);
+        const float *wsb = pws_b + tile * (int64_t)(Rtb * 32);
         const _Float16 *W0 = reinterpret_cast<const _Float16 *>(ldsa + p.a.w_off[0]);
         const int plane0 = p.a.f2_plane[0], st0 = p.a.stride[0];
         const int64_t tile_next = tile + (int64_t)gridDim.x * WPB < n_tiles ? tile + (int64_t)gridDim.x * WPB : n_tiles - 1;
         fetch_aidx(tile_next);
+        TN_PTR_BEGIN
 
         f32x16 accS[2], accF[2], actS[2], actF[2];
         // ---- colour head, layer 0, table columns first (their registers are the first to go): both orientations ----
@@ -210,14 +231,13 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             for (int g = 0; g < 8; ++g) m = fmaxf(fmaxf(m, fmaxf(fabsf(av[g][0]), fabsf(av[g][1]))), fmaxf(fabsf(av[g][2]), fabsf(av[g][3])));
             float s_a, inv_a;
             f2_scales(wave_max(m), s_a, inv_a);
-            zero2(accS); zero2(accF);
 #pragma unroll
             for (int ba = 0; ba < nba; ++ba) {
                 const WOp wn = load_w(W0, plane0, st0, j, h, 6 + (ba + 1 < nba ? ba + 1 : ba));
                 const float v[8] = {av[2 * ba][0], av[2 * ba][1], av[2 * ba][2], av[2 * ba][3], av[2 * ba + 1][0], av[2 * ba + 1][1], av[2 * ba + 1][2], av[2 * ba + 1][3]};
                 u32x4h bh, bl;
                 f2_split8(v, s_a, bh, bl);
-                mma_sf<true>(w, bh, bl, accS, accF);
+                mma_sf<true>(w, bh, bl, accS, accF, ba == 0);
                 TN_RC_SB
                 w = wn;
             }
@@ -231,6 +251,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             zero2(actS); zero2(actF);
         }
         TN_RC_SB
+        TN_PTR(0)
         // ---- the feature rows as fp16 operands under one scale per tile ----
         u32x4h xbh[6], xbl[6];
         float inv_x;
@@ -247,17 +268,17 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             }
         }
         TN_RC_SB
+        TN_PTR(1)
         // G_1 rows: needed behind the first layer, requested in front of it
-        load_block_f(wsa + (int64_t)((NH + 1) * H) * 32, j, h, gq[0]);
-        load_block_f(wsa + (int64_t)((NH + 1) * H + 32) * 32, j, h, gq[1]);
+        load_block_f(wsa + (int64_t)((NH + 1) * H) * 32, j, h, gqa[0]);
+        load_block_f(wsa + (int64_t)((NH + 1) * H + 32) * 32, j, h, gqa[1]);
         // ---- colour head, layer 0, x columns ----
         {
             WOp w = load_w(W0, plane0, st0, j, h, 0);
-            zero2(accS); zero2(accF);
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const WOp wn = load_w(W0, plane0, st0, j, h, b + 1 < 6 ? b + 1 : b);
-                mma_sf<true>(w, xbh[b], xbl[b], accS, accF);
+                mma_sf<true>(w, xbh[b], xbl[b], accS, accF, b == 0);
                 TN_RC_SB
                 w = wn;
             }
@@ -276,6 +297,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             }
         }
         TN_RC_SB
+        TN_PTR(2)
         // ---- sigma head: H_1s (lane = feature) -> dW_1s, db_1s on the VALU (<= 4 output rows) ----
         {
             const _Float16 *W0s = reinterpret_cast<const _Float16 *>(ldsb + p.b.w_off[0]);
@@ -284,11 +306,10 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
 #pragma unroll
             for (int o = 0; o < OB; ++o) load_block_f(wsb + 2 * H * 32, o, h, gs[o]);
             WOp w = load_w(W0s, pls, sts, j, h, 0);
-            zero2(accF);
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const WOp wn = load_w(W0s, pls, sts, j, h, b + 1 < 6 ? b + 1 : b);
-                mma_sf<false>(w, xbh[b], xbl[b], accS, accF);
+                mma_sf<false>(w, xbh[b], xbl[b], accS, accF, b == 0);
                 TN_RC_SB
                 w = wn;
             }
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             }
         }
         TN_RC_SB
-        fetch_aux();                    // (32 registers across the hidden layers; the 48 of the feature rows are requested in the last one)
+        TN_PTR(3)
 
         // ---- hidden layers: dW_l += G_l H_l^T with H_l = actF (lane = feature), then H_{l+1} in the orientation(s) still needed ----
         float go[OA][16];               // g_pre rows of the colour head (requested in front of the last layer)
@@ -317,7 +338,16 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
         for (int l = 1; l <= 3; ++l) {
             const _Float16 *Wl = reinterpret_cast<const _Float16 *>(ldsa + p.a.w_off[l]);
             const int plane = p.a.f2_plane[l], stride = p.a.stride[l];
-            // both operands as bf16 triplets: H_l from registers, the G_l rows of the workspace (lane = feature row, register = sample)
+            // the stage's G rows: out of the wave's LDS buffer (l = 1, 3) or the registers requested a layer and a half ago (l = 2); the
+            // requests that follow are in flight for 12 k cycles or more
+            // this stage's rows are in one register set; the next stage's are requested into the other one right here
+            float (&gq)[2][16] = (l == 2) ? gqb : gqa;
+            if (l < 3) {
+                float (&gn)[2][16] = (l == 1) ? gqb : gqa;
+                load_block_f(wsa + (int64_t)((NH + l + 1) * H) * 32, j, h, gn[0]);
+                load_block_f(wsa + (int64_t)((NH + l + 1) * H + 32) * 32, j, h, gn[1]);
+            }
+            // both operands as bf16 triplets: H_l from registers, G_l (lane = feature row, register = sample)
             {
                 b3::Op HB[2][2];
 #pragma unroll
@@ -342,11 +372,11 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
                     TN_RC_SB
                 }
             }
-            // the next stage's rows: a whole layer ahead of their use
-            if (l < 3) {
-                load_block_f(wsa + (int64_t)((NH + l + 1) * H) * 32, j, h, gq[0]);
-                load_block_f(wsa + (int64_t)((NH + l + 1) * H + 32) * 32, j, h, gq[1]);
-            } else {
+            TN_PTR(3 + l)
+            // register prefetches behind the stage's MFMAs, where the operand triplets have gone: the table rows of the next tile (32
+            // registers across the hidden layers), and in the last layer its feature rows (48) and this tile's g_pre rows
+            if (l == 1) fetch_aux();
+            if (l == 3) {
 #pragma unroll
                 for (int o = 0; o < OA; ++o) load_block_f(wsa + 2 * NH * H * 32, o, h, go[o]);
                 fetch_x(tile_next);
@@ -360,7 +390,6 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, actS[kb][r]);
             float s, inv;
             f2_scales(wave_max(m), s, inv);
-            zero2(accS); zero2(accF);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const WOp wn = load_w(Wl, plane, stride, j, h, b + 1 < 4 ? b + 1 : b);
@@ -369,8 +398,8 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
                 for (int e = 0; e < 8; ++e) v[e] = actS[b >> 1][8 * (b & 1) + e];
                 u32x4h bh, bl;
                 f2_split8(v, s, bh, bl);
-                if (l < 3) mma_sf<true>(w, bh, bl, accS, accF);
-                else mma_sf<false>(w, bh, bl, accS, accF);       // (H_4 only feeds the output layer's gradient)
+                if (l < 3) mma_sf<true>(w, bh, bl, accS, accF, b == 0);
+                else mma_sf<false>(w, bh, bl, accS, accF, b == 0);       // (H_4 only feeds the output layer's gradient)
                 TN_RC_SB
                 w = wn;
             }
@@ -389,6 +418,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
                 }
             }
             TN_RC_SB
+            TN_PTR(6 + l)
         }
         // ---- output layer of the colour head: dW_4 = g_pre H_4^T, db_4 on the VALU ----
 #pragma unroll
@@ -398,6 +428,7 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
             for (int r = 0; r < 16; ++r) { s0 = fmaf(go[o][r], actF[0][r], s0); s1 = fmaf(go[o][r], actF[1][r], s1); sg += go[o][r]; }
             dwo[o][0] += s0; dwo[o][1] += s1; dbo[o] += sg;
         }
+        TN_PTR(10)
     }
 
     // ---- flush: D[row = G feature][column = H feature], lanes = consecutive columns of one weight row ----
@@ -446,6 +477,17 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
     }
 }
 
+template <int WPB, bool AUX, int OA, int OB, int NGA, int NBA>
+__global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights_f2(p.a, lds);
+    stage_weights_f2(p.b, lds + p.a.lds_floats);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    wgrad_rc_body<WPB, AUX, OA, OB, NGA, NBA>(p, lds, lds + p.a.lds_floats, nullptr, p.x, p.aux,
+                                              p.a.aux_index, p.ws_a, p.ws_b);
+}
+
 // ------------------------------------------------------------------------------------------------
 // first layers of both heads
 // ------------------------------------------------------------------------------------------------
@@ -455,6 +497,9 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
 // mlp_bwd2.hip's mlp_wgrad4_kernel reduced to its first-layer waves: the tile's G_0 rows of both heads, its x rows and its table rows
 // are staged ONCE per workgroup in LDS (coalesced 16-byte chunks, two buffers, one barrier per tile, every load a full iteration ahead),
 // wave w < 5 owns column block w of the colour head (tiles tn = 0, 1), waves 5 .. 7 column blocks 0 .. 2 of the sigma head.
+// Measured and not kept: the same tiling with every element split into its bf16 triplet on the way from the staging registers to LDS
+// (x / table rows stored transposed, 24 bf16 MFMAs per wave and tile instead of 32 fp32 ones): 0.43 ms against this form's 0.36 -- twelve
+// 2-byte LDS writes per x chunk and one workgroup per CU (139 KB) cost more than the matrix pipe gains.
 struct FlArgs {
     const float *x, *aux;         // [n, 96]; per-ray table [*, aux_stride]
     const int *aux_index;

@@ -64,7 +64,7 @@ KERNEL_MODEL = {
     # data-gradient chain of both heads + the scatter into the nine plane gradients in one kernel: bound by the rate of
     # memory-side fp32 atomics (the lane-atomic count per launch comes from the PMC pass: WRITE_SIZE / 4 B)
     "tn_kplanes_mlp_bwd_pair:chain": ("atomic", FLOP_HEADS_DGRAD, "sample", "mlp_chain_kernel<..., KP> (both chains + plane scatter, one kernel)"),
-    "tn_kplanes_mlp_bwd_pair:wgrad": ("mfma", FLOP_HEADS, "sample", "mlp_wgrad4_kernel + mlp_wgrad_kernel"),
+    "tn_kplanes_mlp_bwd_pair:wgrad": ("mfma", FLOP_HEADS, "sample", "wgrad_first_kernel + wgrad_rc_kernel (TN_MLP_LEAN: activations rebuilt) | mlp_wgrad4_kernel + mlp_wgrad_kernel (stash form)"),
     "tn_kplanes_fwd": ("hbm", 12 + 4608 + 384, "sample", "kplanes_fwd_kernel"),
     "tn_kplanes_bwd": ("atomic", 0, "sample", "kplanes_bwd_kernel"),
     "tn_adam_reg_multi": ("hbm", 32, "plane element", "adam_reg_multi_kernel (p, g, m, v in; p, g, m, v out)"),
@@ -75,8 +75,28 @@ KERNEL_MODEL = {
 MFMA_KERNELS = {
     "tn_kplanes_mlp_fwd_pair": ["mlp_fwd_kernel<64, true, 12, true, true, true, true", "mlp_fwd_kernel<64, true, 8, true, true, true, true"],
     "tn_kplanes_mlp_bwd_pair:chain": ["mlp_chain_kernel<64, 4, 8, true, false, true, true>"],
-    "tn_kplanes_mlp_bwd_pair:wgrad": ["mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1"],
+    "tn_kplanes_mlp_bwd_pair:wgrad": ["mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1", "wgrad_first_kernel", "wgrad_rc_kernel"],
 }
+# Which matrix instructions a timed launch issues, and the dense peak of THAT class in fp32-equivalent TFLOP/s (a fraction of the fp32 MFMA
+# peak says nothing about a launch that runs on the fp16 / bf16 cores).  f16x2: 3 fp16 MFMAs per fp32 product block; bf16x3: 6 bf16 MFMAs.
+MFMA_CLASS = {
+    "f16x2": ("v_mfma_f32_32x32x16_f16, two-term fp16 splits", PEAK_F16X2_TFLOPS),
+    "bf16x3": ("v_mfma_f32_32x32x16_bf16, three-term bf16 splits", PEAK_BF16X3_TFLOPS),
+    "fp32": ("v_mfma_f32_32x32x2_f32", PEAK_FP32_MFMA_TFLOPS),
+}
+
+
+def launch_class(tag: str, mode: str, lean: bool):
+    """(instruction class, what actually limits the launch) of a timed tag under matrix mode `mode`"""
+    if tag == "tn_kplanes_mlp_fwd_pair":
+        return ("f16x2" if mode == "f16x2" else "fp32",
+                "gather round trips + VALU (lean: 0.45 KB written per sample)" if lean else "HBM writes of the activation workspace (2.8 KB per sample)")
+    if tag == "tn_kplanes_mlp_bwd_pair:chain":
+        return ("fp32", "memory-side fp32 atomics of the plane scatter (co_bound)")
+    if tag == "tn_kplanes_mlp_bwd_pair:wgrad":
+        return (("f16x2 (rebuilt forward, both orientations) + bf16x3 (G x H) + fp32 (first layers)", "VALU issue + matrix pipe of one wave per SIMD (wgrad_rc), fp32 matrix pipe (wgrad_first)") if lean
+                else ("fp32", "HBM reads of the activation workspace (3.7 KB per sample)"))
+    return ("fp32", None)
 
 
 def _matmul_mode() -> str:
@@ -113,6 +133,50 @@ def visible_gpus() -> int:
         if v is not None and v.strip() != "":
             n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
     return n
+
+
+def bench_grid0(decay: float, res: int = 128):
+    """the bench's initial occupancy grid (same construction as oracle/make_psnr_curve.py bench_grid0)"""
+    lin = torch.linspace(-1, 1, res)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    return torch.where(xx * xx + yy * yy + zz * zz < 0.25, 1.0, decay ** 20).to(torch.float32)
+
+
+def psnr_replay(o, d, rgbs, dev, n_steps: int, grid0, ho, hd, hrgb):
+    """PSNR@step against the reference recipe ON THE CONFIGURATION THE METRIC IS QUOTED ON (BASELINE.json; run.py:53-54,97-319): a second
+    trainer with the harness' replayable random streams (TrainConfig.host_shuffle: host ray permutation, counter-RNG jitter, seeded
+    refresh jitter) walks the same `n_steps` steps the CPU port of the reference's train() walked for tests/golden/G21_psnr_bench.json
+    (oracle/make_psnr_curve.py --bench: same scene, B = S = 1024, same initial grid and parameters, same streams), then renders the held-out
+    800 x 800 camera.  Outside every timed window (the timed trainer shuffles on the device).  Returns None when the golden has no entry
+    for this step count."""
+    from tinynerf_amd.run import TrainConfig, Trainer, psnr as psnr_fn
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "G21_psnr_bench.json")))
+    except Exception:       # noqa: BLE001
+        return None
+    ref = gold["runs"][0]["psnr"].get(str(n_steps))
+    if ref is None:
+        return {"step": n_steps, "reference": None, "note": "tests/golden/G21_psnr_bench.json holds steps " + ", ".join(sorted(gold["runs"][0]["psnr"], key=int))
+                + " (the driver's --warmup 5 --steps 20 ends on 65, the defaults on 70)"}
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=1024, n_samples=1024, seed=0, host_shuffle=True)
+    t2 = Trainer(cfg, o, d, rgbs, torch.ones(3, device=dev), dev)
+    t2.occupancy_grid.grid.copy_(grid0)
+    t2.occupancy_grid.mean = float(t2.occupancy_grid.grid.mean().item())
+    counts = []
+    for _ in range(n_steps):
+        counts.append(int(t2.step()["n_samples"]))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        img = t2.render_rays(ho, hd)
+    val = float(psnr_fn(img, hrgb))
+    gs = gold["runs"][0]["samples_per_step"]
+    out = {"step": n_steps, "psnr": val, "reference": ref, "delta_db": val - ref,
+           "batch_sizes_equal_first_8": counts[:8] == gs[:8], "loss": t2.loss_value(), "reference_loss": gold["runs"][0]["loss"][n_steps - 1],
+           "golden": "tests/golden/G21_psnr_bench.json (oracle/make_psnr_curve.py --bench: CPU port of the reference's train() on this "
+                     "configuration, replay streams); gate: |delta_db| < 0.1 (tests/test_hip_psnr.py)"}
+    del t2
+    torch.cuda.empty_cache()
+    return out
 
 
 def parse():
@@ -285,8 +349,7 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
            "best_samples_per_s": rate[best], "windows_ms_per_step": win_ms, "steps_each": steps, "warmup_steps": warm,
            "step_ms_events": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms)},
            "device_allocs_in_windows": a1["device_allocs"] - a0["device_allocs"], "alloc_retries": a1["alloc_retries"],
-           "segments": a1["segments"], "reserved_gb": a1["reserved_gb"], "loss": t2.loss_value(),
-           "note": "ms_per_step / samples_per_s = median window; per-step times from HIP events on the launch stream"}
+           "segments": a1["segments"], "reserved_gb": a1["reserved_gb"], "loss": t2.loss_value()}      # (ms_per_step / samples_per_s: median window)
     # width-256 / 128 stacks: algorithmic FLOP of the whole model (forward + data gradient + weight gradient) over the step
     flop = model_flop_per_sample(t2.renderer)
     if flop:
@@ -298,13 +361,13 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
             # every layer of the stack and the heads' forward as two-term fp16 splits with power-of-two scales (TN_MLP_F16X2): THREE fp16
             # MFMAs per fp32 product block; the heads' backward and the first-layer weight gradients stay on the fp32 MFMA
             out["mfma_frac"] = tf / PEAK_F16X2_TFLOPS
-            out["mfma_peak"] = {"tflops": PEAK_F16X2_TFLOPS, "what": "dense fp16 MFMA peak / 3 products per fp32 product (f16x2)"}
+            out["mfma_peak"] = {"tflops": PEAK_F16X2_TFLOPS, "what": "fp16 MFMA peak / 3 (f16x2)"}
             out["vs_fp32_mfma_peak"] = tf / PEAK_FP32_MFMA_TFLOPS
         elif mode == "bf16x3":
             # wide-stack layers on the bf16 matrix cores with exact 3-way operand splits (TN_MLP_BF16X3): fp32-accurate products
             # at six bf16 MFMAs each; the width-64 heads stay on the fp32 MFMA
             out["mfma_frac"] = tf / PEAK_BF16X3_TFLOPS
-            out["mfma_peak"] = {"tflops": PEAK_BF16X3_TFLOPS, "what": "dense bf16 MFMA peak / 6 products per fp32 product (bf16x3)"}
+            out["mfma_peak"] = {"tflops": PEAK_BF16X3_TFLOPS, "what": "bf16 MFMA peak / 6 (bf16x3)"}
             out["vs_fp32_mfma_peak"] = tf / PEAK_FP32_MFMA_TFLOPS
         else:
             out["mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
@@ -407,10 +470,10 @@ def main():
     shard = world if args.scaling == "strong" else 1
     cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=1024, n_samples=1024, seed=0, shard=shard)
     tr = Trainer(cfg, o, d, rgbs, torch.ones(3, device=dev), dev, rank=rank, world_size=world)
-    # occupancy: 1 inside the centred ball of radius 0.5 (normalised coords), decay^20 elsewhere
-    lin = torch.linspace(-1, 1, 128, device=dev)
-    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
-    tr.occupancy_grid.grid.copy_(torch.where(xx * xx + yy * yy + zz * zz < 0.25, 1.0, tr.occupancy_grid.decay ** 20))
+    # occupancy: 1 inside the centred ball of radius 0.5 (normalised coords), decay^20 elsewhere -- built with torch's CPU kernels and
+    # uploaded, so that the CPU checker's replay of this configuration (oracle/make_psnr_curve.py --bench -> G21) starts from the same bits
+    grid0 = bench_grid0(tr.occupancy_grid.decay).to(dev)
+    tr.occupancy_grid.grid.copy_(grid0)
     tr.occupancy_grid.mean = float(tr.occupancy_grid.grid.mean().item())
 
     def sync():
@@ -483,9 +546,15 @@ def main():
         psnr_at_step = {"step": tr.train_step, "psnr": float(psnr_fn(img, hrgb)), "render_ms": render_ms,
                         "view": "held-out 800x800 camera (rays.synthetic_scene(n_views=1, seed=10007)), inference path (training=False sampling)",
                         "samples_per_step": samples / args.steps,
-                        "reference": "tests/golden/G17_psnr_curve.json + tests/test_hip_psnr.py: held-out PSNR of the HIP Trainer against the CPU "
-                                     "port of the reference's train() at equal step counts (seed means, 50..300 steps)"}
-        del img, ho, hd, hrgb
+                        "note": "psnr = the TIMED trainer (device-side shuffle: its ray order is its own); `replay` = a second trainer on the "
+                                "replayable streams, held against the CPU port of the reference's train() on this very configuration"}
+        del img
+        if world == 1 and args.views == 20:
+            try:
+                psnr_at_step["replay"] = psnr_replay(o, d, rgbs, dev, tr.train_step, grid0, ho, hd, hrgb)
+            except Exception as e:                                  # noqa: BLE001 -- the headline line must still be printed
+                psnr_at_step["replay"] = {"error": repr(e)}
+        del ho, hd, hrgb
     # the occupancy refresh (run.py:248-249) runs every 16 * 4096 / B steps: a window of K < 64 steps behind a short warm-up
     # never contains one, so its cost is measured here and folded into `value_with_refresh` at its amortised weight
     refresh = None
@@ -536,8 +605,8 @@ def main():
     others = None
     if rank == 0 and world == 1 and not args.no_stages:
         others = {}
-        for key, method, matmul in (("vanilla", "vanilla", None), ("cobafa", "cobafa", None), ("vanilla_bf16x3", "vanilla", "bf16x3"),
-                                    ("vanilla_fp32_mfma", "vanilla", "fp32")):
+        for key, method, matmul in (("kplanes_fp32_heads", "kplanes", "fp32"), ("vanilla", "vanilla", None), ("cobafa", "cobafa", None),
+                                    ("vanilla_bf16x3", "vanilla", "bf16x3"), ("vanilla_fp32_mfma", "vanilla", "fp32")):
             try:
                 others[key] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows, matmul)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
@@ -564,38 +633,39 @@ def main():
                     act += v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * 1024.0
             return busy / act if act else None
 
+        from tinynerf_amd import fused as _fused
+        mode = _matmul_mode()
+        lean = bool(_fused.KP_LEAN and mode == "f16x2")
+
         def roofline_of(tag):
             bound, unit_work, unit, kernels = KERNEL_MODEL[tag]
             k = ks[tag]
             sec = k["avg_ms"] * 1e-3
             traffic = pmc.get("per_entry", {}).get(tag) if pmc else None
+            cls, limit = launch_class(tag, mode, lean)
             r = {"kernel": tag, "kernels": kernels, "avg_launch_ms": k["avg_ms"], "ms_per_step": k["total_ms"] / args.steps,
                  "rows_per_launch": k["avg_rows"], "row": unit, "algorithmic_per_row": unit_work, "traffic": traffic,
-                 "traffic_source": PMC_PROFILE if traffic is not None else None}
+                 "traffic_source": PMC_PROFILE if traffic is not None else None, "instructions": cls, "limited_by": limit}
             tflops = unit_work * k["avg_rows"] / sec / 1e12 if bound in ("mfma", "atomic") and unit_work else None
-            if bound == "mfma":
-                r.update(bound="mfma", achieved=tflops, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=tflops / PEAK_FP32_MFMA_TFLOPS)
+            if tflops:
+                # `frac` is quoted against the dense peak of the instruction class the launch issues (MFMA_CLASS); the fp32-equivalent
+                # rate over the fp32 MFMA peak is given beside it and means "how much faster than an fp32-MFMA kernel could be"
+                peak = MFMA_CLASS[cls][1] if cls in MFMA_CLASS else PEAK_FP32_MFMA_TFLOPS
+                r.update(bound="mfma", achieved=tflops, peak=peak, unit="TFLOP/s (fp32-equivalent)", frac=tflops / peak,
+                         vs_fp32_mfma_peak=tflops / PEAK_FP32_MFMA_TFLOPS)
             elif bound == "hbm":
                 gbs = unit_work * k["avg_rows"] / sec / 1e9
                 r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS)
-            else:       # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
+            else:               # the stand-alone scatter has no matrix work: HBM-side bytes of the PMC pass against the HBM peak
+                gbs = traffic / sec / 1e9 if traffic else None
+                r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS if gbs else None)
+            if bound == "atomic":   # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
                 lanes = pmc.get("lane_atomics_per_entry", {}).get(tag) if pmc else None
                 ach = lanes / sec / 1e9 if lanes else None
-                # the contract's two rooflines first (this launch also carries both heads' data-gradient MFMAs: bound "mfma" with
-                # the algorithmic FLOP), then what actually limits it: the chip's memory-side atomic rate
-                if tflops:
-                    r.update(bound="mfma", achieved=tflops, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=tflops / PEAK_FP32_MFMA_TFLOPS)
-                else:           # the stand-alone scatter has no matrix work: HBM-side bytes of the PMC pass against the HBM peak
-                    gbs = traffic / sec / 1e9 if traffic else None
-                    r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS if gbs else None)
-                r.update(
-                         co_bound={"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
-                                   "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
-                                   "note": "memory-side fp32 atomics of the plane scatter (full-line requests); peak = MEASURED IN THIS REPO "
-                                           "(scripts/microbench/atomic_scaling.hip: 325 G/s on random lines from >= 4096 waves; "
-                                           "atomic_patterns.hip: 160 G/s on runs of neighbouring lines, which is what consecutive flushes of a "
-                                           "ray are), not a figure of MI355X_MICROARCH.md; with its gathers removed the launch takes the same "
-                                           "time (DESIGN 4.2): this path is the limit it runs at"})
+                r["co_bound"] = {"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
+                                 "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
+                                 "peak_source": "scripts/microbench/atomic_scaling.hip (this repo: 325 G/s, random full lines from >= 4096 waves; "
+                                                "history and conditions: DESIGN 4.2)"}
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
             try:
@@ -603,9 +673,7 @@ def main():
             except Exception:        # noqa: BLE001 -- an odd profile file must not cost the bench line
                 busy = None
             if busy is not None:
-                r["mfma_busy"] = {"frac": busy, "source": MFMA_PROFILE,
-                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the same kernels (profiled pass: "
-                                          "clocks ~3 % lower than the timed run)"}
+                r["mfma_busy"] = {"frac": busy, "source": MFMA_PROFILE}      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)
             return r
 
         step_ms = dt / args.steps * 1e3
@@ -615,21 +683,42 @@ def main():
         per_gpu_samples = samples / args.steps / world
         whole = {"mfma_tflops": FLOP_STEP * per_gpu_samples / (step_ms * 1e-3) / 1e12,
                  "mfma_frac": FLOP_STEP * per_gpu_samples / (step_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                 "note": "algorithmic FLOP of both heads: forward 56 192 + data gradient 49 664 (no gradient for the 51 per-ray input "
-                         "columns) + weight gradient 56 192 = 162 048 per sample, over the whole step"}
+                 "note": "algorithmic FLOP of both heads (forward 56 192 + data gradient 49 664 + weight gradient 56 192 per sample) over the "
+                         "whole step, fp32-equivalent, against the fp32 MFMA peak"}
         if pmc and pmc.get("bytes_per_step"):
             whole.update(hbm_bytes_per_step=pmc["bytes_per_step"], hbm_gbs=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9,
                          hbm_frac=pmc["bytes_per_step"] / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, hbm_source=PMC_PROFILE)
         srt = sorted(window_ms)
+        if stages:
+            tf = FLOP_HEADS * stages["batch_samples"] / (stages["batch_samples"] / stages["render_fwd_samples_per_s"]) / 1e12
+            cls = "f16x2" if mode == "f16x2" else "fp32"
+            stages["render_fwd_roofline"] = {"tflops_fp32_equivalent": tf, "instructions": cls, "frac_of_instruction_class_peak": tf / MFMA_CLASS[cls][1],
+                                             "vs_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS}
+        # <= 1 KB: what a reader of the driver's record needs first (repeated as the LAST key: a tail of the line keeps it as well)
+        oc = others or {}
+        summary = {"value": samples / dt, "ms_per_step": step_ms, "windows_median_ms": srt[len(srt) // 2], "matmul": mode, "lean": lean,
+                   "kernels_ms": {t.replace("tn_kplanes_mlp_", "").replace("tn_", ""): round(v["total_ms"] / args.steps, 4) for t, v in sorted(ks.items())},
+                   "other_ms": {k: round(v["ms_per_step"], 3) for k, v in oc.items() if isinstance(v, dict) and "ms_per_step" in v},
+                   "render_fwd_samples_per_s": stages["render_fwd_samples_per_s"] if stages else None,
+                   "sampler_samples_per_s": stages["sampler_samples_per_s"] if stages else None,
+                   "psnr": ({"step": psnr_at_step["step"], "timed_run": round(psnr_at_step["psnr"], 3),
+                             **({k: (round(v, 4) if isinstance(v, float) else v) for k, v in (psnr_at_step.get("replay") or {}).items()
+                                 if k in ("psnr", "reference", "delta_db")})} if psnr_at_step else None),
+                   "hbm_bytes_per_step": whole.get("hbm_bytes_per_step"), "dominant": roof["kernel"] if roof else None,
+                   "dominant_frac": roof["frac"] if roof else None}
         line = {
+            "summary": summary,
             "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 storage, accumulation and results; TN_MATMUL=%s: " % _matmul_mode() + "with f16x2 (default) the heads' forward products run "
-                          "on v_mfma_f32_32x32x16_f16 as two-term fp16 splits with power-of-two scales (22 of fp32's 24 significand bits per operand, "
-                          "fp32 accumulate; parity tests at the fp32 tolerances), the backward on v_mfma_f32_32x32x2_f32",
             "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
+                       # fp32 storage, accumulation and results everywhere; what the matrix products run on (parity tests at the fp32 tolerances):
+                       "matmul": {"f16x2": "heads' forward (+ its rebuild inside the weight-gradient launch, TN_MLP_LEAN) as two-term fp16 splits with power-of-two "
+                                           "scales on v_mfma_f32_32x32x16_f16; weight-gradient products G x H as exact three-term bf16 splits on "
+                                           "v_mfma_f32_32x32x16_bf16; data-gradient chain and first-layer weight gradients on v_mfma_f32_32x32x2_f32",
+                                  "fp32": "every product on v_mfma_f32_32x32x2_f32", "bf16x3": "heads as fp32; wide stacks (other_configs) as exact bf16 triplets"}[mode],
+                       "TN_MATMUL": mode, "TN_KP_LEAN": lean,
                        "parallelism": (f"dp{world} ({args.scaling} scaling: " + ("every rank runs the recipe's batch" if args.scaling == "weak" else
                                                                                  f"the recipe's B*S samples per step split over the ranks, {1024 // world} rays per loader batch and rank")
                                        + f"): rays sharded over {world} ranks (one per GPU), RCCL all-reduce of plane / MLP gradients"
@@ -645,11 +734,9 @@ def main():
             "stages": stages,
             "other_configs": others,
             "kernel_timing": {"measured_window": sorted(ks_measured), "window_1": sorted(t for t in ks if t not in ks_measured),
-                              "note": "HIP-event pairs on the launch stream; the measured window carries them around the dominant launch only "
-                                      "(found in the last warm-up steps), the first variance window around every modelled launch: ten event "
-                                      "records per step cost 0.03 - 0.2 ms of the step"},
+                              "note": "HIP-event pairs on the launch stream: window 0 around the dominant launch only, window 1 around every modelled launch"},
             "windows": {"n": len(window_ms), "steps_each": args.steps, "ms_per_step": window_ms, "min": srt[0], "median": srt[len(srt) // 2],
-                        "note": "window 0 is the measurement (value, ms_per_step, the dominant launch's events); the others show the spread -- window 1 carries the events of every modelled launch, the window that contains step 64 the occupancy refresh"},
+                        "note": "window 0 = value; window 1 carries all launch events; the window that contains step 64 the occupancy refresh"},
             "kernels_ms_per_step": {t: v["total_ms"] / args.steps for t, v in sorted(ks.items())},
             "allocator": dict(alloc_counters(), device_allocs_in_window0=alloc_w0, arenas_grown_in_window0=grown_w0),
             "roofline": roof,
@@ -658,6 +745,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (the other ranks would sit in the closing barrier)
             line["cpu_baseline"] = cpu_baseline(tr, args.cpu_samples)
+        line["summary_tail"] = summary
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

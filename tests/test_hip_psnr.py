@@ -137,3 +137,33 @@ def test_psnr_at_step_on_the_reference_trajectory_deep_stacks(golden, tight_unti
     for s_ in eval_at:
         assert abs(curve[s_] - run["psnr"][str(s_)]) < (2e-3 if s_ == 0 else 0.1 if s_ <= tight_until else 1.5), (s_, report)
     assert curve[max(eval_at)] > curve[0] + 1.0, report
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("heads_mode", ["f16x2", "fp32"])
+def test_psnr_at_step_on_the_headline_configuration(heads_mode, monkeypatch):
+    """G21 (round 5): PSNR@step pinned on the configuration BASELINE.json's metric is quoted on -- bench.py's 20 synthetic 800 x 800
+    cameras, B = 1024 rays x S = 1024, its occupancy ball, seed 0 -- against the CPU port of the reference's train() on the same replayable
+    streams (oracle/make_psnr_curve.py --bench, ~1 h of CPU).  After the driver's 5 + 3 x 20 = 65 steps (across the occupancy refresh at
+    step 64) the held-out 800 x 800 view must agree within the north star's 0.1 dB, in both head forms (f16x2: the default, with the lean
+    backward of round 5; fp32: the stash form on the fp32 MFMA); the first dynamic batches must have the golden's sizes and the loss of
+    the last step agree to 2 %.  bench.py prints the same comparison as psnr_at_step.replay."""
+    import importlib.util
+    from tinynerf_amd import models, rays
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench.torch = torch
+    monkeypatch.setattr(models, "MATMUL", heads_mode)
+    gold = json.load(open(os.path.join(GOLDEN, "G21_psnr_bench.json")))
+    c = gold["config"]
+    assert c["n_views"] == 20 and c["res"] == 800 and c["batch_size"] == 1024 and c["n_samples"] == 1024 and gold["replay"]
+    dev = torch.device(DEV)
+    o, d, rgbs, _, _ = rays.synthetic_scene(n_views=c["n_views"], res=c["res"], seed=c["scene_seed"], device=DEV)
+    ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=c["res"], seed=c["heldout_seed"], device=DEV)
+    grid0 = bench.bench_grid0(0.01 ** (1 / 16)).to(dev)
+    res = bench.psnr_replay(o, d, rgbs, dev, 65, grid0, ho, hd, hrgb)
+    assert res["reference"] == gold["runs"][0]["psnr"]["65"] and res["batch_sizes_equal_first_8"], res
+    assert abs(res["delta_db"]) < 0.1, res
+    assert abs(res["loss"] - res["reference_loss"]) <= 0.02 * res["reference_loss"], res

@@ -53,3 +53,19 @@ def test_independent_stream_golden_is_well_formed():
         assert len(run["loss"]) == g["steps"] and all(np.isfinite(run["loss"]))
         p = run["psnr"]
         assert 8.5 < p["0"] < 10.0 and p["300"] > p["0"] + 3.0                  # the recipe learns on this scene
+
+
+def test_headline_configuration_golden_is_well_formed():
+    """G21 (oracle/make_psnr_curve.py --bench): the replay run on bench.py's own configuration -- the step counts the bench ends on are
+    there, the recipe learns, and the batch rule lands on ~2^20 samples per step."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "G21_psnr_bench.json")))
+    mk = _maker()
+    assert g["replay"] and g["config"] == mk.BENCH_CONFIG and g["steps"] == 70 and g["eval_at"] == list(mk.BENCH_EVAL_AT)
+    run = g["runs"][0]
+    p = run["psnr"]
+    assert set(p) == {"0", "30", "65", "70"} and p["0"] < p["30"] < p["65"] < p["70"] and 19.0 < p["65"] < 21.0
+    assert len(run["loss"]) == 70 and all(np.isfinite(run["loss"])) and run["loss"][-1] < 0.25 * run["loss"][0]
+    assert all(0.95 * 2 ** 20 < n < 1.05 * 2 ** 20 for n in run["samples_per_step"])
+    # the initial grid of the golden is bench.py's: the same construction on both sides
+    grid = mk.bench_grid0(128)
+    assert grid.dtype == np.float32 and abs(float(grid.mean()) - (0.0654498 + (1 - 0.0654498) * 0.01 ** (20 / 16))) < 2e-3

@@ -490,7 +490,11 @@ int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float lr, float be
  * rgbs / weights become fresh leaves, param.grad stays None and torch.optim.Adam skips the parameter, run.py:258-260,
  * including its per-parameter step count).  `gate` is a device scalar (e.g. max_i w_i of the step): gate > 0 -> `step_dev[0]`
  * (device int32 counter of the updates these tensors have received) is incremented and the update of tn_adam_multi runs with
- * that count; gate <= 0 -> parameters, moments and counter are left untouched (gradients are still zeroed if asked). */
+ * that count; gate <= 0 -> parameters, moments and counter are left untouched (gradients are still zeroed if asked).
+ * zero_grad: bit 0 = zero the gradients; bit 1 (round 5) = `step_dev` has a SECOND int32, step_dev[1], which is set to 1 when an updated
+ * parameter is not finite (never cleared here).  The kernels' ReLU is v_max_f32: a NaN pre-activation becomes 0 where torch.relu
+ * (models.py:7-28) hands it on, so a diverged run would train on silently; the harness turns this flag -- and, for K-Planes planes, the
+ * regulariser sums of tn_adam_reg_multi, which any non-finite plane value poisons -- into the NaN loss the reference reports. */
 int tn_adam_multi_gated(const tn_adam_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int32_t *step_dev, const float *gate, int32_t zero_grad, void *stream);
 
@@ -504,7 +508,11 @@ typedef struct tn_adam_reg_item {
     float *param_out, *grad, *exp_avg, *exp_avg_sq;
     int64_t n;
     int32_t H, W, C, sum_slot;
-    float cy, cx, cl1, reserved;
+    float cy, cx, cl1;
+    /* Sharded optimizer pass (round 5, N > 1 with the recipe's batch split over the ranks): rows [row0, row1) of an [H,W,C] plane are this
+     * rank's -- only they are updated (their TV gradient still reads the neighbouring rows of `param`, which every rank holds), only their
+     * terms go into `sums`; outside them nothing but the gradient zeroing happens (4 B per element instead of 32).  row1 == 0: every row. */
+    int32_t row0, row1, reserved;
 } tn_adam_reg_item;
 int tn_adam_reg_multi(const tn_adam_reg_item *items, int32_t n_items, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, int32_t zero_grad, float upstream, double *sums, void *stream);

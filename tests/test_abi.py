@@ -50,15 +50,17 @@ def test_struct_layouts_match_c(tmp_path):
     from tinynerf_amd import _lib as L
     prog = tmp_path / "layout.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tinynerf_hip.h"\n'
-                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tn_sampler_desc), offsetof(tn_sampler_desc, t_table),'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tn_sampler_desc), offsetof(tn_sampler_desc, t_table),'
                     'offsetof(tn_sampler_desc, seed), sizeof(tn_mlp_desc), offsetof(tn_mlp_desc, weights),'
-                    'offsetof(tn_mlp_desc, biases), sizeof(tn_kplanes_desc), offsetof(tn_kplanes_desc, planes));return 0;}\n')
+                    'offsetof(tn_mlp_desc, biases), sizeof(tn_kplanes_desc), offsetof(tn_kplanes_desc, planes),'
+                    'sizeof(tn_adam_reg_item), offsetof(tn_adam_reg_item, cy), offsetof(tn_adam_reg_item, row0), sizeof(tn_adam_item));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(L.SamplerDesc), L.SamplerDesc.t_table.offset, L.SamplerDesc.seed.offset,
             ctypes.sizeof(L.MlpDesc), L.MlpDesc.weights.offset, L.MlpDesc.biases.offset,
-            ctypes.sizeof(L.KPlanesDesc), L.KPlanesDesc.planes.offset]
+            ctypes.sizeof(L.KPlanesDesc), L.KPlanesDesc.planes.offset,
+            ctypes.sizeof(L.AdamRegItem), L.AdamRegItem.cy.offset, L.AdamRegItem.row0.offset, ctypes.sizeof(L.AdamItem)]
     assert got == want
 
 

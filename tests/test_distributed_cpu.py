@@ -115,3 +115,47 @@ def test_gradient_exchange_equals_single_process(flat, world):
     for k, p in m.named_parameters():
         for rank in range(world):                                       # every rank holds the full-batch gradient
             torch.testing.assert_close(torch.from_numpy(res[rank][2][k]), p.grad.contiguous(), rtol=1e-5, atol=1e-7)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from tinynerf_amd.run import Trainer
+    torch.manual_seed(0)
+    p = torch.rand(1, 32, 64, 48).contiguous(memory_format=torch.channels_last)            # the same parameters on every rank
+    g = torch.rand(1, 32, 64, 48, generator=torch.Generator().manual_seed(50 + rank)).contiguous(memory_format=torch.channels_last)
+    total = g.clone()
+    torch.distributed.all_reduce(total)                                                    # the oracle: what an all-reduce would give
+    Trainer._reduce_scatter_rows(g, rank, world).wait()
+    r0, r1 = Trainer._own_rows(64, rank, world)
+    assert r1 - r0 == 64 // world
+    torch.testing.assert_close(g[:, :, r0:r1], total[:, :, r0:r1], rtol=1e-6, atol=1e-6)   # this rank's rows hold the sum over ranks
+    with torch.no_grad():                                                                  # "optimizer pass" on the rank's rows only
+        p[:, :, r0:r1] -= 0.1 * g[:, :, r0:r1]
+    for w in Trainer._all_gather_rows(p, rank, world):
+        w.wait()
+    q.put((rank, p.contiguous().numpy().copy(), total.contiguous().numpy().copy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_exchange_equals_all_reduce(world):
+    """TrainConfig.sharded_optimizer (round 5): reduce-scatter of a plane gradient into the rank's own rows -> update of those
+    rows -> all-gather of the updated rows, against all-reduce + the same update of every row on every rank: identical parameters on
+    all ranks (bit for bit between ranks), on the product's own Trainer methods (in place on the channels_last memory, no copies)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs: p.join(timeout=30)
+    assert all(p.exitcode == 0 for p in procs)
+    torch.manual_seed(0)
+    p0 = torch.rand(1, 32, 64, 48).contiguous(memory_format=torch.channels_last)
+    want = (p0 - 0.1 * torch.from_numpy(res[0][2])).contiguous().numpy()
+    for rank in range(world):
+        assert (res[rank][1] == res[0][1]).all()
+        torch.testing.assert_close(torch.from_numpy(res[rank][1]), torch.from_numpy(want), rtol=1e-6, atol=1e-6)

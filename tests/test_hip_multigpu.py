@@ -98,10 +98,11 @@ def _scene():
     return o.contiguous(), d.contiguous(), rgb.contiguous()
 
 
-def _cfg(method):
+def _cfg(method, sharded=False):
     from tinynerf_amd.run import TrainConfig
     return TrainConfig(method=method, scene_type="aabb", batch_size=256, n_samples=48, seed=4, occupancy_res=32, deterministic=True,
-                       kplanes_resolutions=(32, 64, 128))        # 128^2 x 32 >= 2^18 elements: its own early all-reduce
+                       kplanes_resolutions=(32, 64, 128),        # 128^2 x 32 >= 2^18 elements: its own early all-reduce
+                       sharded_optimizer=sharded)                # True: reduce-scatter -> Adam on the rank's rows -> all-gather
 
 
 N_STEPS = 3
@@ -144,7 +145,7 @@ def _smooth_adam(tr, smooth):
             g["eps"] = 1.0
 
 
-def _rank_main(rank, world, port, method, q, smooth=False):
+def _rank_main(rank, world, port, method, q, smooth=False, sharded=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from tinynerf_amd.run import Trainer
@@ -152,8 +153,9 @@ def _rank_main(rank, world, port, method, q, smooth=False):
     torch.cuda.set_device(dev)
     o, d, rgb = _scene()
     half = slice(rank, None, world)                                 # disjoint halves of the ray set
-    tr = Trainer(_cfg(method), o[half].to(dev), d[half].to(dev), rgb[half].to(dev), torch.ones(3, device=dev), dev, rank=rank,
+    tr = Trainer(_cfg(method, sharded), o[half].to(dev), d[half].to(dev), rgb[half].to(dev), torch.ones(3, device=dev), dev, rank=rank,
                  world_size=world)
+    assert tr._sharded == (sharded and method == "kplanes")
     _no_dropout(tr)
     _half_empty_grid(tr)
     _smooth_adam(tr, smooth)
@@ -171,24 +173,30 @@ def _rank_main(rank, world, port, method, q, smooth=False):
         cursor = tr._cursor
         st = tr.step()
         out.append(dict(cursor=cursor, n_rays=int(st["n_rays"]), n_samples=int(st["n_samples"]), loss=tr.loss_value(), grads=cap["g"],
-                        grid=tr.occupancy_grid.grid.cpu().numpy().copy(), pending=len(tr._early), early_calls=early_calls[0]))
+                        grid=tr.occupancy_grid.grid.cpu().numpy().copy(), pending=len(tr._early), early_calls=early_calls[0],
+                        params={k: p.detach().cpu().contiguous().numpy().copy() for k, p in tr.renderer.named_parameters()
+                                if sharded and (tr.train_step == 1 or p.numel() < (1 << 20))}))
     q.put((rank, out))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("method,world,smooth", [("kplanes", 2, False), ("cobafa", 2, False), ("kplanes", 4, True), ("cobafa", 2, True)])
-def test_ranks_equal_one_rank_on_the_union(method, world, smooth):
+@pytest.mark.parametrize("method,world,smooth,sharded", [("kplanes", 2, False, False), ("cobafa", 2, False, False), ("kplanes", 4, True, False),
+                                                         ("cobafa", 2, True, False), ("kplanes", 2, True, True), ("kplanes", 4, True, True)])
+def test_ranks_equal_one_rank_on_the_union(method, world, smooth, sharded):
     """`world` gloo ranks sharing this GPU run the real Trainer.step() on disjoint shares of a ray set; one rank on the union of
     their batches must give the same loss, reduced gradients and occupancy grids.  smooth=False: the reference's optimizer
     (later steps loose, see _smooth_adam); smooth=True: every step as tight as the first.  world = 4: the exchange code with
-    more than one peer (bucket + gate slot, coalesced live-row slices, rank-strided ray streams)."""
+    more than one peer (bucket + gate slot, coalesced live-row slices, rank-strided ray streams).  sharded (round 5): the plane
+    gradients travel as reduce-scatter, every rank runs Adam + TV on ITS rows of every plane and the updated rows are all-gathered --
+    a rank's reduced plane gradient is then only defined on its own rows, and what must agree with the one-rank run (and between the
+    ranks, bit for bit) are the PARAMETERS after the step."""
     from tinynerf_amd.run import Trainer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, method, q, smooth)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, method, q, smooth, sharded)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -225,6 +233,9 @@ def test_ranks_equal_one_rank_on_the_union(method, world, smooth):
             assert abs(r["loss"] - loss) <= tol * abs(loss), (step, rank, r["loss"], loss)
             for k, ref in cap["g"].items():
                 got = r["grads"][k]
+                if sharded and ".plane" in k:           # reduce-scatter: the rank holds the sum on ITS rows of the plane only
+                    r0, r1 = Trainer._own_rows(ref.shape[2], rank, world)
+                    got, ref = got[:, :, r0:r1], ref[:, :, r0:r1]
                 if ref.size >= (1 << 16):
                     # a grid voxel / plane texel sums thousands of atomics whose terms cancel (+-1e-3 summing to 1e-4): single
                     # elements carry 1e-4 of the largest element as order noise, and from the second step on Adam (eps 1e-15)
@@ -238,6 +249,13 @@ def test_ranks_equal_one_rank_on_the_union(method, world, smooth):
                     np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
             if step == 0:
                 assert np.array_equal(r["grid"], tr.occupancy_grid.grid.cpu().numpy())      # identical grids without communication
+            if sharded:
+                # parameters after the optimizer pass + all-gather: identical on every rank, and the one-rank run's up to the order noise of
+                # the gradients (Adam with eps = 1: Lipschitz) -- every row of every plane, i.e. also the rows other ranks updated
+                for k, pv in r["params"].items():
+                    assert np.array_equal(pv, res[0][step]["params"][k]), (k, step, rank)
+                    one = dict(tr.renderer.named_parameters())[k].detach().cpu().contiguous().numpy()
+                    assert float(np.linalg.norm((pv - one).astype(np.float64))) <= 2e-5 * float(np.linalg.norm(one.astype(np.float64))), (k, step)
         assert all(np.array_equal(res[0][step]["grid"], res[rank][step]["grid"]) for rank in range(1, world))
     assert not any(r["pending"] for rank in range(world) for r in res[rank])       # every early all-reduce was awaited
     if method == "kplanes":      # the fused node handed its plane gradients over mid-backward (CHAIN_ONLY -> scatter -> WGRAD_ONLY) every step

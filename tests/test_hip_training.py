@@ -484,3 +484,33 @@ def test_heads_read_the_stack_output_from_workspace_rows(method, monkeypatch):
     assert all(np.isfinite(losses[True])), losses
     np.testing.assert_allclose(losses[True][0], losses[False][0], rtol=1e-6)
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["plane", "colour_weight", "sigma_bias"])
+def test_a_non_finite_parameter_surfaces_as_the_reference_nan_loss(where):
+    """torch.relu hands a NaN on (models.py:7-28), so in the reference ONE non-finite parameter makes the loss NaN at the next step
+    (run.py:252-256: MSE + TV over every plane).  The kernels' ReLU is v_max_f32, which returns 0 for a NaN pre-activation: rendered
+    colours and the MSE stay finite.  Round-4 verdict: decide.  Decision (round 5): the optimizer pass raises a device flag when it
+    writes a non-finite parameter (tn_adam_multi_gated, zero_grad bit 1), a non-finite plane value poisons the regulariser sums of
+    tn_adam_reg_multi, and Trainer.loss_device() reports NaN from then on -- no host sync, nothing on the kernels' hot paths."""
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=256, n_samples=32, seed=1, occupancy_res=32, deterministic=True,
+                      kplanes_resolutions=(16, 32, 64))
+    tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+    for _ in range(2):
+        tr.step()
+        assert np.isfinite(tr.loss_value())
+    with torch.no_grad():
+        if where == "plane":
+            tr.renderer.feature_module.plane_tensors()[4][0, 5, 17, 9] = float("nan")
+        elif where == "colour_weight":
+            tr.renderer.rgb_decoder.net.net[2][0].weight[3, 5] = float("inf")
+        else:
+            tr.renderer.sigma_decoder.net.net[0].bias[7] = float("nan")
+    tr.step()
+    tr.step()                                    # (the reference: NaN at the step after the parameter went bad, and ever after)
+    assert np.isnan(tr.loss_value())
+    tr.step()
+    assert np.isnan(tr.loss_value())

@@ -83,7 +83,7 @@ class AdamItem(C.Structure):
 class AdamRegItem(C.Structure):
     _fields_ = [("param", C.c_void_p), ("param_out", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("sum_slot", C.c_int32),
-                ("cy", C.c_float), ("cx", C.c_float), ("cl1", C.c_float), ("reserved", C.c_float)]
+                ("cy", C.c_float), ("cx", C.c_float), ("cl1", C.c_float), ("row0", C.c_int32), ("row1", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CobafaDesc(C.Structure):

@@ -146,9 +146,10 @@ __global__ void adam_gate_kernel(int32_t *__restrict__ step, const float *__rest
 template <bool GATED>
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamItems items, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                          float bc2_sqrt, int zero_grad, const int32_t *__restrict__ step_dev,
-                                                         const float *__restrict__ gate)
+                                                         const float *__restrict__ gate, int32_t *__restrict__ nonfinite)
 {
     const tn_adam_item &t = items.it[blockIdx.y];
+    bool bad = false;            // an updated parameter that is not finite (see tn_adam_multi_gated: zero_grad bit 1)
     float *__restrict__ p = t.param; float *__restrict__ g = t.grad; float *__restrict__ m = t.exp_avg; float *__restrict__ v = t.exp_avg_sq;
     const int64_t n = t.n, n4 = (n + 3) / 4;
     if constexpr (GATED) {
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamItems items, float 
                 vv[c] = b2 * vv[c] + (1.0f - b2) * gg * gg;
                 const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
                 pv[c] = pv[c] - (lr / bc1) * (mv[c] / denom);
+                bad |= !(fabsf(pv[c]) <= 3.402823466e38f);
             }
             reinterpret_cast<f4 *>(p)[i] = pv; reinterpret_cast<f4 *>(m)[i] = mv; reinterpret_cast<f4 *>(v)[i] = vv;
             if (zero_grad) reinterpret_cast<f4 *>(g)[i] = f4{0.f, 0.f, 0.f, 0.f};
@@ -181,10 +183,12 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamItems items, float 
                 m[e] = m[e] + (gg - m[e]) * (1.0f - b1);
                 v[e] = b2 * v[e] + (1.0f - b2) * gg * gg;
                 p[e] = p[e] - (lr / bc1) * (m[e] / (sqrtf(v[e]) / bc2_sqrt + eps));
+                bad |= !(fabsf(p[e]) <= 3.402823466e38f);
                 if (zero_grad) g[e] = 0.0f;
             }
         }
     }
+    if (nonfinite != nullptr && bad) nonfinite[0] = 1;          // (plain stores of one value: no atomic needed)
 }
 
 // Adam with the K-Planes regulariser folded in (harness): for plane tensors the total-variation / L1 gradient is built
@@ -203,7 +207,13 @@ __global__ __launch_bounds__(256) void adam_reg_multi_kernel(AdamRegItems items,
     const int W = t.W, H = t.H, C4 = t.C >> 2;
     const float cy2 = 2.0f * t.cy, cx2 = 2.0f * t.cx;
     float sy = 0.f, sx = 0.f, sl = 0.f;
+    // sharded pass: this rank's rows of the plane as a range of float4 indices (everything, unless row1 > 0)
+    const int64_t own0 = (reg && t.row1 > 0) ? (int64_t)t.row0 * W * C4 : 0, own1 = (reg && t.row1 > 0) ? (int64_t)t.row1 * W * C4 : n4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < own0 || i >= own1) {                            // another rank's rows: only the gradient buffer is cleared
+            if (zero_grad) reinterpret_cast<f4 *>(g)[i] = f4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         if (4 * i + 3 < n) {
             const f4 *q = reinterpret_cast<const f4 *>(p);
             f4 pv = q[i], gv = reinterpret_cast<f4 *>(g)[i];
@@ -341,7 +351,7 @@ extern "C" int tn_adam_multi(const tn_adam_item *items, int32_t n_items, float l
         }
         if (largest == 0) continue;
         adam_multi_kernel<false><<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
-            pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad, nullptr, nullptr);
+            pack, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, zero_grad, nullptr, nullptr, nullptr);
         if (int rc = tn::check_launch("adam_multi_kernel")) return rc;
     }
     return TN_OK;
@@ -369,7 +379,7 @@ extern "C" int tn_adam_multi_gated(const tn_adam_item *items, int32_t n_items, f
         }
         if (largest == 0) continue;
         adam_multi_kernel<true><<<dim3(std::min<unsigned>(blocks_for(largest), 1024), (unsigned)cnt), dim3(256), 0, (hipStream_t)stream>>>(
-            pack, lr, beta1, beta2, eps, weight_decay, 1.0f, 1.0f, zero_grad, step_dev, gate);
+            pack, lr, beta1, beta2, eps, weight_decay, 1.0f, 1.0f, zero_grad & 1, step_dev, gate, (zero_grad & 2) ? step_dev + 1 : nullptr);
         if (int rc = tn::check_launch("adam_multi_kernel<gated>")) return rc;
     }
     return TN_OK;

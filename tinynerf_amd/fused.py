@@ -110,7 +110,9 @@ def _upstream_is_gated(ctx: Any) -> bool:
 
 
 INFER_PAIR = os.environ.get("TN_INFER_PAIR", "1") != "0"       # (0: always the gated inference form -- A/B, debugging)
-INFER_PAIR_MIN_LIVE = 0.6
+INFER_PAIR_MIN_LIVE = 0.6       # the pair form is taken at >= this live fraction ...
+INFER_PAIR_HYSTERESIS = 0.15    # ... and kept until the fraction falls below MIN_LIVE - HYSTERESIS (chunks of an image alternate between background
+                                # and object: without the band the form -- not the result -- would flip from chunk to chunk)
 
 
 def _infer_prefers_pair(stats: Optional[dict]) -> bool:
@@ -124,7 +126,12 @@ def _infer_prefers_pair(stats: Optional[dict]) -> bool:
     for slot in st["slots"]:
         if slot["seq"] > st["seen"] and slot["event"].query():
             st["seen"], st["value"] = slot["seq"], float(slot["pinned"][0])
-    return st["value"] is not None and st["value"] >= INFER_PAIR_MIN_LIVE
+    if st["value"] is None:
+        return False
+    on = st.get("pair_on", False)
+    on = st["value"] >= (INFER_PAIR_MIN_LIVE - INFER_PAIR_HYSTERESIS if on else INFER_PAIR_MIN_LIVE)
+    st["pair_on"] = on
+    return on
 
 
 def _note_live_fraction(stats: dict, weights: torch.Tensor) -> None:
@@ -140,7 +147,8 @@ def _note_live_fraction(stats: dict, weights: torch.Tensor) -> None:
                 st["seen"], st["value"] = slot["seq"], float(slot["pinned"][0])
             st["seq"] += 1
             slot["seq"] = st["seq"]
-            slot["pinned"].copy_((weights > 0).float().mean().reshape(1), non_blocking=True)
+            # (one reduction launch + one 4-byte copy; the count is divided on the host side of the pinned slot)
+            slot["pinned"].copy_((torch.count_nonzero(weights) / float(weights.numel())).reshape(1).float(), non_blocking=True)
             slot["event"].record(torch.cuda.current_stream(weights.device))
             return
     # every slot still in flight: skip this measurement
@@ -567,11 +575,20 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
     # harness: the stack whose row view this node matched last time may leave its output as rows only (TN_MLP_ROWS_ONLY) -- armed for
     # exactly this forward; _RenderHeads fails loudly if it then cannot read the rows
     producer = renderer.__dict__.get("_rows_producer")
+    armed = None
     if producer is not None and arena is not None and torch.is_grad_enabled() and MATMUL_F16X2():
         sc = producer.__dict__.get("scratch")
         if sc is not None and len(sc) > 4:
             sc[4]["rows_only"] = True
-    feat = fm(packed[:, :3])
+            armed = sc[4]
+    try:
+        feat = fm(packed[:, :3])
+    finally:
+        # the flag is for exactly THIS forward: if the producer stack did not run (an exception, a feature module that skipped it) it must
+        # not stay armed for an unrelated forward, whose row-major output would then silently stay unwritten
+        if armed is not None and armed.pop("rows_only", False):
+            import warnings
+            warnings.warn("tinynerf_amd.fused: TN_MLP_ROWS_ONLY was armed but the feature stack did not consume it; disarmed", RuntimeWarning)
     train = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in (*sig_p, *rgb_p)))
     link = None
     if train and arena is not None:          # harness: the stack that produced `feat` may offer row views of its workspace

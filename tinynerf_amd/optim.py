@@ -27,7 +27,8 @@ class FusedAdam(torch.optim.Optimizer):
         advances -- when it is > 0 (tn_adam_multi_gated).  This is what torch.optim.Adam does with the ``grad is None`` parameters
         of the reference's "Empty iteration" (core.py:251-254), decided on the device instead of by a host read-back.
 
-        ``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None) folds
+        ``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None[, rows={id(plane):
+        (row0, row1)}: the sharded pass of N > 1 -- only these rows are updated and summed, the caller all-gathers them]) folds
         the K-Planes regulariser's gradient (and its sums) into the update of those planes (tn_adam_reg_multi): the planes are
         streamed once per step.  Their new values are written to a second buffer which then becomes ``plane.data``."""
         loss = closure() if closure is not None else None
@@ -71,10 +72,11 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         if self._gated_count.get(dev) is None:      # device-side count of the updates that were not gated away
                             first = min(self.state[p]["step"] for p, _, _, _ in tensors) - 1
-                            self._gated_count[dev] = torch.full((1,), first, dtype=torch.int32, device=dev)
+                            # [0]: the count; [1]: raised by the kernel when an updated parameter is not finite (nonfinite_flag)
+                            self._gated_count[dev] = torch.tensor([first, 0], dtype=torch.int32, device=dev)
                         self._gated_params[dev] = [p for p, _, _, _ in tensors]
                         L.call("tn_adam_multi_gated", dev, items, C.c_int32(len(tensors)), *common[:5], L.ptr(self._gated_count[dev]),
-                               L.ptr(gate), common[6])
+                               L.ptr(gate), C.c_int32(common[6].value | 2))
                     continue
                 items = (L.AdamRegItem * len(tensors))()
                 for it, (p, g, m, v) in zip(items, tensors):
@@ -87,6 +89,7 @@ class FusedAdam(torch.optim.Optimizer):
                     it.param, it.param_out, it.grad = p.data_ptr(), st["shadow"].data_ptr(), g.data_ptr()
                     it.exp_avg, it.exp_avg_sq, it.n = m.data_ptr(), v.data_ptr(), p.numel()
                     it.H, it.W, it.C, it.sum_slot, it.cy, it.cx, it.cl1 = H, W, Cc, slot, cy, cx, cl
+                    it.row0, it.row1 = (plane_reg.get("rows") or {}).get(id(p), (0, 0))       # sharded pass: this rank's rows only
                 sums = plane_reg.get("sums")
                 L.call("tn_adam_reg_multi", dev, items, C.c_int32(len(tensors)), *common, C.c_float(plane_reg["upstream"]), L.ptr(sums))
                 for p, _, _, _ in tensors:                   # the updated values live in the second buffer: swap
@@ -103,10 +106,17 @@ class FusedAdam(torch.optim.Optimizer):
         for dev, cnt in self._gated_count.items():
             if cnt is None:
                 continue
-            c = int(cnt.item())
+            c = int(cnt[0].item())
             for p in self._gated_params.get(dev, []):
                 if p in self.state:
                     self.state[p]["step"] = c
+
+    def nonfinite_flag(self, device) -> "torch.Tensor | None":
+        """int32 [1] on `device`: 1 once the gated update has written a non-finite parameter (None before the first gated step).  The
+        reference's loss is NaN from that step on (torch.relu hands a NaN on, models.py:7-28; the kernels' v_max_f32 does not):
+        run.Trainer.loss_device() folds the flag into the loss it reports."""
+        cnt = self._gated_count.get(device)
+        return None if cnt is None else cnt[1:2]
 
     def state_dict(self):
         self.sync_step_counts()

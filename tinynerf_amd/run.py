@@ -57,6 +57,12 @@ class TrainConfig:
     # a stream that any machine can regenerate (the CPU checker's replay mode walks the same rays) at the
     # price of one host permutation + upload per epoch (fine for parity runs, not for the 12.8 M-ray tables of the bench)
     host_shuffle: bool = False
+    # N > 1: how the plane gradients travel.  False: in-place all-reduce of the live rows, every rank runs Adam + TV on all 33 M plane
+    # elements.  True (round 5): reduce-scatter -> Adam + TV on the rank's own 1 / N of every plane's rows -> all-gather of the updated
+    # rows: half the bytes of an all-reduce on the wire before the optimizer and 1 / N of its 0.22 ms; the all-gather moves every row
+    # (weight decay and the regulariser change dead rows too).  None: on when the recipe's batch is split over >= 4 ranks (shard >= 4:
+    # DESIGN 5.1 -- below ~1.1 ms of compute per step the replicated optimizer pass is what limits strong scaling).
+    sharded_optimizer: Optional[bool] = None
 
 
 def jitter_seed(seed: int, batch_no: int, rank: int = 0) -> int:
@@ -167,6 +173,10 @@ class Trainer:
         self._reduce_rows_prev: Optional[List[Tuple[int, int]]] = None
         if world_size > 1 and isinstance(self.renderer.feature_module, KPlanesFeatureField):
             self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
+        want = cfg.sharded_optimizer if cfg.sharded_optimizer is not None else cfg.shard >= 4
+        self._sharded = bool(want and world_size > 1 and self._plane_of and
+                             all(p.size(2) % world_size == 0 for p in self.renderer.feature_module.plane_tensors()))
+        self._gathers: List[object] = []
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
         self._side: Optional[torch.cuda.Stream] = None
@@ -418,12 +428,20 @@ class Trainer:
             # the gradient exchange, with its full weight (grad_scale: the loss is scaled and never unscaled)
             spec, reg_coef = self.renderer.feature_module.regulariser_spec(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
             plane_reg = {"spec": spec, "upstream": cfg.grad_scale, "sums": acc[1:]}
+            if self._sharded:                # this rank's rows of every plane: the only ones its optimizer pass touches
+                plane_reg["rows"] = {id(p): Trainer._own_rows(p.size(2), self.rank, self.world) for p in self.renderer.feature_module.plane_tensors()}
         self._loss_parts = (acc, inv, inv_dev, reg_coef)
         if self.world > 1:
             self.all_reduce_grads(gate)
         if self.grad_hook is not None:
             self.grad_hook(self)
         self.optimizer.step(plane_reg=plane_reg, gate=gate)
+        if self._sharded:                    # the updated rows of every rank to every rank (all of them: weight decay and TV move dead rows too)
+            works = []
+            for p in self.renderer.feature_module.plane_tensors():
+                works += Trainer._all_gather_rows(p.data, self.rank, self.world)
+            for w in works:
+                w.wait()
         self.scheduler.step()
         self.train_step += 1
         self.last = {"n_samples": float(packed.size(0)), "n_rays": float(info.size(0)), "k": float(k)}
@@ -453,11 +471,16 @@ class Trainer:
         from the accumulators the step left behind (valid until the next step); no host sync."""
         acc, inv, inv_dev, reg_coef = self._loss_parts
         v = acc[0] * inv * (inv_dev[0].double() if inv_dev is not None else 1.0)
-        if reg_coef is not None:
-            v = v + (acc[1:1 + reg_coef.numel()] * reg_coef.reshape(-1)).sum() / self.world
+        if reg_coef is not None:                  # (every rank holds the full sums -- or, sharded optimizer pass, its rows' share of them)
+            v = v + (acc[1:1 + reg_coef.numel()] * reg_coef.reshape(-1)).sum() / (1 if getattr(self, "_sharded", False) else self.world)
         v = v.float().reshape(1).clone()
         if self.world > 1:
             torch.distributed.all_reduce(v)
+        # a parameter that is not finite: the reference's next forward reports NaN (torch.relu hands NaN on, models.py:7-28) where the
+        # kernels' v_max_f32 ReLU swallows it -- the optimizer pass raises a flag (planes: their regulariser sums above are NaN already)
+        bad = self.optimizer.nonfinite_flag(self.device) if hasattr(self.optimizer, "nonfinite_flag") else None
+        if bad is not None:
+            v = torch.where(bad != 0, torch.full_like(v, float("nan")), v)
         return v
 
     def loss_value(self) -> float:
@@ -521,8 +544,9 @@ class Trainer:
 
     @staticmethod
     def _all_reduce_many(views):
-        """In-place all-reduce of several dense tensors as ONE collective call (the backend's coalesced all-reduce: one grouped
-        RCCL launch instead of one launch -- and 5-20 us of host time beside an idle GPU -- per tensor); returns a waitable."""
+        """In-place all-reduce of several dense tensors as ONE collective call where the backend has one (RCCL: one grouped launch
+        instead of one launch -- and 5-20 us of host time beside an idle GPU -- per tensor); returns a waitable.  Public API only:
+        torch.distributed.all_reduce_coalesced (round 4 used the private _coalescing_manager)."""
         views = [v for v in views if v.numel()]
         if not views:
             return None
@@ -536,14 +560,43 @@ class Trainer:
                     for w in works:
                         w.wait()
             return _All()
-        with torch.distributed._coalescing_manager(async_ops=True) as cm:
-            for v in views:
-                torch.distributed.all_reduce(v)
-        return cm
+        import warnings
+        with warnings.catch_warnings():                     # (the call is public; torch announces a future replacement on every use)
+            warnings.simplefilter("ignore")
+            return torch.distributed.all_reduce_coalesced(views, async_op=True)
+
+    # ---- sharded optimizer pass (TrainConfig.sharded_optimizer): rank r owns rows [r H / N, (r + 1) H / N) of every plane ----
+    @staticmethod
+    def _own_rows(H: int, rank: int, world: int) -> Tuple[int, int]:
+        return H * rank // world, H * (rank + 1) // world
+
+    @staticmethod
+    def _reduce_scatter_rows(g: torch.Tensor, rank: int, world: int):
+        """sum of all ranks' gradient `g` (a dense channels_last plane gradient, H % world == 0) into THIS rank's rows of its own
+        buffer, in place; the other rows keep partial sums nobody reads (the optimizer pass clears them).  Returns a waitable."""
+        flat = Trainer._dense_view(g).view(-1)
+        chunk = flat.numel() // world
+        own = flat[rank * chunk:(rank + 1) * chunk]
+        if torch.distributed.get_backend() == "nccl" or not flat.is_cuda:
+            return torch.distributed.reduce_scatter_tensor(own, flat, async_op=True)
+        return torch.distributed.all_reduce(flat, async_op=True)      # (gloo on GPU tensors -- the shared-GPU tests: same sums in the rank's rows)
+
+    @staticmethod
+    def _all_gather_rows(p: torch.Tensor, rank: int, world: int):
+        """every rank's own rows of `p` (updated by its optimizer pass) to every rank, in place; returns waitables"""
+        flat = Trainer._dense_view(p).view(-1)
+        chunk = flat.numel() // world
+        if torch.distributed.get_backend() == "nccl" or not flat.is_cuda:
+            return [torch.distributed.all_gather_into_tensor(flat, flat[rank * chunk:(rank + 1) * chunk], async_op=True)]
+        return [torch.distributed.broadcast(flat[r * chunk:(r + 1) * chunk], src=r, async_op=True) for r in range(world)]
 
     def _planes_ready(self, grads) -> None:
         """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are
         final: their all-reduce starts here and travels while the heads' weight gradients are still being computed."""
+        if getattr(self, "_sharded", False):
+            for g in grads:
+                self._early[g.data_ptr()] = Trainer._reduce_scatter_rows(g, self.rank, self.world)
+            return
         views, ptrs = [], []
         for i, g in enumerate(grads):
             flat = self._reduce_view(g, i if self._plane_of else None)
@@ -580,6 +633,9 @@ class Trainer:
             if p.grad is None or id(p) in self._flat_ids:
                 continue
             if p.grad.data_ptr() in early:
+                continue
+            if getattr(self, "_sharded", False) and id(p) in self._plane_of:
+                handles.append(Trainer._reduce_scatter_rows(p.grad, self.rank, self.world))      # (not started mid-backward: here)
                 continue
             flat = self._reduce_view(p.grad, self._plane_of.get(id(p)))
             if flat is not None:                 # large and dense in memory: reduced in place (live rows only)

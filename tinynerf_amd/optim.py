@@ -115,8 +115,10 @@ class FusedAdam(torch.optim.Optimizer):
         """int32 [1] on `device`: 1 once the gated update has written a non-finite parameter (None before the first gated step).  The
         reference's loss is NaN from that step on (torch.relu hands a NaN on, models.py:7-28; the kernels' v_max_f32 does not):
         run.Trainer.loss_device() folds the flag into the loss it reports."""
-        cnt = self._gated_count.get(device)
-        return None if cnt is None else cnt[1:2]
+        for dev, cnt in self._gated_count.items():            # ("cuda" and "cuda:0" are different dictionary keys)
+            if cnt is not None and dev.type == torch.device(device).type and (torch.device(device).index in (None, dev.index)):
+                return cnt[1:2]
+        return None
 
     def state_dict(self):
         self.sync_step_counts()

@@ -150,6 +150,10 @@ struct RcArgs {
 // pass serialises them completely -- vmcnt(0) in front of every request and of every ds_read behind one: 0.64 ms against 0.54 --, through
 // inline assembly the requests overlap, but the 16 address registers per stage brought 19 spills back, and a scratch reload drains the
 // queue like any other vmcnt(0).  The register form below (two sets in turn, requested a stage + a layer ahead) has none.
+// Also measured, not kept: the weight gradients dealt out by layer to FOUR launches with at most four accumulator tiles per wave (256
+// registers, two waves per SIMD, no spills; each role re-evaluates the part of the chain it needs: 564 MFMAs per tile instead of 420):
+// 0.21 + 0.25 + 0.26 + 0.29 = 1.00 ms against this kernel's 0.54 -- what a role saves in matrix work it pays several times over in the
+// per-tile work every role repeats (feature rows, table rows, their conversion, the first layer).
 template <int WPB, bool AUX, int OA, int OB, int NGA, int NBA>
 __device__ __forceinline__ void wgrad_rc_body(const RcArgs &p, const float *__restrict__ ldsa, const float *__restrict__ ldsb, float *__restrict__ /*unused*/,
                                               const float *__restrict__ px, const float *__restrict__ paux, const int *__restrict__ paidx,

@@ -10,5 +10,5 @@ import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
     for r in rows[:int(__import__("os").environ.get("KS_TOP", "12"))]:
-        print("%9.3f ms %5s calls %9.1f us avg  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "")[:100]))
+        print("%9.3f ms %5s calls %9.1f us avg %9.1f min  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "")[:100]))
 PY

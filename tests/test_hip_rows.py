@@ -99,11 +99,13 @@ def test_rows_view_reports_only_layer_kernel_stacks():
     desc = m._mlp_desc(fm.net.params(), 3, L.ENC_POSENC, 10, L.ACT_NONE, fm.encoding.freqs)
     y, g, st = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     assert L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) == 0
-    rows_h, rows_e, rows_m = 9 * 256, 64, 2 * 8 * 9          # hidden activations, encoded inputs, ReLU bit rows (2 per block and activation)
-    assert y.value == (rows_h + rows_e) * 32 and g.value == y.value + 256 * 32 and st.value == (rows_h + rows_e + 512 + rows_m) * 32
+    # slab layout (round 5): every row set contiguous over the 32 tiles -- slabs of 32 x 256 rows: 9 hidden activations, buffer A (= y),
+    # buffer B (= d loss / d y), and one slab shared by the 64 encoded-input rows and the 9 x 16 ReLU bit rows; a tile of a slab = 256 rows
+    slab = 32 * 256 * 32
+    assert y.value == 9 * slab and g.value == 10 * slab and st.value == 256 * 32
     fn = L.lib().tn_mlp_bwd_workspace_bytes
     fn.restype = C.c_int64
-    assert fn(C.byref(desc), C.c_int64(1000)) == 32 * st.value * 4 + 256     # (+ the tail: per-layer maxima for the f16x2 weight gradient)
+    assert fn(C.byref(desc), C.c_int64(1000)) == 12 * slab * 4 + 256     # (+ the tail: per-layer maxima for the f16x2 weight gradient)
     od = m.VanillaOpacityDecoder(256).to(DEV)                         # a width-64 head has no row views
     d2 = m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
     assert L.lib().tn_mlp_rows_view(C.byref(d2), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) != 0

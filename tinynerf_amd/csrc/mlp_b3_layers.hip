@@ -450,8 +450,7 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int row = (threadIdx.x + TH * c) >> 2;
-        src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
-        if (TN_B3_ABLATE & 64) src_off[c] = a.off_g * 32 + (threadIdx.x + TH * c) * 4;      // (timing experiment: contiguous)
+        src_off[c] = (row < H ? row : row - H) * 32 + 4 * qd;          // relative to the tile's G rows (c < NCH / 2) / A rows
         dst_off[c] = row * RS + 4 * qd;
     }
     float dbacc[NCH / 2];
@@ -459,10 +458,12 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
     for (int c = 0; c < NCH / 2; ++c) dbacc[c] = 0.0f;
     const int64_t n_half = 2 * n_tiles;                           // half tile t: tile t / 2, samples 16 (t & 1) .. + 15
     const int64_t stride = gridDim.x;                             // tiles are dealt round-robin to the workgroups
+    struct Bases { const global_char *g, *a; };                   // wave-uniform: the half tile's G rows and A rows
     auto half_src = [&](int64_t it) {                             // `it`-th half tile of this workgroup
         int64_t tile = blockIdx.x + (it >> 1) * stride;
         tile = tile < n_tiles ? tile : n_tiles - 1;
-        return stash + tile * (int64_t)a.rows_total * 32 + 16 * (it & 1);
+        return Bases{wave_uniform_global(stash + (tile * a.rows_total + a.off_g) * 32 + 16 * (it & 1)),
+                     wave_uniform_global(stash + (tile * a.rows_total + a.off_a) * 32 + 16 * (it & 1))};
     };
     const int64_t my_tiles = (int64_t)blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + stride - 1) / stride : 0;
     const int64_t iters = 2 * my_tiles;
@@ -478,10 +479,10 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
     unsigned src_boff[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) src_boff[c] = (unsigned)src_off[c] * 4u;
-    auto load_chunk = [&](const global_char *base, int c) {
+    auto load_chunk = [&](const Bases &base, int c) {
         unsigned off = src_boff[c];
         asm volatile("" : "+v"(off));                          // (keeps the zero-extension at the access: SGPR-base form)
-        st[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(base + off);
+        st[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>((c < NCH / 2 ? base.g : base.a) + off);
     };
     auto convert_chunk = [&](int c, unsigned short *buf) {
         unsigned h0, m0, l0, h1, m1, l1;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
     // behind every MFMA.
     unsigned cu[8];          // conversion state carried between micro-steps
     float cf[4];
-    auto micro = [&](int c, int m, unsigned short *buf, const global_char *nb) {
+    auto micro = [&](int c, int m, unsigned short *buf, const Bases &nb) {
         const unsigned MSK = 0xffff0000u;
         const int e = m >= 5 ? 2 : 0;                        // value pair (e, e + 1) of the chunk
         const int mm = m >= 5 ? m - 5 : m;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
     };
     // prologue: half tile 0 converted, half tile 1 in registers
     {
-        const global_char *b0 = wave_uniform_global(half_src(0)), *b1 = wave_uniform_global(half_src(1));
+        const Bases b0 = half_src(0), b1 = half_src(1);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) load_chunk(b0, c);
 #pragma unroll
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_b3_k
         constexpr bool CONVERT = decltype(convert_tag)::value;
         const unsigned short *bc = lds + cur * BUF;
         unsigned short *bnx = lds + (cur ^ 1) * BUF;
-        const global_char *nb = wave_uniform_global(half_src(it + 2 < iters ? it + 2 : it));     // (clamped: loaded, never used)
+        const Bases nb = half_src(it + 2 < iters ? it + 2 : it);     // (clamped: loaded, never used)
         Op gop[BN];
 #pragma unroll
         for (int bn = 0; bn < BN; ++bn) gop[bn] = read_op(bc, g_off[bn]);

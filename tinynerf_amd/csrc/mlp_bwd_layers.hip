@@ -37,7 +37,7 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
 // behind the last tile of a training workspace: the largest |value| of every layer's input rows ([0, 16): activations, reported
 // by the f16x2 forward of layer l; [16, 32): gradients, by its data gradient) -- the scales of the f16x2 weight gradient
 constexpr int64_t WS_TAIL_BYTES = 256;
-__host__ inline float *ws_tail(float *stash, int64_t n, int rows_total) { return stash + ((n + 31) / 32) * (int64_t)rows_total * 32; }
+__host__ inline float *ws_tail(float *stash, int64_t total_rows) { return stash + total_rows * 32; }
 
 __host__ __device__ inline bool plain_x_rows(int H, int n_layers, int enc, int K0_pad, int out_dim) {
     return enc == TN_ENC_NONE && K0_pad <= 64 && H >= 128 && n_layers >= 3 && out_dim > 4 && out_dim <= H;     // (= layer_kernel_path)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_stash_kernel(MlpArgs a, const fl
 
 // buffer A: pre-activation rows (written by the FWD_ONLY forward) -> output gradient  g = gy * act'(pre)
 __global__ __launch_bounds__(256) void out_grad_kernel(const float *__restrict__ gy, int64_t n, int out, int out_act, int rows_total,
-                                                       int off_g, float *__restrict__ stash)
+                                                       int64_t off_g, float *__restrict__ stash)
 {
     // [32 samples][out] block of gy -> [out][32 samples] rows through LDS: both sides of the transposition are coalesced
     // (16-byte loads along a sample's row when `out` allows it, no integer division in the index arithmetic)
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WPB * 64) void dgrad_lds_kernel(DgradArgs a, int64_
 // positional-encoding inputs of a tile as workspace rows [slot][32 samples] (the E rows of the layout)
 // (slots: rows written -- K0_pad for the encodings, 64 for plain inputs: slots past the input width are zero rows)
 __global__ __launch_bounds__(256) void enc_rows_kernel(MlpArgs a, const float *__restrict__ x, int64_t n, float *__restrict__ stash,
-                                                       int rows_total, int off_e, int slots)
+                                                       int rows_total, int64_t off_e, int slots)
 {
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n + 31) >> 5;
@@ -872,14 +872,13 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradArgs a, int64_t n, 
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         const int row = 8 * (wave * NI + e) + (lane >> 3);
-        const int src_row = row < H ? a.off_g + row : a.off_a + row - H;
-        src_off[e] = src_row * 32 + 4 * ((lane & 7) ^ ((row >> 1) & 7));
+        src_off[e] = (row < H ? row : row - H) * 32 + 4 * ((lane & 7) ^ ((row >> 1) & 7));       // relative to the G rows / the A rows of the tile
     }
     auto fetch = [&](int64_t tile, float *buf) {
-        const float *st = stash + tile * (int64_t)a.rows_total * 32;
+        const float *stg = urow(stash, tile * a.rows_total + a.off_g), *sta = urow(stash, tile * a.rows_total + a.off_a);
 #pragma unroll
         for (int e = 0; e < NI; ++e)
-            glds16(st + src_off[e], buf + 256 * (wave * NI + e));
+            glds16((8 * (wave * NI + e) < H ? stg : sta) + src_off[e], buf + 256 * (wave * NI + e));      // (wave-uniform choice: 8 rows per request)
     };
     // operand chunk e (samples 16 h + 4 e .. + 3) of row r: slot (4 h + e) ^ ((r >> 1) & 7)
     int g_off[BN], a_off[BK];
@@ -1064,6 +1063,63 @@ __host__ inline bool layer_kernel_path(int H, int L, int out) { return H >= 128 
 // Vanilla stack against 11.5 KB of training workspace).
 __host__ inline int infer_rows_total(int H, const Layout &lay) { return 2 * H + lay.rowsE; }
 
+// Where the row sets of a training workspace live; every kernel addresses  row = tile * rows_total + off.
+//   * tile-major (make_layout; what the general-shape kernels compute for themselves): a tile holds all its row sets back to back,
+//     rows_total = lay.total, off = the set's offset inside the tile.
+//   * slab (round 5; the layer-kernel path whose first layer takes row operands, i.e. every launch gets its offsets as arguments):
+//     every row set is contiguous over the tiles -- slab s = rows [s n_tiles H, (s + 1) n_tiles H), tile t of it at t H -- so
+//     rows_total = H and off = s n_tiles H (+ the set's place inside a shared slab: the E rows and the bit rows are packed together).
+//     A launch then streams two or three dense arrays instead of 32 KB pieces 300 - 400 KB apart: the same copy of 1 KB + 1 KB per
+//     sample runs at 5.5 TB/s (6.0 with nt hints) instead of 4.98 (scripts/microbench/row_copy.hip) -- the layer kernels sat AT
+//     that 4.98.
+struct RowMap {
+    bool slab;
+    int rows_total, H, L;
+    int64_t sl;                                  // rows per slab
+    Layout lay;
+    int64_t e_off, m_off[TN_MLP_MAX_LAYERS];
+    int n_slabs;
+    int64_t offH(int l) const { return slab ? l * sl : (int64_t)l * H; }                 // activation l (output of layer l), l < L - 1
+    int64_t offE() const { return slab ? e_off : lay.rowsH; }
+    int64_t offGA() const { return slab ? (L - 1) * sl : lay.rowsH + lay.rowsE; }
+    int64_t offGB() const { return slab ? L * sl : lay.rowsH + lay.rowsE + lay.rowsG; }
+    int64_t offM(int l) const { return slab ? m_off[l] : lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * l; }   // bit rows of activation l
+    int64_t total_rows(int64_t n_tiles) const { return slab ? n_slabs * sl : n_tiles * lay.total; }
+};
+__host__ inline bool slab_eligible(int H, int L, int enc, int in_dim, int K0_pad, int out) {
+    if (!(H == 128 || H == 256) || !layer_kernel_path(H, L, out) || L > TN_MLP_MAX_LAYERS) return false;
+    const Layout lay = make_layout(H, L, enc, in_dim, K0_pad, out);
+    const bool plain = plain_x_rows(H, L, enc, K0_pad, out) && lay.rowsE == 64;
+    return ((enc == TN_ENC_POSENC && K0_pad <= 64) || plain) && lay.rowsG == H && lay.rowsE <= H;
+}
+__host__ inline RowMap make_rowmap(int H, int L, int enc, int in_dim, int K0_pad, int out, int64_t n_tiles, bool slab) {
+    RowMap m;
+    m.lay = make_layout(H, L, enc, in_dim, K0_pad, out);
+    m.slab = slab; m.H = H; m.L = L; m.sl = n_tiles * H;
+    m.rows_total = slab ? H : m.lay.total;
+    m.e_off = 0; m.n_slabs = 0;
+    for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) m.m_off[l] = 0;
+    if (slab) {
+        int64_t sidx = L + 1;                      // slabs 0 .. L - 2: activations, L - 1 / L: buffers A / B
+        int within = 0;
+        m.e_off = sidx * m.sl; within = m.lay.rowsE;
+        const int mr = 2 * (H / 32);
+        for (int l = 0; l + 1 < L; ++l) {
+            if (within + mr > H) { ++sidx; within = 0; }
+            m.m_off[l] = sidx * m.sl + within;
+            within += mr;
+        }
+        m.n_slabs = (int)sidx + 1;
+    }
+    return m;
+}
+// rows of a training workspace (without its tail): room for either layout (a backward pass without a stashed forward runs tile-major)
+__host__ inline int64_t ws_rows(int H, int L, int enc, int in_dim, int K0_pad, int out, int64_t n_tiles) {
+    const int64_t tm = make_rowmap(H, L, enc, in_dim, K0_pad, out, n_tiles, false).total_rows(n_tiles);
+    if (!slab_eligible(H, L, enc, in_dim, K0_pad, out)) return tm;
+    return std::max(tm, make_rowmap(H, L, enc, in_dim, K0_pad, out, n_tiles, true).total_rows(n_tiles));
+}
+
 template <int H>
 int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, float *y, float *stash, hipStream_t s, bool inference = false)
 {
@@ -1073,14 +1129,14 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
     if constexpr (H >= 128) {
         const int L = a.n_layers, out = a.out_dim;
         if (layer_kernel_path(H, L, out)) {       // first layer, then one launch per layer with W in LDS
-            const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, out);
-            const int total = inference ? infer_rows_total(H, lay) : lay.total;
-            const int offE = inference ? 2 * H : lay.rowsH;
-            auto off_in = [&](int l) { return inference ? ((l - 1) & 1) * H : (l - 1) * H; };
-            auto off_out = [&](int l) { return inference ? (l & 1) * H : (l + 1 < L ? l * H : lay.rowsH + lay.rowsE); };
-            const int offM = lay.rowsH + lay.rowsE + 2 * lay.rowsG;
-            auto off_bits = [&](int l) { return (inference || l + 1 >= L) ? -1 : offM + 2 * (H / 32) * l; };      // activation l = output of layer l
-            float *tail = (a.f2 && !inference && L <= 16) ? ws_tail(stash, n, lay.total) : nullptr;
+            const RowMap rm = make_rowmap(H, L, a.enc, a.in_dim, a.K0_pad, out, n_tiles, !inference && slab_eligible(H, L, a.enc, a.in_dim, a.K0_pad, out));
+            const Layout &lay = rm.lay;
+            const int total = inference ? infer_rows_total(H, lay) : rm.rows_total;
+            const int64_t offE = inference ? 2 * H : rm.offE();
+            auto off_in = [&](int l) -> int64_t { return inference ? ((l - 1) & 1) * H : rm.offH(l - 1); };
+            auto off_out = [&](int l) -> int64_t { return inference ? (l & 1) * H : (l + 1 < L ? rm.offH(l) : rm.offGA()); };
+            auto off_bits = [&](int l) -> int64_t { return (inference || l + 1 >= L) ? -1 : rm.offM(l); };      // activation l = output of layer l
+            float *tail = (a.f2 && !inference && L <= 16) ? ws_tail(stash, ws_rows(H, L, a.enc, a.in_dim, a.K0_pad, out, n_tiles)) : nullptr;
             if (tail) {
                 hipError_t me = hipMemsetAsync(tail, 0, WS_TAIL_BYTES, s);
                 if (me != hipSuccess) { tn::set_error("mlp_fwd(f16x2): cannot clear the workspace tail: %s", hipGetErrorString(me)); return (int)me; }
@@ -1092,7 +1148,7 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
                 FwdLayerArgs f;
                 f.W = a.W[0]; f.B = a.B[0]; f.N = a.N[0]; f.K = a.K0; f.Kp = plain ? 64 : a.K0_pad; f.rows_total = total;
-                f.off_in = offE; f.off_out = 0; f.out_act = a.out_act; f.off_bits = off_bits(0);
+                f.off_in = offE; f.off_out = inference ? 0 : rm.offH(0); f.out_act = a.out_act; f.off_bits = off_bits(0);
                 if (a.f2) { if (int rc = launch_fwd_first_f2(H, f, n, stash, s)) return rc; }
                 else if (int rc = launch_fwd_lds<H, 2, H / 32>(f, n, stash, y, s)) return rc;
             } else {
@@ -1133,8 +1189,11 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
                float *const *gb, float *gx, float *stash, hipStream_t s, bool stashed = false, bool gy_rows = false)
 {
     const int L = a.n_layers;
-    const Layout lay = make_layout(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim);
     const int64_t n_tiles = (n + 31) / 32;
+    // (the slab layout is what the stashing forward of the same configuration left behind, run_fwd_only)
+    const RowMap rm = make_rowmap(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim, n_tiles, stashed && slab_eligible(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim));
+    const Layout &lay = rm.lay;
+    const int64_t tail_rows = ws_rows(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim, n_tiles);
     constexpr int WPB = H <= 64 ? 8 : 4;
     if (gy_rows) {
         // TN_MLP_GRAD_Y_ROWS: the consumers of y (the heads' data-gradient chains) have written d loss / d y as rows into
@@ -1142,20 +1201,20 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         TN_REQUIRE(stashed && a.out_act == TN_ACT_NONE && (a.out_dim & 31) == 0, TN_E_CONFIG,
                    "tn_mlp_bwd: TN_MLP_GRAD_Y_ROWS needs TN_MLP_STASHED, no output activation and out_dim % 32 == 0");
     } else if (stashed) {        // activations and the last pre-activation are in the workspace already (tn_mlp_fwd_stash)
-        out_grad_kernel<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * 8)), dim3(256), 0, s>>>(gy, n, a.out_dim, a.out_act, lay.total,
-                                                                                         lay.rowsH + lay.rowsE, stash);
+        out_grad_kernel<<<dim3((unsigned)std::min<int64_t>(n_tiles, 256 * 8)), dim3(256), 0, s>>>(gy, n, a.out_dim, a.out_act, rm.rows_total,
+                                                                                         rm.offGA(), stash);
         if (int rc = tn::check_launch("out_grad_kernel")) return rc;
     } else {
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 2);
         fwd_stash_kernel<H, WPB><<<dim3((unsigned)blocks), dim3(WPB * 64), 0, s>>>(a, x, aux, gy, n, stash);
         if (int rc = tn::check_launch("fwd_stash_kernel")) return rc;
     }
-    const int offE = lay.rowsH, offGA = lay.rowsH + lay.rowsE, offGB = offGA + lay.rowsG;
-    int cur = gy_rows ? offGB : offGA, nxt = gy_rows ? offGA : offGB;
+    const int64_t offE = rm.offE(), offGA = rm.offGA(), offGB = rm.offGB();
+    int64_t cur = gy_rows ? offGB : offGA, nxt = gy_rows ? offGA : offGB;
     for (int l = L - 1; l >= 0; --l) {
         WgradArgs w;
         w.gW = gw[l]; w.gB = gb[l]; w.N = a.N[l]; w.K = a.K[l]; w.K_pad = l == 0 ? a.K0_pad : a.K[l];
-        w.rows_total = lay.total; w.off_g = cur; w.off_a = l > 0 ? (l - 1) * H : 0; w.off_e = offE;
+        w.rows_total = rm.rows_total; w.off_g = cur; w.off_a = l > 0 ? rm.offH(l - 1) : 0; w.off_e = offE;
         w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
@@ -1164,11 +1223,11 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             // f16x2: the layer's data gradient first -- it reports the largest |gradient| of the rows both kernels read -- then the
             // weight gradient with that scale and the one the forward pass left for the layer's input rows
             if (!w.first && w.N == H && w.K == H && a.f2 && stashed && layer_kernel_path(H, L, a.out_dim) && L <= 16) {
-                float *tail = ws_tail(stash, n, lay.total);
+                float *tail = ws_tail(stash, tail_rows);
                 DgradArgs d;
-                d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
-                d.off_gin = cur; d.off_gout = nxt; d.off_mask = (l - 1) * H;
-                d.off_bits = lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * (l - 1);
+                d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = rm.rows_total;
+                d.off_gin = cur; d.off_gout = nxt; d.off_mask = rm.offH(l - 1);
+                d.off_bits = rm.offM(l - 1);
                 d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
                 d.max_in = tail + 16 + l;
                 if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc;
@@ -1188,8 +1247,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if constexpr (H == 256 || H == 128) {
             // plain inputs staged as 64 rows by the training forward (Cobafa's 36 features): same kernel, 128 x 64 / 256 x 64
             if (!staged && w.first && stashed && lay.rowsE == 64 && plain_x_rows(H, L, a.enc, a.K0_pad, a.out_dim) && w.N == H) {
-                if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)cur * 32, (int64_t)lay.total * 32, H, stash + (int64_t)offE * 32,
-                                               (int64_t)lay.total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
+                if (int rc = tn_mlp_wgrad_rows(stash + cur * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
+                                               (int64_t)rm.rows_total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
                 staged = true;
             }
         }
@@ -1198,8 +1257,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             // the row-operand kernel of mlp_wgrad_rows.hip (LDS-direct tiles, 2 x 1 accumulator tiles per wave) instead of
             // per-wave operand loads from L2
             if (!staged && w.first && lay.xs == 0 && w.K_pad == 64 && w.N == H) {
-                if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)cur * 32, (int64_t)lay.total * 32, H, stash + (int64_t)offE * 32,
-                                               (int64_t)lay.total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
+                if (int rc = tn_mlp_wgrad_rows(stash + cur * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
+                                               (int64_t)rm.rows_total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
                 staged = true;
             }
         }
@@ -1213,11 +1272,11 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if (int rc = tn::check_launch("wgrad_layer_kernel")) return rc;
 
         DgradArgs d;
-        d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = lay.total;
-        d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? (l - 1) * H : 0;
+        d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = rm.rows_total;
+        d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? rm.offH(l - 1) : 0;
         // ReLU bit rows exist for every activation the training forward of the layer-kernel path wrote (run_fwd_only)
         const bool bits = stashed && layer_kernel_path(H, L, a.out_dim) && l >= 1;
-        d.off_bits = bits ? lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * (l - 1) : -1;
+        d.off_bits = bits ? rm.offM(l - 1) : -1;
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {
@@ -1278,8 +1337,7 @@ extern "C" __attribute__((visibility("hidden"))) int64_t tn_mlp_bwd_layers_works
     if (H != 32 && H != 64 && H != 128 && H != 256) return 0;
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
     if (((desc->dims[L] + 31) / 32) * (H / 32) > 64) return 0;          // weight-gradient tiling of the output layer (run_layers)
-    const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L]);
-    return ((n + 31) / 32) * (int64_t)lay.total * 32 * (int64_t)sizeof(float) + WS_TAIL_BYTES;
+    return ws_rows(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L], (n + 31) / 32) * 32 * (int64_t)sizeof(float) + WS_TAIL_BYTES;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux,
@@ -1316,10 +1374,11 @@ extern "C" int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_r
     TN_REQUIRE(!two_pass_supported(desc) && tn_mlp_bwd_layers_workspace_bytes(desc, 32) > 0 && layer_kernel_path(H, L, out) &&
                    (out & 31) == 0 && desc->out_activation == TN_ACT_NONE && desc->encoding != TN_ENC_AUX_CAT, TN_E_CONFIG,
                "tn_mlp_rows_view: only wide stacks evaluated layer by layer (width 128 / 256, >= 3 layers, out % 32 == 0, no output activation) keep row views");
-    const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, out);
-    *y_rows = (int64_t)(lay.rowsH + lay.rowsE) * 32;                 // buffer A: the last layer's (pre-)activation = y
-    *grad_y_rows = (int64_t)(lay.rowsH + lay.rowsE + lay.rowsG) * 32;    // buffer B
-    *tile_stride = (int64_t)lay.total * 32;
+    const int K0p = (desc->dims[0] + 7) & ~7;
+    const RowMap rm = make_rowmap(H, L, desc->encoding, desc->in_dim, K0p, out, (n + 31) / 32, slab_eligible(H, L, desc->encoding, desc->in_dim, K0p, out));
+    *y_rows = rm.offGA() * 32;                 // buffer A: the last layer's (pre-)activation = y
+    *grad_y_rows = rm.offGB() * 32;            // buffer B
+    *tile_stride = (int64_t)rm.rows_total * 32;
     return TN_OK;
 }
 

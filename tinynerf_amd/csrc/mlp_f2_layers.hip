@@ -39,8 +39,17 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct Op2 { u32x4 hi, lo; };            // 8 values as two packed-fp16 operands
 
+// TN_F2_NT: non-temporal hints on the row streams of these kernels (bit 0: LDS-direct loads of the forward / data gradient,
+// bit 1: row stores).  In the slab layout a layer launch reads one dense 1 GB array and writes another; nothing is re-read from a
+// cache, and the same copy runs at 5.9 instead of 5.5 TB/s with the hints (scripts/microbench/row_copy.hip).
+#ifndef TN_F2_SB
+#define TN_F2_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef TN_F2_NT
+#define TN_F2_NT 3
+#endif
 __device__ __forceinline__ void glds16(const float *src, float *dst) {
-    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, (TN_F2_NT & 1) ? 2 : 0);      // aux bit 1 = nt
 }
 __device__ __forceinline__ f32x16 mfma_h(const u32x4 &a, const u32x4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -144,6 +153,10 @@ struct Stream2 {
     }
     // largest |value| of this wave's 32 staged rows per sample -> pm[slot][sample][wave]
     __device__ __forceinline__ void publish_max(int sbuf) {
+#ifdef TN_ABL_NOMAX
+        if (h == 0) pm[sbuf * G::PM_F + j * G::WPS + wib] = 1.0f;
+        return;
+#endif
         const float *s_ = sp(sbuf);
         float m = 0.0f;
 #pragma unroll
@@ -191,7 +204,9 @@ struct Stream2 {
     }
     // acc += (W s_W) (x s_j) for the wave's block from tile buffer `cur`; converts the staged tile it + 1 (staging buffer, maxima slot
     // `nb` = (it + 1) & 1) into buffer cur ^ 1 during the first CONV steps.  Returns through `inv_next` 1 / scale of tile it + 1.
-    __device__ __forceinline__ void k_loop(const Op2 (&A)[KS], f32x16 &acc, int cur, int nb, float &inv_next) const {
+    // `next_request` runs behind step CONV: the staged tile it + 1 is consumed then, and the wave asks for tile it + 3 into the same rows
+    template <typename Req>
+    __device__ __forceinline__ void k_loop(const Op2 (&A)[KS], f32x16 &acc, int cur, int nb, float &inv_next, Req next_request) const {
         const unsigned short *tc = tiles + cur * (2 * PLANE);
         const float *s_ = sp(nb);
         unsigned short *n_ = np(cur ^ 1);
@@ -214,7 +229,7 @@ struct Stream2 {
                     cn[2 * u + 1] = s_[(2 * p + 1) * 32];
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            TN_F2_SB;
             const bool conv = s >= 1 && s <= CONV;
             constexpr int NMS = 3 * PPS;                     // micro-steps per step: scale + hi | residual + lo | two LDS writes
             unsigned cu[2];
@@ -238,27 +253,37 @@ struct Stream2 {
                 }
             };
             // three partial products, small terms first; one conversion micro-step (two at H = 128) behind every MFMA
+#ifndef TN_ABL_NOMFMA
             acc = mfma_h(A[s].lo, b.hi, acc);
+#else
+            asm volatile("" :: "v"(A[s].lo), "v"(A[s].hi), "v"(b.hi), "v"(b.lo));
+#endif
 #pragma unroll
             for (int e = 0; e < PPS; ++e) micro(0 * PPS + e);
-            __builtin_amdgcn_sched_barrier(0);
+            TN_F2_SB;
+#ifndef TN_ABL_NOMFMA
             acc = mfma_h(A[s].hi, b.lo, acc);
+#endif
 #pragma unroll
             for (int e = 0; e < PPS; ++e) micro(1 * PPS + e);
-            __builtin_amdgcn_sched_barrier(0);
+            TN_F2_SB;
+#ifndef TN_ABL_NOMFMA
             acc = mfma_h(A[s].hi, b.hi, acc);
+#endif
 #pragma unroll
             for (int e = 0; e < PPS; ++e) micro(2 * PPS + e);
-            __builtin_amdgcn_sched_barrier(0);
+            if (s == CONV) next_request();
+            TN_F2_SB;
             b = bn;
 #pragma unroll
             for (int u = 0; u < 2 * PPS; ++u) cv[u] = cn[u];
         }
     }
-    // behind the k loop of iteration `it`: the rows of tile it + 2 (requested at the top of the iteration into staging buffer
-    // it & 1) have landed -- nothing younger is in flight, the tile's own stores are issued afterwards -- and their maxima go out
+    // behind the k loop of iteration `it`: the rows of tile it + 2 (requested in the middle of iteration it - 1 into staging buffer
+    // it & 1) have landed -- the only younger requests are the four of tile it + 3 from the middle of this k loop (vector memory
+    // operations retire in order; the stores of tile it - 1 are older) -- and their maxima go out
     __device__ __forceinline__ void finish_staging(int sbuf) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         publish_max(sbuf);
     }
     __device__ __forceinline__ void tile_barrier() const {
@@ -343,21 +368,28 @@ __global__ __launch_bounds__(F2Geom<H>::THREADS) void fwd_f2_kernel(FwdLayerArgs
 #pragma clang loop unroll(disable)
     for (int64_t it = 0; it < st.iters; ++it) {
         const int par = (int)(it & 1);
-        if (it > 0) st.request(stash, st.tile_of(it + 2), a.rows_total, a.off_in, par);     // (tile 2 was requested by the prologue)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         float inv_next;
-        st.k_loop(A, acc, cur, par ^ 1, inv_next);
+        st.k_loop(A, acc, cur, par ^ 1, inv_next, [&]() { st.request(stash, st.tile_of(it + 3), a.rows_total, a.off_in, par ^ 1); });
         st.finish_staging(par);
         const int64_t tile = st.tile_of(it);
         tn::pin16(acc);
         const float c = inv_w * inv_cur;
+#ifndef TN_ABL_NOEPI
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], c, bias[r]);
+#endif
         if constexpr (!LAST) {
+#ifndef TN_ABL_NOEPI
             acc = tn::relu16(acc);
-            wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc);
+#endif
+#ifndef TN_ABL_NOSTORE
+            wreg_store_block<(TN_F2_NT & 2) != 0>(urow(stash, tile * a.rows_total + a.off_out), ob, j, h, acc);
+#else
+            tn::pin16(acc);
+#endif
             if (a.off_bits >= 0) {
                 unsigned *bits = reinterpret_cast<unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * ob));
                 bits[lane] = relu_bits(acc);
@@ -436,19 +468,18 @@ __global__ __launch_bounds__(F2Geom<H>::THREADS) void dgrad_f2_kernel(DgradArgs 
         const int par = (int)(it & 1);
         const int64_t tile = st.tile_of(it);
         const unsigned mbits = reinterpret_cast<const unsigned *>(urow(stash, tile * a.rows_total + a.off_bits + 2 * kb))[lane];
-        if (it > 0) st.request(stash, st.tile_of(it + 2), a.rows_total, a.off_gin, par);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         float inv_next;
-        st.k_loop(A, acc, cur, par ^ 1, inv_next);
+        st.k_loop(A, acc, cur, par ^ 1, inv_next, [&]() { st.request(stash, st.tile_of(it + 3), a.rows_total, a.off_gin, par ^ 1); });
         st.finish_staging(par);
         tn::pin16(acc);
         const float c = inv_w * inv_cur;
         f32x16 res;
 #pragma unroll
         for (int r = 0; r < 16; ++r) res[r] = mask_keep(acc[r] * c, mbits, r);
-        wreg_store_block(urow(stash, tile * a.rows_total + a.off_gout), kb, j, h, res);
+        wreg_store_block<(TN_F2_NT & 2) != 0>(urow(stash, tile * a.rows_total + a.off_gout), kb, j, h, res);
         st.tile_barrier();
         inv_cur = inv_next;
         cur ^= 1;
@@ -497,46 +528,56 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_k
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int row = (threadIdx.x + TH * c) >> 2;
-        src_off[c] = (row < H ? a.off_g + row : a.off_a + row - H) * 32 + 4 * qd;
+        src_off[c] = (row < H ? row : row - H) * 32 + 4 * qd;          // relative to the tile's G rows (c < NCH / 2) / A rows
         dst_off[c] = row * RS + 4 * qd;
     }
     float dbacc[NCH / 2];
 #pragma unroll
     for (int c = 0; c < NCH / 2; ++c) dbacc[c] = 0.0f;
     const int64_t stride = gridDim.x;
-    auto half_src = [&](int64_t it) {
-        int64_t tile = blockIdx.x + (it >> 1) * stride;
-        tile = tile < n_tiles ? tile : n_tiles - 1;
-        return stash + tile * (int64_t)a.rows_total * 32 + 16 * (it & 1);
-    };
-    const int64_t my_tiles = (int64_t)blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + stride - 1) / stride : 0;
-    const int64_t iters = 2 * my_tiles;
-    if (iters == 0) return;
     typedef const __attribute__((address_space(1))) char gchar;
+    struct Bases { gchar *g, *a; };                                // wave-uniform: the half tile's G rows and A rows
     auto uniform_global = [](const float *p) {
         const uint64_t v = (uint64_t)p;
         const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         return (gchar *)u;
     };
-    f32x4 st[NCH];
+    auto half_src = [&](int64_t it) {
+        int64_t tile = blockIdx.x + (it >> 1) * stride;
+        tile = tile < n_tiles ? tile : n_tiles - 1;
+        return Bases{uniform_global(stash + (tile * a.rows_total + a.off_g) * 32 + 16 * (it & 1)),
+                     uniform_global(stash + (tile * a.rows_total + a.off_a) * 32 + 16 * (it & 1))};
+    };
+    const int64_t my_tiles = (int64_t)blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + stride - 1) / stride : 0;
+    const int64_t iters = 2 * my_tiles;
+    if (iters == 0) return;
+    // two register sets of raw chunks: half tile it + 1 (being converted during half step it) and it + 2 (in flight); a chunk's
+    // successor two half tiles on is requested into its own registers as soon as it is converted -- every request has two half
+    // steps (~3 us) to land, 64 KB per CU in flight (one set: 32 KB and one half step, which is the loaded HBM latency -- the
+    // kernel ran at exactly 32 KB x 256 CUs per half step = 4.9 TB/s)
+    f32x4 st[2][NCH];
     unsigned src_boff[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) src_boff[c] = (unsigned)src_off[c] * 4u;
-    auto load_chunk = [&](gchar *base, int c) {
+    auto load_chunk = [&](const Bases &base, int c, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         unsigned off = src_boff[c];
         asm volatile("" : "+v"(off));
-        st[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(base + off);
+        // (no nt hint here: a half tile takes 64 of a row's 128 bytes and the other half comes out of L2 one half step later -- with
+        // the hint the launch takes 0.56 instead of 0.39 ms)
+        st[SET][c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>((c < NCH / 2 ? base.g : base.a) + off);
     };
     // conversion of chunk c in six micro-steps (0 / 2: scale + hi of a value pair, 1 / 3: residual + lo, 4: the two 8-byte LDS
     // writes, 5: bias sum + request of the chunk's successor); G chunks come first (c < NCH / 2)
     unsigned cu[4];
     float cf[2];
-    auto micro = [&](int c, int m, unsigned short *buf, gchar *nb) {
+    auto micro = [&](int c, int m, unsigned short *buf, const Bases &nb, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         const float sc = c < NCH / 2 ? s_g : s_a;
         if (m < 4) {
             const int e = m >= 2 ? 2 : 0;
             if ((m & 1) == 0) {
-                cf[0] = st[c][e] * sc; cf[1] = st[c][e + 1] * sc;
+                cf[0] = st[SET][c][e] * sc; cf[1] = st[SET][c][e + 1] * sc;
                 const f16x2 hh = {(_Float16)cf[0], (_Float16)cf[1]};
                 cu[e] = __builtin_bit_cast(unsigned, hh);
             } else {
@@ -549,18 +590,22 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_k
             *reinterpret_cast<uint2 *>(d) = make_uint2(cu[0], cu[2]);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(cu[1], cu[3]);
         } else {
-            if (c < NCH / 2) dbacc[c] += (st[c][0] + st[c][1]) + (st[c][2] + st[c][3]);
-            load_chunk(nb, c);
+            if (c < NCH / 2) dbacc[c] += (st[SET][c][0] + st[SET][c][1]) + (st[SET][c][2] + st[SET][c][3]);
+            load_chunk(nb, c, set_tag);
         }
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     {
-        gchar *b0 = uniform_global(half_src(0)), *b1 = uniform_global(half_src(1));
+        const Bases b0 = half_src(0), b1 = half_src(1), b2 = half_src(2 < iters ? 2 : 0);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) load_chunk(b0, c);
+        for (int c = 0; c < NCH; ++c) load_chunk(b0, c, Set0{});
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) load_chunk(b1, c, Set1{});
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) micro(c, m, lds, b1);
+            for (int m = 0; m < 6; ++m) micro(c, m, lds, b2, Set0{});
         }
     }
     __syncthreads();
@@ -575,11 +620,15 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_k
         o.lo = *reinterpret_cast<const u32x4 *>(buf + off + PLANE);
         return o;
     };
-    auto half_step = [&](int64_t it, int cur, auto convert_tag) {
+    // half step `it` (parity P = it & 1, a compile-time constant: the loop below is unrolled by two): products from LDS buffer P,
+    // half tile it + 1 (register set P ^ 1) converted into buffer P ^ 1, half tile it + 3 requested into that set
+    auto half_step = [&](int64_t it, auto par_tag, auto convert_tag) {
+        constexpr int P = decltype(par_tag)::value;
         constexpr bool CONVERT = decltype(convert_tag)::value;
-        const unsigned short *bc = lds + cur * BUF;
-        unsigned short *bnx = lds + (cur ^ 1) * BUF;
-        gchar *nb = uniform_global(half_src(it + 2 < iters ? it + 2 : it));
+        using SetN = std::integral_constant<int, P ^ 1>;
+        const unsigned short *bc = lds + P * BUF;
+        unsigned short *bnx = lds + (P ^ 1) * BUF;
+        const Bases nb = half_src(it + 3 < iters ? it + 3 : it + 1 < iters ? it + 1 : it);
         Op2 gop[BN];
 #pragma unroll
         for (int bn = 0; bn < BN; ++bn) gop[bn] = read_op(bc, g_off[bn]);
@@ -600,7 +649,7 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_k
 #pragma unroll
                         for (int u = 0; u < PER; ++u) {
                             const int m = ((bk * 3 + t) * BN + bn) * PER + u;
-                            micro(m / 6, m % 6, bnx, nb);
+                            micro(m / 6, m % 6, bnx, nb, SetN{});
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -615,13 +664,13 @@ __global__ __launch_bounds__(64 * (H / 32 / BN) * (H / 32 / BK)) void wgrad_f2_k
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    int cur = 0;
 #pragma clang loop unroll(disable)
-    for (int64_t it = 0; it + 1 < iters; ++it) {
-        half_step(it, cur, std::true_type{});
-        cur ^= 1;
+    for (int64_t it = 0; it + 2 < iters; it += 2) {               // (iters is even: two half tiles per tile)
+        half_step(it, Set0{}, std::true_type{});
+        half_step(it + 1, Set1{}, std::true_type{});
     }
-    half_step(iters - 1, cur, std::false_type{});
+    half_step(iters - 2, Set0{}, std::true_type{});
+    half_step(iters - 1, Set1{}, std::false_type{});
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     const float c_out = inv_g * inv_a;
 #pragma unroll
@@ -745,7 +794,7 @@ __global__ __launch_bounds__(WPB * 64) void fwd_first_f2_kernel(FwdLayerArgs a, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], c, bias_s[32 * ot + frow(r, h)]);
             acc = tn::relu16(acc);
-            wreg_store_block(urow(stash, tile * a.rows_total + a.off_out), ot, j, h, acc);
+            wreg_store_block<(TN_F2_NT & 2) != 0>(urow(stash, tile * a.rows_total + a.off_out), ot, j, h, acc);
             if (a.off_bits >= 0) reinterpret_cast<unsigned *>(st + (a.off_bits + 2 * ot) * 32)[lane] = relu_bits(acc);
         }
     }

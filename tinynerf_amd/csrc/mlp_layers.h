@@ -15,9 +15,9 @@ __device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2
 struct DgradArgs {
     const float *W;       // [N][K] torch layout
     int N, K;             // rows / columns of W
-    int rows_total;       // stash rows per tile
-    int off_gin, off_gout, off_mask;    // row offsets inside a tile
-    int off_bits;                       // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
+    int rows_total;       // stash rows per tile: row set at offset `off` of tile t = rows [t rows_total + off, ...) of the workspace
+    int64_t off_gin, off_gout, off_mask;    // row offsets (tile-major layout: inside a tile; slab layout: slab base + offset inside the slab's tile, see RowMap)
+    int64_t off_bits;                   // >= 0: ReLU bit rows of the mask activation (dgrad_wreg_kernel), else float mask rows
     int enc, in_dim, n_freqs;           // FIRST only: column permutation of layer 0
     int accum_gx;                       // FIRST only: grad_x += (TN_MLP_ACCUM_GRAD_X)
     float *max_in = nullptr;            // f16x2: receives the largest |value| of the rows at off_gin (atomic max; scale of the layer's weight gradient)
@@ -28,9 +28,10 @@ struct FwdLayerArgs {
     const float *W, *B;   // [N][K] torch layout, [N]
     int N, K;
     int Kp;               // input rows present in the workspace (K for hidden layers, K0_pad for the encoded first layer)
-    int rows_total, off_in, off_out;
+    int rows_total;
+    int64_t off_in, off_out;
     int out_act;
-    int off_bits;         // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
+    int64_t off_bits;     // >= 0: the output activation's ReLU bits go to these rows (2 per 32-feature block), < 0: not wanted
     float *max_in = nullptr;            // f16x2: receives the largest |value| of the rows at off_in (see DgradArgs)
 };
 
@@ -38,7 +39,8 @@ struct FwdLayerArgs {
 struct WgradArgs {
     float *gW, *gB;
     int N, K, K_pad;
-    int rows_total, off_g, off_a, off_e;
+    int rows_total;
+    int64_t off_g, off_a, off_e;
     int first, enc, in_dim, n_freqs, xs;
     const float *g_max = nullptr, *a_max = nullptr;       // f16x2: largest |value| of the G rows / of the A rows over ALL tiles
 };
@@ -61,12 +63,17 @@ __device__ __forceinline__ void wreg_load_rows(const float *__restrict__ rows, i
     for (int e = 0; e < 16; ++e) stage[e] = *reinterpret_cast<const float *>(p + off + (unsigned)(e * 128));
 }
 // D-layout rows of block `ob` (lane (j, h), reg r: row 32 ob + frow(r, h), sample j) from / to [row][32 samples] rows
+// (NT: non-temporal stores -- rows that the next launch streams once and nobody re-reads from a cache)
+template <bool NT = false>
 __device__ __forceinline__ void wreg_store_block(float *__restrict__ rows, int ob, int j, int h, const f32x16 &v) {
     char *p = reinterpret_cast<char *>(rows + 32 * ob * 32);
     unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
     asm volatile("" : "+v"(off));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) *reinterpret_cast<float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = v[r];
+    for (int r = 0; r < 16; ++r) {
+        float *d = reinterpret_cast<float *>(p + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
+        if constexpr (NT) __builtin_nontemporal_store(v[r], d); else *d = v[r];
+    }
 }
 __device__ __forceinline__ void wreg_load_block(const float *__restrict__ rows, int ob, int j, int h, float (&m)[16]) {
     const char *p = reinterpret_cast<const char *>(rows + 32 * ob * 32);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage: scripts/timeline.sh <tag> <python script> [args...]  -- kernel trace of a script (GPU box); prints the launches of a ~T_MS window
-# (default 18 ms) that starts T_BACK ms (default 50) before the last launch ends: start offset, duration, queue, kernel
+# between two launches of the marker kernel T_MARK (default sample_pack_kernel = one training step), the T_BACK-th from the end: start offset, duration, queue, kernel
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -10,11 +10,12 @@ python3 - /tmp/tl_$tag <<'PY'
 import csv, glob, sys, os
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-at = t1 - float(os.environ.get("T_BACK", "50")) * 1e6
-win = float(os.environ.get("T_MS", "18")) * 1e6
-for r in rows:
+mark = os.environ.get("T_MARK", "sample_pack_kernel")
+hits = [k for k, r in enumerate(rows) if mark in r["Kernel_Name"]]
+back = int(os.environ.get("T_BACK", "3"))
+k0, k1 = hits[-back - 1], hits[-back]
+at = int(rows[k0]["Start_Timestamp"])
+for r in rows[k0:k1 + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    if s < at or s > at + win: continue
     print("%9.1f us +%8.1f  q%-3s %s" % ((s - at) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"].replace("(anonymous namespace)::", "")[:90]))
 PY

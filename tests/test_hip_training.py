@@ -487,6 +487,38 @@ def test_heads_read_the_stack_output_from_workspace_rows(method, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vanilla", "cobafa"])
+def test_paired_data_gradient_behind_the_wide_stacks(method, monkeypatch):
+    """Round 5: behind a wide stack both heads' data gradients can run as ONE pass (tn_mlp_bwd_pair writing d loss / d feat as
+    workspace rows once; behind the 256-wide stack in two column windows of W_0, the second reading the G_0 rows the first wrote).
+    Same products in the same arithmetic, summed in one accumulator instead of through memory: parameters after three steps
+    equal the two-call form's to fp32 rounding, and the first step's loss is identical."""
+    from tinynerf_amd import fused
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    out = {}
+    for mode in ("0", "all"):
+        monkeypatch.setattr(fused, "HEADS_PAIR_BACKWARD", mode)
+        cfg = TrainConfig(method=method, scene_type="aabb", batch_size=256, n_samples=32, seed=3, occupancy_res=32, deterministic=True)
+        tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+        for group in tr.optimizer.param_groups:
+            group["lr"] = 1e-3
+        if method == "cobafa":
+            tr.renderer.feature_module.dropout.p = 0.0
+        ls = []
+        for _ in range(3):
+            tr.step()
+            ls.append(tr.loss_value())
+        out[mode] = (ls, {k: v.detach().float().cpu().numpy().copy() for k, v in tr.renderer.state_dict().items()})
+    assert out["0"][0][0] == out["all"][0][0]
+    np.testing.assert_allclose(out["all"][0], out["0"][0], rtol=2e-5)
+    for k, v in out["0"][1].items():
+        w = out["all"][1][k]
+        assert np.all(np.isfinite(w)), k
+        np.testing.assert_allclose(w, v, rtol=0, atol=2e-5 * max(1e-3, float(np.abs(v).max())), err_msg=k)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("where", ["plane", "colour_weight", "sigma_bias"])
 def test_a_non_finite_parameter_surfaces_as_the_reference_nan_loss(where):
     """torch.relu hands a NaN on (models.py:7-28), so in the reference ONE non-finite parameter makes the loss NaN at the next step

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     const int64_t n_tiles = (n + 31) >> 5;
     const int G0 = a.K0_pad >> 3;
     const int out = a.out_dim;
+    const bool skip_g = (PAIR && !KP && STASHED) ? a.skip_g_rows != 0 : false;      // (second column window of a split launch; never with the fused scatter)
 
     // STASHED: the per-tile inputs (ReLU masks, last pre-activation, output gradient) of the NEXT tile are requested at the
     // top of the current one.  VMEM operations of a wave retire in order, so a load issued after a tile's ~150 row stores
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 const int64_t tn_ = tile + (int64_t)gridDim.x * WPB;
                 fetch_tile(tn_ < n_tiles ? tn_ : n_tiles - 1);       // before this tile's stores
             }
-            if constexpr (PAIR) {                                    // head b: g_pre rows, G_0 = relu'(H_1) * (W_1^T g_pre), G_0 rows
+            if (PAIR && !skip_g) {                            // head b: g_pre rows, G_0 = relu'(H_1) * (W_1^T g_pre), G_0 rows
                 float *stb = pr.stash + tile * (int64_t)(Rb * 32);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                if (h == 0) stP[o * 32 + j] = gp[o];
+                if (h == 0 && !skip_g) stP[o * 32 + j] = gp[o];
             (void)stQ; (void)stM;
         } else {
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
@@ -309,6 +310,11 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         }
         TN_PTB(0)
         f32x16 G[T];
+        if (STASHED && skip_g) {
+            // second column window of a split launch (launch_v2): G_0 is in the workspace already, nothing of the chain is repeated
+#pragma unroll
+            for (int ob = 0; ob < T; ++ob) tn::mlp::load_rows(stG, G[ob], ob, j, h);
+        } else {
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) {
 #pragma unroll
@@ -329,8 +335,10 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         // ---------------- hidden layers, last to first ----------------
         static_for<NH - 1>([&](auto lc) {
             constexpr int l = NH - 1 - decltype(lc)::value;     // l = NH-1 .. 1 : G holds G_l
+            if (!skip_g) {
 #pragma unroll
-            for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
+                for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
+            }
             const float *Wl = lds + a.w_off[l];
             constexpr int sl = H + 4;                       // stride of every hidden layer (mlp_stage.h plan()): a constant lets the
                                                             // row offsets below become ds_read immediates instead of VALU adds
@@ -374,8 +382,11 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 for (int r = 0; r < 16; ++r) G[kt][r] = mask_keep(Gn[kt][r], mask[l - 1][kt], r);
             }
         });
+        }
+        if (!skip_g) {
 #pragma unroll
-        for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
+            for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);      // G_0
+        }
 
         TN_PTB(1)
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
@@ -383,9 +394,16 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
-            const int n_kt = (a.in_dim + 31) >> 5;
+            const int n_kt = ((a.gx_ncols ? a.gx_ncols : a.in_dim) + 31) >> 5;      // (window of x columns: LDS holds these columns of W_0)
+            const int kt0 = a.gx_col0 >> 5;
             f32x16 Gb[T];
-            if constexpr (PAIR) first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
+            if constexpr (PAIR) {
+                if (skip_g) {
+                    const float *stb = pr.stash + tile * (int64_t)(Rb * 32);
+#pragma unroll
+                    for (int ob = 0; ob < T; ++ob) tn::mlp::load_rows(stb + H * 32, Gb[ob], ob, j, h);
+                } else first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
+            }
             const int64_t rowc = row < n ? row : n - 1;
             f32x4 old[4], oldn[4];
             // d loss / d x as [feature][32-sample] rows (tn_mlp_desc::grad_x_rows: the consumer is a wide stack's layer kernel):
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             if constexpr (ACCUM) {
                 if (gxr == nullptr) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * kt0 + 8 * q + 4 * h);
                 }
             }
 #pragma clang loop unroll(disable)
@@ -403,13 +421,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 if constexpr (ACCUM) {
-                    if (gxr != nullptr) tn::mlp::load_rows(gxr + kt * 32 * 32, acc, 0, j, h);     // the MFMAs below accumulate on top
+                    if (gxr != nullptr) tn::mlp::load_rows(gxr + (kt0 + kt) * 32 * 32, acc, 0, j, h);     // the MFMAs below accumulate on top
                 }
                 if constexpr (ACCUM) {
                     if (gxr == nullptr) {
                     const int ktn = kt + 1 < n_kt ? kt + 1 : kt;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * ktn + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * (kt0 + ktn) + 8 * q + 4 * h);
                     }
                 }
                 {
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     if (gx == nullptr) continue;
                 }
                 if (gxr != nullptr) {               // rows of samples >= n carry zeros (their output gradient was zeroed)
-                    store_rows(gxr + kt * 32 * 32, acc, 0, j, h);
+                    store_rows(gxr + (kt0 + kt) * 32 * 32, acc, 0, j, h);
                     continue;
                 }
                 if constexpr (ACCUM) {
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                             f32x4 v = old[q];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) v[u] += acc[4 * q + u];
-                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + 32 * kt + 8 * q + 4 * h) = v;
+                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + 32 * (kt0 + kt) + 8 * q + 4 * h) = v;
                         }
                     }
 #pragma unroll
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 } else if (valid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int f0 = 32 * kt + 8 * q + 4 * h;
+                        const int f0 = 32 * (kt0 + kt) + 8 * q + 4 * h;
                         if (f0 + 3 < a.in_dim && (a.in_dim & 3) == 0) {
                             f32x4 v;
 #pragma unroll
@@ -910,11 +928,12 @@ bool v2_supported(const tn_mlp_desc *d) { return two_pass_supported(d); }
 // phase bit 0: data-gradient chain, bit 1: weight gradient.  pair != nullptr: the chain also runs head `pair->b`.
 // first layer of a head without its aux columns: the stashed chain only ever reads W_0's x columns (W_0^T G_0 over the x
 // slots), and the 14 KB this saves in LDS are what the fused scatter's per-wave tiles need
-MlpArgs compact_first_layer(const MlpArgs &a)
+MlpArgs compact_first_layer(const MlpArgs &a, int col0 = 0, int ncols = 0)
 {
     MlpArgs c = a;
     const int H = a.N[0];
-    c.K0_pad = (a.in_dim + 7) & ~7;
+    c.K0_pad = ((ncols ? ncols : a.in_dim) + 7) & ~7;
+    c.gx_col0 = col0; c.gx_ncols = ncols;
     int off = 0;
     for (int l = 0; l < a.n_layers; ++l) {
         const int Kp = l == 0 ? c.K0_pad : H;
@@ -960,20 +979,38 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (stashed && a.accum_gx && (gx != nullptr || a.gx_rows != nullptr) && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
     PairArgs pr;
     pr.gy = nullptr; pr.stash = nullptr;
+    MlpArgs a1 = a;                           // (the launch's own copy: a column window of W_0 may replace the full first layer)
+    int windows = 1;
     if (pair) {
         pr = *pair;
         if constexpr (NH == 4) kern = mlp_chain_kernel<H, NH, WPP, true, false, true>;
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: the paired chain is built for the 5-layer colour head");
         wpb = WPP;
         lds_bytes += (size_t)pr.b.lds_floats * 4;
+        if (lds_bytes > (size_t)LDS_LIMIT_BYTES && stashed && (a.in_dim & 63) == 0 && a.enc == TN_ENC_AUX_CAT && pair->b.enc == TN_ENC_NONE) {
+            // heads behind a 256-wide stack: W_0 of both heads (2 x 64 x 256 floats) and the hidden layers do not fit LDS together.
+            // The stashed chain reads W_0 only for grad_x = W_0^T G_0, one 32-column block at a time: two launches, each with one half of
+            // the x columns of both first layers in LDS; the second one reads both heads' G_0 rows, which the first one wrote (the hidden chain is 60 % of a launch's fp32 MFMAs: not repeated).
+            windows = 2;
+            a1 = compact_first_layer(a, 0, a.in_dim / 2);
+            pr.b = compact_first_layer(pair->b, 0, a.in_dim / 2);
+            lds_bytes = ((size_t)a1.lds_floats + (size_t)pr.b.lds_floats) * 4;
+        }
     } else pr.b = a;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));
     const int64_t blocks = std::min<int64_t>((n_tiles + wpb - 1) / wpb, 256 * per_cu);
-    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash, pr, KpBwd());
-    if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
+    for (int w = 0; w < windows; ++w) {
+        if (w == 1) {
+            a1 = compact_first_layer(a, a.in_dim / 2, a.in_dim / 2);
+            pr.b = compact_first_layer(pair->b, a.in_dim / 2, a.in_dim / 2);
+            a1.skip_g_rows = 1;
+        }
+        kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a1, x, aux, gy, n, gx, stash, pr, KpBwd());
+        if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
+    }
     }
     if (!(phase & 2)) return TN_OK;
 
@@ -1127,7 +1164,7 @@ static int bwd_pair_common(const tn_mlp_desc *desc, const tn_mlp_desc *partner, 
     const int64_t need_a = tn_mlp_bwd_workspace_bytes(desc, n), need_b = tn_mlp_bwd_workspace_bytes(partner, n);
     TN_REQUIRE(workspace && workspace_bytes >= need_a && partner_workspace && partner_workspace_bytes >= need_b, TN_E_NULL,
                "tn_mlp_bwd_pair: workspace missing or too small");
-    TN_REQUIRE(x && grad_y && partner_grad_y && (grad_x || kpb) && grad_weights && grad_biases && partner_grad_weights && partner_grad_biases,
+    TN_REQUIRE(x && grad_y && partner_grad_y && (grad_x || kpb || desc->grad_x_rows) && grad_weights && grad_biases && partner_grad_weights && partner_grad_biases,
                TN_E_NULL, "tn_mlp_bwd_pair: null pointer");
     MlpArgs a, b;
     int H = 0, Hb = 0;

@@ -29,6 +29,10 @@ struct MlpArgs {
     int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
     int rows_only;         // TN_MLP_ROWS_ONLY (producer: no row-major y)
     int x_from_rows;       // TN_MLP_X_FROM_ROWS (consumer: x only exists as x_rows)
+    // column window of the stashed chain's grad_x = W_0^T G_0 (mlp_bwd2.hip, paired heads behind a 256-wide stack: both first layers
+    // do not fit LDS at once, so the launch is split by x columns): the LDS copy of W_0 holds x slots [gx_col0, gx_col0 + gx_ncols)
+    // (gx_ncols == 0: all of them); skip_g_rows: the G / g_pre rows of the workspace are already written (second window)
+    int gx_col0 = 0, gx_ncols = 0, skip_g_rows = 0;
     int lean;              // TN_MLP_LEAN: the training forward leaves the H rows of the workspace unwritten (mlp_wgrad_rc.hip rebuilds them)
     int f2_plane[TN_MLP_MAX_LAYERS], f2_scale;     // f16x2 heads (mlp_f2_heads.h): halfs per weight plane, float index of the (s, 1 / s) pairs
 };
@@ -52,7 +56,8 @@ __device__ inline void stage_weights(const MlpArgs &a, float *lds) {
         for (int e = threadIdx.x; e < rows * stride; e += blockDim.x) {
             const int r = e / stride, q = e - r * stride;
             float v = 0.0f;
-            if (r < N && q < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, q) : q)];
+            const int qs = l == 0 ? q + a.gx_col0 : q;
+            if (r < N && qs < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, qs) : qs)];
             w[e] = v;
         }
         float *b = lds + a.b_off[l];

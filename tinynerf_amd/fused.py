@@ -38,6 +38,11 @@ PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_
 FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
 FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient chain launch (tn_kplanes_mlp_bwd_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
+# ... also behind the wide stacks (_RenderHeads; round 5): "128" (default) = behind Cobafa's 128-wide stack, where one launch holds both
+# first layers (0.67 against 0.43 + 0.28 ms per 2^20 samples); "all" = also behind the 256-wide stack, in two column windows -- measured
+# SLOWER there (0.71 + 0.45 against 0.61 + 0.49 ms: 137 GFLOP of W_0^T G_0 on the fp32 MFMA either way, and the window form adds the G_0
+# re-read), kept for the parity test; "0" = never
+HEADS_PAIR_BACKWARD = os.environ.get("TN_HEADS_PAIR", "128")
 # schedule of the K-Planes backward: "fused" = chain + scatter in one kernel, then the weight gradients; "split" = chain, then the
 # stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
 # second stream BESIDE the weight-gradient kernels (bound by HBM)
@@ -527,10 +532,17 @@ class _RenderHeads(Function):
             for d in (rdesc, sdesc):
                 d.x_rows, d.grad_x_rows = link["y_rows"], link["grad_rows"]
                 d.x_rows_tile_stride = d.grad_x_rows_tile_stride = link["stride"]
-        L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw_r, gb_r, L.ptr(g_feat),
-               L.ptr(ws_r), C.c_int64(rb))
-        L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s, L.ptr(g_feat),
-               L.ptr(ws_s), C.c_int64(sb))
+        if link is not None and (HEADS_PAIR_BACKWARD == "all" or (HEADS_PAIR_BACKWARD == "128" and F == 128)) and F % 64 == 0 and ns == 2 and nr == 5 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
+            # both heads' data gradients in one pass (two column windows at 256 inputs: mlp_bwd2.hip): d loss / d feat is written once as
+            # the sum of the two instead of written by the colour head and read, added to and written again by the sigma head
+            sdesc.flags &= ~L.MLP_ACCUM_GRAD_X
+            L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
+                   C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            L.call("tn_mlp_bwd", dev, C.byref(rdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), C.c_int64(n), gw_r, gb_r, L.ptr(g_feat),
+                   L.ptr(ws_r), C.c_int64(rb))
+            L.call("tn_mlp_bwd", dev, C.byref(sdesc), L.ptr(feat), C.c_void_p(None), L.ptr(g_sigma), C.c_int64(n), gw_s, gb_s, L.ptr(g_feat),
+                   L.ptr(ws_s), C.c_int64(sb))
         if link is not None:
             link["delivered"] = True
             g_feat = torch.empty(1, device=dev).expand(n, F)

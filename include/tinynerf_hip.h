@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TN_ABI_VERSION 4
+#define TN_ABI_VERSION 5
 
 enum {
     TN_OK = 0,
@@ -211,6 +211,15 @@ enum { TN_ENC_NONE = 0,
                                  * view: TN_MLP_F16X2, in_dim 128 or 256, <= 4 outputs.  Without the flag such a launch still
                                  * prefers x_rows when they are set (coalesced 128-byte rows instead of 16 bytes per lane and sample). */
 
+#define TN_MLP_SKIP_LAST 1024   /* a wide stack evaluated layer by layer whose LAST layer is a plain Linear feeding only Linear first layers of
+                                 * its consumers (reference models.py:59-89: Linear(256, 256) then Linear(256, 64) twice with nothing in
+                                 * between): W_head (W_last h + b_last) + b_head = (W_head W_last) h + (W_head b_last + b_head), so the caller
+                                 * merges the two layers' parameters and the stack stops at its last HIDDEN activation.  tn_mlp_fwd_stash
+                                 * then runs layers 0 .. L - 2 only (y is not written), tn_mlp_rows_view_hidden says where that activation,
+                                 * the slot for its gradient and its ReLU bit rows are, and tn_mlp_bwd (with TN_MLP_STASHED |
+                                 * TN_MLP_GRAD_Y_ROWS) starts from that gradient and leaves the last layer's parameter gradients untouched
+                                 * (they follow from the merged parameters' gradients by the chain rule).  One layer launch less in the
+                                 * forward pass, two less in the backward pass, and the feature tensor never exists. */
 #define TN_MLP_LEAN 512        /* the paired width-64 heads (tn_mlp_fwd_stash_pair / tn_kplanes_mlp_fwd_pair and their backward twins), round 5:
                                  * the training forward writes only the ReLU bit masks, the last pre-activation and the feature rows --
                                  * NOT the hidden activations H_l (1.3 KB per sample that crossed HBM twice) -- and the weight-gradient
@@ -254,6 +263,12 @@ typedef struct tn_mlp_desc {
     float *grad_x_rows;
     int64_t x_rows_tile_stride;               /* floats */
     int64_t grad_x_rows_tile_stride;
+    /* ReLU bit rows for grad_x_rows (optional; tn_mlp_rows_view_hidden): when the rows a head reads are a HIDDEN activation of the
+     * producer (TN_MLP_SKIP_LAST), d loss / d x leaves multiplied by relu'(x) -- bit r of the dword at
+     * grad_x_mask_rows[t * grad_x_mask_tile_stride + 64 b + lane] says whether feature 32 b + (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of
+     * sample 32 t + (lane & 31) was positive (the layer kernels' bit rows, two 128-byte rows per 32-feature block). */
+    const void *grad_x_mask_rows;
+    int64_t grad_x_mask_tile_stride;          /* dwords */
 } tn_mlp_desc;
 
 /* One plain Linear (reference src/models.py:183-191: KPlanesExplicitOpacityDecoder.net = torch.nn.Linear(96, 96), the only
@@ -273,6 +288,12 @@ int tn_linear_bwd(const float *x, const float *weight, const float *grad_y, int6
  *   grad_y_rows  where tn_mlp_bwd with TN_MLP_GRAD_Y_ROWS expects d loss / d y in that layout;
  * and the tile stride (floats per 32 samples) of both.  TN_E_CONFIG when the configuration has no such views. */
 int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_rows, int64_t *grad_y_rows, int64_t *tile_stride);
+/* ... of a stack that ran / will run with TN_MLP_SKIP_LAST: the last hidden activation h (offsets in floats from the workspace
+ * base, [feature][32-sample] rows, tile stride as above), the slot where tn_mlp_bwd expects d loss / d h -- ALREADY multiplied by
+ * relu'(h): consumers apply tn_mlp_desc::grad_x_mask_rows --, and h's ReLU bit rows (offset in floats = dwords; the bit rows' tile
+ * stride equals tile_stride). */
+int tn_mlp_rows_view_hidden(const tn_mlp_desc *desc, int64_t n, int64_t *h_rows, int64_t *grad_h_rows, int64_t *mask_rows,
+                            int64_t *tile_stride);
 
 /* y [n, dims[n_layers]] = MLP(x [n,in_dim], aux [n,3] (dirs for TN_ENC_DIR_CAT, else NULL)).
  * pre_act (optional, [n, dims[n_layers]]) receives the last layer's output before out_activation. */

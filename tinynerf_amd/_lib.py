@@ -44,6 +44,7 @@ class MlpDesc(C.Structure):
         ("aux_index", C.c_void_p), ("aux_stride", C.c_int32), ("reserved", C.c_int32),
         ("row_gate", C.c_void_p),
         ("x_rows", C.c_void_p), ("grad_x_rows", C.c_void_p), ("x_rows_tile_stride", C.c_int64), ("grad_x_rows_tile_stride", C.c_int64),
+        ("grad_x_mask_rows", C.c_void_p), ("grad_x_mask_tile_stride", C.c_int64),
     ]
 
 
@@ -67,7 +68,8 @@ MLP_F16X2 = 64
 MLP_ROWS_ONLY = 128
 MLP_X_FROM_ROWS = 256
 MLP_LEAN = 512
-ABI_VERSION = 4            # include/tinynerf_hip.h TN_ABI_VERSION: a stale library (TN_LIB_PATH, a forgotten rebuild) fails at load, not in a kernel
+MLP_SKIP_LAST = 1024
+ABI_VERSION = 5            # include/tinynerf_hip.h TN_ABI_VERSION: a stale library (TN_LIB_PATH, a forgotten rebuild) fails at load, not in a kernel
 
 
 class PlaneRegItem(C.Structure):
@@ -145,6 +147,11 @@ def require_cuda(*tensors: Optional[torch.Tensor]) -> torch.device:
             raise RuntimeError("tinynerf_amd: tensors are on different devices")
     assert dev is not None
     return dev
+
+
+def call_plain(name: str, *args) -> None:
+    """Invoke a host-only entry point (no stream argument); raises on a non-zero return code."""
+    check(getattr(lib(), name)(*args), name)
 
 
 def call(name: str, device: torch.device, *args) -> None:

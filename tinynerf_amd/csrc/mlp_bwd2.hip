@@ -466,6 +466,11 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                     if (gx == nullptr) continue;
                 }
                 if (gxr != nullptr) {               // rows of samples >= n carry zeros (their output gradient was zeroed)
+                    if (!KP && a.gx_mask_rows != nullptr) {      // x is a hidden activation of the producer: d / d (its pre-activation)
+                        const unsigned mb = a.gx_mask_rows[tile * a.gx_mask_stride + (kt0 + kt) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = mask_keep(acc[r], mb, r);
+                    }
                     store_rows(gxr + (kt0 + kt) * 32 * 32, acc, 0, j, h);
                     continue;
                 }

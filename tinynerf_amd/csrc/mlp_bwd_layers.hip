@@ -1159,7 +1159,9 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                     a, x, aux, nullptr, n, stash, y);
                 if (int rc = tn::check_launch("fwd_stash_kernel(first layer)")) return rc;
             }
-            for (int l = 1; l < L; ++l) {
+            if (a.skip_last && (inference || !rm.slab || !a.f2 || out != H))
+                return tn::fail(TN_E_CONFIG, "tn_mlp_fwd_stash: TN_MLP_SKIP_LAST needs the f16x2 training forward of a slab-layout stack whose output is as wide as its hidden layers");
+            for (int l = 1; l < L - (a.skip_last ? 1 : 0); ++l) {       // (TN_MLP_SKIP_LAST: the caller merged the last layer into its consumers)
                 FwdLayerArgs f;
                 f.W = a.W[l]; f.B = a.B[l]; f.N = a.N[l]; f.K = a.K[l]; f.Kp = a.K[l]; f.rows_total = total;
                 f.off_in = off_in(l); f.off_out = off_out(l); f.out_act = a.out_act; f.off_bits = off_bits(l);
@@ -1195,6 +1197,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
     const Layout &lay = rm.lay;
     const int64_t tail_rows = ws_rows(H, L, a.enc, a.in_dim, a.K0_pad, a.out_dim, n_tiles);
     constexpr int WPB = H <= 64 ? 8 : 4;
+    if (a.skip_last) TN_REQUIRE(gy_rows && stashed && rm.slab && a.f2, TN_E_CONFIG, "tn_mlp_bwd: TN_MLP_SKIP_LAST needs TN_MLP_STASHED | TN_MLP_GRAD_Y_ROWS on the f16x2 slab-layout stack");
     if (gy_rows) {
         // TN_MLP_GRAD_Y_ROWS: the consumers of y (the heads' data-gradient chains) have written d loss / d y as rows into
         // buffer B (tn_mlp_rows_view): nothing to transpose, the walk below starts from B and ping-pongs into A
@@ -1211,7 +1214,8 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
     }
     const int64_t offE = rm.offE(), offGA = rm.offGA(), offGB = rm.offGB();
     int64_t cur = gy_rows ? offGB : offGA, nxt = gy_rows ? offGA : offGB;
-    for (int l = L - 1; l >= 0; --l) {
+    // (TN_MLP_SKIP_LAST: buffer B holds d loss / d (pre-activation of layer L - 2) -- the walk starts one layer lower)
+    for (int l = L - 1 - (a.skip_last ? 1 : 0); l >= 0; --l) {
         WgradArgs w;
         w.gW = gw[l]; w.gB = gb[l]; w.N = a.N[l]; w.K = a.K[l]; w.K_pad = l == 0 ? a.K0_pad : a.K[l];
         w.rows_total = rm.rows_total; w.off_g = cur; w.off_a = l > 0 ? rm.offH(l - 1) : 0; w.off_e = offE;
@@ -1378,6 +1382,25 @@ extern "C" int tn_mlp_rows_view(const tn_mlp_desc *desc, int64_t n, int64_t *y_r
     const RowMap rm = make_rowmap(H, L, desc->encoding, desc->in_dim, K0p, out, (n + 31) / 32, slab_eligible(H, L, desc->encoding, desc->in_dim, K0p, out));
     *y_rows = rm.offGA() * 32;                 // buffer A: the last layer's (pre-)activation = y
     *grad_y_rows = rm.offGB() * 32;            // buffer B
+    *tile_stride = (int64_t)rm.rows_total * 32;
+    return TN_OK;
+}
+
+extern "C" int tn_mlp_rows_view_hidden(const tn_mlp_desc *desc, int64_t n, int64_t *h_rows, int64_t *grad_h_rows, int64_t *mask_rows,
+                                       int64_t *tile_stride)
+{
+    TN_REQUIRE(desc && h_rows && grad_h_rows && mask_rows && tile_stride, TN_E_NULL, "tn_mlp_rows_view_hidden: null pointer");
+    TN_REQUIRE(n >= 0, TN_E_SIZE, "tn_mlp_rows_view_hidden: negative n");
+    const int L = desc->n_layers;
+    TN_REQUIRE(L >= 3 && L <= TN_MLP_MAX_LAYERS, TN_E_CONFIG, "tn_mlp_rows_view_hidden: n_layers must be in [3, 12]");
+    const int H = desc->dims[1], out = desc->dims[L], K0p = (desc->dims[0] + 7) & ~7;
+    TN_REQUIRE((desc->flags & TN_MLP_SKIP_LAST) && (desc->flags & TN_MLP_F16X2) && out == H && desc->out_activation == TN_ACT_NONE &&
+                   !two_pass_supported(desc) && slab_eligible(H, L, desc->encoding, desc->in_dim, K0p, out), TN_E_CONFIG,
+               "tn_mlp_rows_view_hidden: TN_MLP_SKIP_LAST | TN_MLP_F16X2 on a slab-layout stack (width 128 / 256, output as wide, no output activation)");
+    const RowMap rm = make_rowmap(H, L, desc->encoding, desc->in_dim, K0p, out, (n + 31) / 32, true);
+    *h_rows = rm.offH(L - 2) * 32;
+    *grad_h_rows = rm.offGB() * 32;
+    *mask_rows = rm.offM(L - 2) * 32;
     *tile_stride = (int64_t)rm.rows_total * 32;
     return TN_OK;
 }

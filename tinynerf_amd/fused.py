@@ -47,6 +47,11 @@ HEADS_PAIR_BACKWARD = os.environ.get("TN_HEADS_PAIR", "128")
 # stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
 # second stream BESIDE the weight-gradient kernels (bound by HBM)
 BWD_SCHEDULE = os.environ.get("TN_BWD_SCHEDULE", "fused")
+# round 5 (TN_MLP_SKIP_LAST): behind a wide stack whose last layer is a plain Linear (Vanilla 256 -> 256, Cobafa 128 -> 128: reference
+# models.py:59-68,239-247) the heads' first layers are Linear too -- the harness merges the two (W_head W_last, W_head b_last + b_head: five
+# small torch matmuls per step, differentiable, so the original parameters get their gradients by the chain rule) and the stack stops at its
+# last hidden activation: one layer launch less in the forward pass, two less in the backward pass, the feature tensor never exists
+MERGE_LAST = os.environ.get("TN_MERGE_LAST", "1") != "0"
 # round 5 (TN_MLP_LEAN): the paired f16x2 training forward writes masks / pre-activations / feature rows only, the weight-gradient launches
 # rebuild the hidden activations from the feature rows (csrc/mlp_wgrad_rc.hip) -- 2.7 GB less workspace traffic per K-Planes step.
 # TN_KP_LEAN=0: the stash-everything form of rounds 1-4 (A/B runs; always taken by the fp32 / bf16x3 head forms)
@@ -281,7 +286,7 @@ class _RenderKPlanes(Function):
             g_out = g_out * (ctx.gate > 0).to(g_out.dtype)       # "Empty iteration": zero gradients, as on the module-by-module path
 
         def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
-            if accumulate and ref is not None and ref.grad is not None and ref.grad.stride() == p.stride():
+            if accumulate and ref is not None and ref.is_leaf and ref.grad is not None and ref.grad.stride() == p.stride():
                 return ref.grad, True
             return torch.zeros_like(p), False
 
@@ -501,7 +506,7 @@ class _RenderHeads(Function):
         refs: Sequence[Optional[torch.Tensor]] = ctx.param_refs if ctx.param_refs is not None else [None] * len(params)
 
         def grad_buffer(p: torch.Tensor, ref: Optional[torch.Tensor]):
-            if accumulate and ref is not None and ref.grad is not None and ref.grad.stride() == p.stride():
+            if accumulate and ref is not None and ref.is_leaf and ref.grad is not None and ref.grad.stride() == p.stride():
                 return ref.grad, True
             return torch.zeros_like(p), False
         bufs = [grad_buffer(p, r) for p, r in zip(params, refs)]
@@ -532,6 +537,8 @@ class _RenderHeads(Function):
             for d in (rdesc, sdesc):
                 d.x_rows, d.grad_x_rows = link["y_rows"], link["grad_rows"]
                 d.x_rows_tile_stride = d.grad_x_rows_tile_stride = link["stride"]
+                if link.get("skipped_last"):     # x is the producer's last HIDDEN activation: d / d (its pre-activation) = relu' * ...
+                    d.grad_x_mask_rows, d.grad_x_mask_tile_stride = link["mask_rows"], link["stride"]
         if link is not None and (HEADS_PAIR_BACKWARD == "all" or (HEADS_PAIR_BACKWARD == "128" and F == 128)) and F % 64 == 0 and ns == 2 and nr == 5 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
             # both heads' data gradients in one pass (two column windows at 256 inputs: mlp_bwd2.hip): d loss / d feat is written once as
             # the sum of the two instead of written by the colour head and read, added to and written again by the sigma head
@@ -548,6 +555,15 @@ class _RenderHeads(Function):
             g_feat = torch.empty(1, device=dev).expand(n, F)
         grads = [None if in_place else g for (g, in_place) in bufs]
         return (g_feat, None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+
+
+def _mergeable(producer, sig_p, rgb_p) -> bool:
+    """the producer stack's last layer is a square Linear without activation feeding nothing but the two heads' first layers"""
+    ps = producer.params()
+    if len(ps) < 6 or ps[-2].dim() != 2 or ps[-2].size(0) != ps[-2].size(1) or ps[-2].size(0) not in (128, 256):
+        return False
+    F = ps[-2].size(0)
+    return sig_p[0].size(1) == F and rgb_p[0].size(1) > F and all(p.requires_grad for p in (ps[-2], ps[-1], sig_p[0], sig_p[1], rgb_p[0], rgb_p[1]))
 
 
 def _vanilla_decoders(renderer) -> bool:
@@ -593,11 +609,15 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
         if sc is not None and len(sc) > 4:
             sc[4]["rows_only"] = True
             armed = sc[4]
+            if MERGE_LAST and _mergeable(producer, sig_p, rgb_p):
+                sc[4]["skip_last"] = True
     try:
         feat = fm(packed[:, :3])
     finally:
         # the flag is for exactly THIS forward: if the producer stack did not run (an exception, a feature module that skipped it) it must
         # not stay armed for an unrelated forward, whose row-major output would then silently stay unwritten
+        if armed is not None:
+            armed.pop("skip_last", None)
         if armed is not None and armed.pop("rows_only", False):
             import warnings
             warnings.warn("tinynerf_amd.fused: TN_MLP_ROWS_ONLY was armed but the feature stack did not consume it; disarmed", RuntimeWarning)
@@ -611,5 +631,16 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
                 link = sc[2]
                 if feat.size(1) in (128, 256) and sc[2].get("n") == feat.size(0):
                     renderer.__dict__["_rows_producer"] = mod
+    if link is not None and link.get("skipped_last"):
+        # the stack stopped at its last hidden activation h (rows): heads on h with the last layer folded into their first layers
+        w_last, b_last = producer.params()[-2:]
+        F = feat.size(1)
+        pe = rgb_p[0].size(1) - F                                   # torch column order of the colour head: [PE(d), d, x] (models.py:87)
+        heads_x = torch.cat([rgb_p[0][:, pe:], sig_p[0]], 0)        # both heads' x columns: [64 + 64, F]
+        merged_w = heads_x @ w_last                                 # W_head W_last
+        merged_b = torch.cat([rgb_p[1], sig_p[1]], 0) + heads_x @ b_last
+        nc = rgb_p[0].size(0)
+        rgb_p = [torch.cat([rgb_p[0][:, :pe], merged_w[:nc]], 1), merged_b[:nc], *rgb_p[2:]]
+        sig_p = [merged_w[nc:], merged_b[nc:], *sig_p[2:]]
     return _RenderHeads.apply(feat, packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(sig_p),
                               accumulate_into_grad, arena, train, hint, stats, link, *sig_p, *rgb_p)

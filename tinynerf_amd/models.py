@@ -96,6 +96,9 @@ class _FusedMLP(Function):
         # this stack's output from the workspace rows (it has matched the row-view link before): the row-major y is then
         # allocated but never written
         rows_only = bool(scratch is not None and len(scratch) > 4 and scratch[4].pop("rows_only", False) and MATMUL == "f16x2")
+        # ... and scratch[4]["skip_last"] when it has merged this stack's last (plain Linear) layer into the heads' first layers
+        # (TN_MLP_SKIP_LAST): the stack then stops at its last hidden activation and offers THAT as rows
+        skip_last = bool(scratch is not None and len(scratch) > 4 and scratch[4].pop("skip_last", False) and rows_only)
         # training: the forward writes the activations straight into the backward's workspace (nothing is recomputed)
         ws, ws_bytes = None, 0
         # `recording` = torch.is_grad_enabled() at the call site: inside torch.no_grad() (infer(), the occupancy refresh)
@@ -111,14 +114,21 @@ class _FusedMLP(Function):
             link = scratch[2] if scratch is not None and len(scratch) > 2 else None
             if rows_only and link is not None:
                 desc.flags |= L.MLP_ROWS_ONLY
+                if skip_last:
+                    desc.flags |= L.MLP_SKIP_LAST
             L.call("tn_mlp_fwd_stash", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(ws_bytes))
             if link is not None:
                 # harness: wide stacks evaluated layer by layer keep y as [feature][32-sample] rows in their workspace and take
                 # d loss / d y in that layout (tn_mlp_rows_view): the render node behind this stack (fused._RenderHeads) reads
                 # / writes them there instead of going through row-major [n, 256] tensors
                 link.clear()
-                y_off, g_off, stride = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-                if L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(n), C.byref(y_off), C.byref(g_off), C.byref(stride)) == 0:
+                y_off, g_off, stride, m_off = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+                if desc.flags & L.MLP_SKIP_LAST:
+                    L.call_plain("tn_mlp_rows_view_hidden", C.byref(desc), C.c_int64(n), C.byref(y_off), C.byref(g_off), C.byref(m_off), C.byref(stride))
+                    link.update(ws=ws, y_rows=ws.data_ptr() + 4 * y_off.value, grad_rows=ws.data_ptr() + 4 * g_off.value,
+                                mask_rows=ws.data_ptr() + 4 * m_off.value, stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(),
+                                delivered=False, rows_only=True, skipped_last=True)
+                elif L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(n), C.byref(y_off), C.byref(g_off), C.byref(stride)) == 0:
                     link.update(ws=ws, y_rows=ws.data_ptr() + 4 * y_off.value, grad_rows=ws.data_ptr() + 4 * g_off.value,
                                 stride=stride.value, n=n, width=y.size(1), y_ptr=y.data_ptr(), delivered=False,
                                 rows_only=bool(desc.flags & L.MLP_ROWS_ONLY))
@@ -145,6 +155,7 @@ class _FusedMLP(Function):
         # harness (scratch[3]): weight gradients are added straight into param.grad where it exists (the optimizer pass zeroes it)
         ctx.param_refs = params if (scratch is not None and len(scratch) > 3 and scratch[3]) else None
         ctx.save_for_backward(x2, aux2, freqs, ws, *ps)
+        ctx.skip_last = bool(ws_bytes and (desc.flags & L.MLP_SKIP_LAST))
         ctx.cfg = (encoding, n_freqs, out_act)
         ctx.x_shape = x.shape
         return y.reshape(*lead, y.size(-1))
@@ -161,7 +172,11 @@ class _FusedMLP(Function):
             ctx.link["delivered"] = False
         gy = None if delivered else grad_y.reshape(n, -1).to(torch.float32).contiguous()
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs,
-                         (L.MLP_STASHED if ws_fwd is not None else 0) | (L.MLP_GRAD_Y_ROWS if delivered else 0))
+                         (L.MLP_STASHED if ws_fwd is not None else 0) | (L.MLP_GRAD_Y_ROWS if delivered else 0) |
+                         (L.MLP_SKIP_LAST if ctx.skip_last else 0))
+        if ctx.skip_last and not delivered:
+            raise RuntimeError("tinynerf_amd: this stack ran without its last layer (TN_MLP_SKIP_LAST) but its consumer did not deliver "
+                               "d loss / d (hidden activation) as workspace rows")
         refs = ctx.param_refs if ctx.param_refs is not None else [None] * len(ps)
         in_place = [r is not None and r.grad is not None and r.grad.stride() == p.stride() and r.grad.dtype == p.dtype for r, p in zip(refs, ps)]
         grads = [r.grad if ip else torch.zeros_like(p) for r, p, ip in zip(refs, ps, in_place)]
@@ -177,7 +192,10 @@ class _FusedMLP(Function):
         L.call("tn_mlp_bwd", dev, C.byref(desc), L.ptr(x2), L.ptr(aux2), L.ptr(gy), C.c_int64(n), gw, gb, L.ptr(gx),
                L.ptr(ws), C.c_int64(ws_bytes))
         gx_out = gx.reshape(ctx.x_shape) if gx is not None else None
-        return (gx_out, None, None, None, None, None, None, None, *[None if ip else g for g, ip in zip(grads, in_place)])
+        out = [None if ip else g for g, ip in zip(grads, in_place)]
+        if ctx.skip_last:                # the last layer's gradients arrive through the merged parameters (fused.render), not from here
+            out[-2:] = [None, None]
+        return (gx_out, None, None, None, None, None, None, None, *out)
 
 
 def _linear_params(net: torch.nn.Sequential) -> List[torch.Tensor]:

@@ -271,6 +271,23 @@ typedef struct tn_mlp_desc {
     int64_t grad_x_mask_tile_stride;          /* dwords */
 } tn_mlp_desc;
 
+/* Merged parameters for TN_MLP_SKIP_LAST (reference models.py:59-89, 239-247: Linear(F, F) -> Linear(F [+ other columns], rows), nothing
+ * in between).  Per consumer ("head"): weight [rows][ld] whose columns [col0, col0 + F) multiply the stack's output, bias [rows].
+ *   tn_linear_merge_fwd: out_weight[:, col0 .. col0 + F) = weight[:, col0 .. col0 + F) w_last, the other columns copied;
+ *                        out_bias = bias + weight[:, col0 .. col0 + F) b_last.
+ *   tn_linear_merge_bwd: grad_merged_* = gradients of those merged parameters; ADDS the gradients of the original parameters to
+ *                        out_weight / out_bias (now: gradient buffers of weight / bias) and to grad_w_last [F][F] / grad_b_last [F]. */
+#define TN_MERGE_MAX_HEADS 4
+typedef struct tn_merge_head {
+    const float *weight, *bias;
+    int32_t rows, ld, col0, reserved;
+    float *out_weight, *out_bias;
+    const float *grad_merged_weight, *grad_merged_bias;       /* tn_linear_merge_bwd only */
+} tn_merge_head;
+int tn_linear_merge_fwd(int32_t n_heads, const tn_merge_head *heads, const float *w_last, const float *b_last, int32_t F, void *stream);
+int tn_linear_merge_bwd(int32_t n_heads, const tn_merge_head *heads, const float *w_last, const float *b_last, int32_t F,
+                        float *grad_w_last, float *grad_b_last, void *stream);
+
 /* One plain Linear (reference src/models.py:183-191: KPlanesExplicitOpacityDecoder.net = torch.nn.Linear(96, 96), the only
  * Linear on the reference's path outside an MLP stack): y [n, out] = x [n, in] weight^T + bias (bias may be NULL), weight
  * [out, in] row-major as torch.nn.Linear holds it, 1 <= in, out <= 128, fp32 MFMA. */

@@ -519,6 +519,70 @@ def test_paired_data_gradient_behind_the_wide_stacks(method, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vanilla", "cobafa"])
+def test_last_layer_merged_into_the_heads(method, monkeypatch):
+    """Round 5 (TN_MLP_SKIP_LAST): the stack's last layer is Linear(F, F) and both heads begin with a Linear on its output (reference
+    models.py:59-89, 239-247) -- from the second training forward on the harness folds the former into the latter (merged parameters once per
+    step, the stack stops at its last hidden activation, the feature tensor never exists).  Same function, other association of the
+    products: every step's loss and all parameters after four steps equal the unmerged run's to fp32 rounding, the last layer's
+    parameters included (their gradients arrive through the merge by the chain rule)."""
+    from tinynerf_amd import fused, models
+    from tinynerf_amd.run import TrainConfig, Trainer
+    if models.MATMUL != "f16x2":
+        pytest.skip("the merge rides on the f16x2 heads' row handoff")
+    o, d, rgb = _scene()
+    out = {}
+    for merge in (False, True):
+        monkeypatch.setattr(fused, "MERGE_LAST", merge)
+        cfg = TrainConfig(method=method, scene_type="aabb", batch_size=256, n_samples=32, seed=3, occupancy_res=32, deterministic=True)
+        tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+        for group in tr.optimizer.param_groups:
+            group["lr"] = 1e-3
+        if method == "cobafa":
+            tr.renderer.feature_module.dropout.p = 0.0
+        ls, skipped = [], []
+        for _ in range(4):
+            tr.step()
+            ls.append(tr.loss_value())
+            prod = tr.renderer.__dict__.get("_rows_producer")
+            skipped.append(bool(prod is not None and prod.__dict__["scratch"][2].get("skipped_last")))
+        assert skipped == ([False, True, True, True] if merge else [False] * 4), skipped
+        out[merge] = (ls, {k: v.detach().float().cpu().numpy().copy() for k, v in tr.renderer.state_dict().items()})
+    assert out[True][0][0] == out[False][0][0]
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5)
+    moved = 0
+    for k, v in out[False][1].items():
+        w = out[True][1][k]
+        assert np.all(np.isfinite(w)), k
+        np.testing.assert_allclose(w, v, rtol=0, atol=5e-5 * max(1e-3, float(np.abs(v).max())), err_msg=k)
+        moved += 1
+    assert moved > 10
+
+
+@pytest.mark.gpu
+def test_linear_merge_kernels_against_autograd():
+    """tn_linear_merge_fwd / _bwd == the torch expressions they replace and their autograd (fp64 reference)."""
+    from tinynerf_amd import fused
+    torch.manual_seed(5)
+    for F, pe in ((256, 51), (128, 51)):
+        ps = [torch.randn(64, pe + F, device=DEV) * 0.1, torch.randn(64, device=DEV), torch.randn(64, F, device=DEV) * 0.1, torch.randn(64, device=DEV),
+              torch.randn(F, F, device=DEV) * 0.1, torch.randn(F, device=DEV)]
+        for p in ps:
+            p.requires_grad_(True)
+        outs = fused._MergeLast.apply(False, pe, *ps)
+        gs = [torch.randn_like(o_) for o_ in outs]
+        got = torch.autograd.grad(outs, ps, gs)
+        ref_p = [p.detach().double().requires_grad_(True) for p in ps]
+        wc, bc, ws, bs, wl, bl = ref_p
+        ref = (torch.cat([wc[:, :pe], wc[:, pe:] @ wl], 1), bc + wc[:, pe:] @ bl, ws @ wl, bs + ws @ bl)
+        want = torch.autograd.grad(ref, ref_p, [g.double() for g in gs])
+        for a_, b_ in zip(outs, ref):
+            np.testing.assert_allclose(a_.detach().cpu().numpy(), b_.detach().cpu().numpy(), rtol=0, atol=2e-6 * float(b_.abs().max()))
+        for a_, b_ in zip(got, want):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=0, atol=2e-6 * float(b_.abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("where", ["plane", "colour_weight", "sigma_bias"])
 def test_a_non_finite_parameter_surfaces_as_the_reference_nan_loss(where):
     """torch.relu hands a NaN on (models.py:7-28), so in the reference ONE non-finite parameter makes the loss NaN at the next step

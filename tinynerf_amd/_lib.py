@@ -48,6 +48,15 @@ class MlpDesc(C.Structure):
     ]
 
 
+class MergeHead(C.Structure):
+    _fields_ = [
+        ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("rows", C.c_int32), ("ld", C.c_int32), ("col0", C.c_int32), ("reserved", C.c_int32),
+        ("out_weight", C.c_void_p), ("out_bias", C.c_void_p),
+        ("grad_merged_weight", C.c_void_p), ("grad_merged_bias", C.c_void_p),
+    ]
+
+
 class KPlanesDesc(C.Structure):
     _fields_ = [
         ("n_scales", C.c_int32), ("channels", C.c_int32),

@@ -28,6 +28,7 @@ STRICT = ["-ffp-contract=off"]          # one rounding per fp op
 FAST = ["-ffp-contract=fast"]
 SOURCES = {
     "common.hip": FAST,
+    "merge.hip": FAST,
     "weights.hip": FAST,
     "sampler.hip": STRICT,
     "planes_reg.hip": FAST,

@@ -396,6 +396,48 @@ class _RenderKPlanes(Function):
         return (None, None, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
+class _MergeLast(Function):
+    """(W_c[:, x] W_last, b_c + W_c[:, x] b_last, W_s W_last, b_s + W_s b_last) and the chain rule back to the six original tensors: one
+    small launch each way (merge.hip) -- the same five matmuls through torch and autograd were ~35 launches, 0.26 ms per step."""
+
+    @staticmethod
+    def forward(ctx: Any, accumulate: bool, pe: int, wc: torch.Tensor, bc: torch.Tensor, ws: torch.Tensor, bs: torch.Tensor,
+                w_last: torch.Tensor, b_last: torch.Tensor):  # type: ignore
+        dev = L.require_cuda(wc, bc, ws, bs, w_last, b_last)
+        ps = [t.contiguous() for t in (wc, bc, ws, bs, w_last, b_last)]
+        F = w_last.size(0)
+        outs = [torch.empty_like(t) for t in ps[:4]]
+        heads = (L.MergeHead * 2)()
+        for k, col0 in ((0, pe), (1, 0)):
+            heads[k].weight, heads[k].bias = ps[2 * k].data_ptr(), ps[2 * k + 1].data_ptr()
+            heads[k].rows, heads[k].ld, heads[k].col0 = ps[2 * k].size(0), ps[2 * k].size(1), col0
+            heads[k].out_weight, heads[k].out_bias = outs[2 * k].data_ptr(), outs[2 * k + 1].data_ptr()
+        L.call("tn_linear_merge_fwd", dev, C.c_int32(2), heads, L.ptr(ps[4]), L.ptr(ps[5]), C.c_int32(F))
+        ctx.save_for_backward(*ps)
+        ctx.cfg = (accumulate, pe)
+        ctx.refs = (wc, bc, ws, bs, w_last, b_last) if accumulate else None
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx: Any, g_wc: torch.Tensor, g_bc: torch.Tensor, g_ws: torch.Tensor, g_bs: torch.Tensor):  # type: ignore
+        ps = ctx.saved_tensors
+        accumulate, pe = ctx.cfg
+        dev = ps[0].device
+        gm = [g.contiguous() if g is not None else torch.zeros_like(p) for g, p in zip((g_wc, g_bc, g_ws, g_bs), ps[:4])]
+        refs = ctx.refs if ctx.refs is not None else [None] * 6
+        in_place = [r is not None and r.is_leaf and r.grad is not None and r.grad.is_contiguous() and r.grad.dtype == p.dtype
+                    for r, p in zip(refs, ps)]
+        grads = [r.grad if ip else torch.zeros_like(p) for r, p, ip in zip(refs, ps, in_place)]
+        heads = (L.MergeHead * 2)()
+        for k, col0 in ((0, pe), (1, 0)):
+            heads[k].weight, heads[k].bias = ps[2 * k].data_ptr(), ps[2 * k + 1].data_ptr()
+            heads[k].rows, heads[k].ld, heads[k].col0 = ps[2 * k].size(0), ps[2 * k].size(1), col0
+            heads[k].out_weight, heads[k].out_bias = grads[2 * k].data_ptr(), grads[2 * k + 1].data_ptr()
+            heads[k].grad_merged_weight, heads[k].grad_merged_bias = gm[2 * k].data_ptr(), gm[2 * k + 1].data_ptr()
+        L.call("tn_linear_merge_bwd", dev, C.c_int32(2), heads, L.ptr(ps[4]), L.ptr(ps[5]), C.c_int32(ps[4].size(0)), L.ptr(grads[4]), L.ptr(grads[5]))
+        return (None, None, *[None if ip else g for g, ip in zip(grads, in_place)])
+
+
 class _RenderHeads(Function):
     """The part of NerfRenderer.forward behind the feature module (core.py:239-267) for ANY field with the Vanilla decoders
     (Vanilla NeRF, Cobafa): sigma head -> weights scan -> colour head -> composite as one autograd node; ``feat`` is an
@@ -634,13 +676,9 @@ def render(renderer, packed: torch.Tensor, info: torch.Tensor, thr: float, accum
     if link is not None and link.get("skipped_last"):
         # the stack stopped at its last hidden activation h (rows): heads on h with the last layer folded into their first layers
         w_last, b_last = producer.params()[-2:]
-        F = feat.size(1)
-        pe = rgb_p[0].size(1) - F                                   # torch column order of the colour head: [PE(d), d, x] (models.py:87)
-        heads_x = torch.cat([rgb_p[0][:, pe:], sig_p[0]], 0)        # both heads' x columns: [64 + 64, F]
-        merged_w = heads_x @ w_last                                 # W_head W_last
-        merged_b = torch.cat([rgb_p[1], sig_p[1]], 0) + heads_x @ b_last
-        nc = rgb_p[0].size(0)
-        rgb_p = [torch.cat([rgb_p[0][:, :pe], merged_w[:nc]], 1), merged_b[:nc], *rgb_p[2:]]
-        sig_p = [merged_w[nc:], merged_b[nc:], *sig_p[2:]]
+        pe = rgb_p[0].size(1) - feat.size(1)                        # torch column order of the colour head: [PE(d), d, x] (models.py:87)
+        wc, bc, ws_, bs_ = _MergeLast.apply(accumulate_into_grad, pe, rgb_p[0], rgb_p[1], sig_p[0], sig_p[1], w_last, b_last)
+        rgb_p = [wc, bc, *rgb_p[2:]]
+        sig_p = [ws_, bs_, *sig_p[2:]]
     return _RenderHeads.apply(feat, packed.contiguous(), info.contiguous(), bg, float(thr), cd.pe.freqs, cd.n_freqs, len(sig_p),
                               accumulate_into_grad, arena, train, hint, stats, link, *sig_p, *rgb_p)

@@ -236,7 +236,7 @@ def test_ranks_equal_one_rank_on_the_union(method, world, smooth, sharded):
                 if sharded and ".plane" in k:           # reduce-scatter: the rank holds the sum on ITS rows of the plane only
                     r0, r1 = Trainer._own_rows(ref.shape[2], rank, world)
                     got, ref = got[:, :, r0:r1], ref[:, :, r0:r1]
-                if ref.size >= (1 << 16):
+                if ref.size >= (1 << 16) or ".plane" in k:           # (a rank's row slice of a small plane is still a sum of atomics)
                     # a grid voxel / plane texel sums thousands of atomics whose terms cancel (+-1e-3 summing to 1e-4): single
                     # elements carry 1e-4 of the largest element as order noise, and from the second step on Adam (eps 1e-15)
                     # turns that noise into full-size updates of the elements it hits; the tensor as a whole must agree to

@@ -29,6 +29,7 @@ FAST = ["-ffp-contract=fast"]
 SOURCES = {
     "common.hip": FAST,
     "merge.hip": FAST,
+    "heads_dx.hip": FAST,
     "weights.hip": FAST,
     "sampler.hip": STRICT,
     "planes_reg.hip": FAST,

@@ -25,6 +25,12 @@
 extern "C" int64_t tn_mlp_bwd_layers_workspace_bytes(const tn_mlp_desc *desc, int64_t n);
 extern "C" int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux, const float *grad_y, int64_t n,
                                  float *const *grad_weights, float *const *grad_biases, float *grad_x, float *workspace, void *stream);
+extern "C" int tn_mlp_wgrad_rows2(const float *g_rows, int64_t g_stride, const float *g_rows2, int64_t g_stride2, const float *a_rows,
+                                  int64_t a_stride, int na, float *gW, int ldw, int col0, float *gB, float *gW2, int ldw2, int col02,
+                                  float *gB2, int64_t n, void *stream);
+extern "C" int tn_heads_dx_rows(const float *w_a, int ld_a, int col0_a, const float *w_b, int ld_b, int col0_b, const float *g_a, int64_t gs_a,
+                                const float *g_b, int64_t gs_b, int F, float *out, int64_t out_stride, const void *mask, int64_t mask_stride,
+                                int64_t n, void *stream);
 extern "C" int tn_mlp_wgrad_lean_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux, int64_t n,
                                       float *const *gw, float *const *gb, float *const *gws, float *const *gbs, const float *ws_a,
                                       const float *ws_b, void *stream);
@@ -74,7 +80,7 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 // PAIR (with STASHED): a second head `b` with ONE hidden layer of the same width that reads the same x (the K-Planes
 // sigma head next to the colour head): its data gradient runs in the same pass, so x's gradient is written once as the
 // sum of both heads instead of written by one launch and read-modified-written by the next.
-struct PairArgs { MlpArgs b; const float *gy; float *stash; };
+struct PairArgs { MlpArgs b; const float *gy; float *stash; int64_t g0_stride = 0; };
 
 // KP (with STASHED, PAIR; north star: the K-Planes lookup in the same launch as the MLP, backward half): x is the K-Planes
 // feature row, so d(loss)/d(x) is not an output but an intermediate: every wave keeps the three 32-column blocks of its
@@ -111,18 +117,23 @@ __device__ __forceinline__ void first_dgrad(const float *__restrict__ Wf, int sf
     }
 }
 
-template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false, bool PAIR = false, bool KP = false>
+// G0B (with STASHED, without PAIR; round 5, heads behind a wide stack): grad_x additionally takes W_0b^T G_0b of ANOTHER head whose data
+// gradient already ran WITHOUT its grad_x part -- G_0b are rows of that head's workspace (pr.stash + tile * pr.g0_stride), pr.b holds
+// only its first layer's x columns.  The 5-layer colour head's chain then needs no first layer in LDS (16 waves per CU instead of 8),
+// and the 2-layer sigma head's launch -- which otherwise read, added to and re-wrote the colour head's grad_x rows -- writes the sum once.
+template <int H, int NH, int WPB, bool STASHED, bool ACCUM = false, bool PAIR = false, bool KP = false, bool G0B = false>
 __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const float *__restrict__ x, const float *__restrict__ aux,
                                                              const float *__restrict__ gy, int64_t n, float *__restrict__ gx,
                                                              float *__restrict__ stash, PairArgs pr, KpBwd kp)
 {
     static_assert(!KP || (STASHED && PAIR && !ACCUM && H == 64), "the fused scatter belongs to the paired, stashed chain of the width-64 heads");
+    static_assert(!G0B || (STASHED && !PAIR && !KP && !ACCUM), "G0B: another head's G_0 rows join a stashed, unpaired chain's grad_x");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = H / 32;
     constexpr int L = NH + 1;
     stage_weights(a, lds);
     const float *ldsb = lds + a.lds_floats;
-    if constexpr (PAIR) stage_weights(pr.b, lds + a.lds_floats);
+    if constexpr (PAIR || G0B) stage_weights(pr.b, lds + a.lds_floats);
     __syncthreads();
     if constexpr (STASHED && NH > 1) {
         // nothing is recomputed: the hidden layers are only ever read transposed (W_l^T G_l), so transpose them in place once
@@ -142,7 +153,6 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
     const int64_t n_tiles = (n + 31) >> 5;
     const int G0 = a.K0_pad >> 3;
     const int out = a.out_dim;
-    const bool skip_g = (PAIR && !KP && STASHED) ? a.skip_g_rows != 0 : false;      // (second column window of a split launch; never with the fused scatter)
 
     // STASHED: the per-tile inputs (ReLU masks, last pre-activation, output gradient) of the NEXT tile are requested at the
     // top of the current one.  VMEM operations of a wave retire in order, so a load issued after a tile's ~150 row stores
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 const int64_t tn_ = tile + (int64_t)gridDim.x * WPB;
                 fetch_tile(tn_ < n_tiles ? tn_ : n_tiles - 1);       // before this tile's stores
             }
-            if (PAIR && !skip_g) {                            // head b: g_pre rows, G_0 = relu'(H_1) * (W_1^T g_pre), G_0 rows
+            if constexpr (PAIR) {                                    // head b: g_pre rows, G_0 = relu'(H_1) * (W_1^T g_pre), G_0 rows
                 float *stb = pr.stash + tile * (int64_t)(Rb * 32);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                if (h == 0 && !skip_g) stP[o * 32 + j] = gp[o];
+                if (h == 0) stP[o * 32 + j] = gp[o];
             (void)stQ; (void)stM;
         } else {
         const float *xrow = x + (valid ? row : 0) * a.in_dim;
@@ -310,11 +320,6 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         }
         TN_PTB(0)
         f32x16 G[T];
-        if (STASHED && skip_g) {
-            // second column window of a split launch (launch_v2): G_0 is in the workspace already, nothing of the chain is repeated
-#pragma unroll
-            for (int ob = 0; ob < T; ++ob) tn::mlp::load_rows(stG, G[ob], ob, j, h);
-        } else {
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) {
 #pragma unroll
@@ -335,10 +340,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
         // ---------------- hidden layers, last to first ----------------
         static_for<NH - 1>([&](auto lc) {
             constexpr int l = NH - 1 - decltype(lc)::value;     // l = NH-1 .. 1 : G holds G_l
-            if (!skip_g) {
 #pragma unroll
-                for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
-            }
+            for (int ob = 0; ob < T; ++ob) store_rows(stG + l * H * 32, G[ob], ob, j, h);
             const float *Wl = lds + a.w_off[l];
             constexpr int sl = H + 4;                       // stride of every hidden layer (mlp_stage.h plan()): a constant lets the
                                                             // row offsets below become ds_read immediates instead of VALU adds
@@ -382,11 +385,8 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 for (int r = 0; r < 16; ++r) G[kt][r] = mask_keep(Gn[kt][r], mask[l - 1][kt], r);
             }
         });
-        }
-        if (!skip_g) {
 #pragma unroll
-            for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);      // G_0
-        }
+        for (int ob = 0; ob < T; ++ob) store_rows(stG, G[ob], ob, j, h);          // G_0
 
         TN_PTB(1)
         // ---------------- grad_x = W_0^T G_0 over the x slots ----------------
@@ -394,15 +394,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             f32x16 gacc[KP ? 3 : 1];                // KP: d loss / d features of the three scales, kept for the scatter
             const float *W0 = lds + a.w_off[0];
             const int s0 = a.stride[0];
-            const int n_kt = ((a.gx_ncols ? a.gx_ncols : a.in_dim) + 31) >> 5;      // (window of x columns: LDS holds these columns of W_0)
-            const int kt0 = a.gx_col0 >> 5;
+            const int n_kt = (a.in_dim + 31) >> 5;
             f32x16 Gb[T];
-            if constexpr (PAIR) {
-                if (skip_g) {
-                    const float *stb = pr.stash + tile * (int64_t)(Rb * 32);
+            if constexpr (PAIR) first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
+            if constexpr (G0B) {
+                const float *g0b = pr.stash + tile * pr.g0_stride;
 #pragma unroll
-                    for (int ob = 0; ob < T; ++ob) tn::mlp::load_rows(stb + H * 32, Gb[ob], ob, j, h);
-                } else first_dgrad<H>(ldsb + pr.b.w_off[1], pr.b.stride[1], pr.b.out_dim, gpb, pmask, h, Gb);
+                for (int ob = 0; ob < T; ++ob) tn::mlp::load_rows(g0b, Gb[ob], ob, j, h);
             }
             const int64_t rowc = row < n ? row : n - 1;
             f32x4 old[4], oldn[4];
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
             if constexpr (ACCUM) {
                 if (gxr == nullptr) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * kt0 + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 8 * q + 4 * h);
                 }
             }
 #pragma clang loop unroll(disable)
@@ -421,13 +419,13 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 if constexpr (ACCUM) {
-                    if (gxr != nullptr) tn::mlp::load_rows(gxr + (kt0 + kt) * 32 * 32, acc, 0, j, h);     // the MFMAs below accumulate on top
+                    if (gxr != nullptr) tn::mlp::load_rows(gxr + kt * 32 * 32, acc, 0, j, h);     // the MFMAs below accumulate on top
                 }
                 if constexpr (ACCUM) {
                     if (gxr == nullptr) {
                     const int ktn = kt + 1 < n_kt ? kt + 1 : kt;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * (kt0 + ktn) + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; ++q) oldn[q] = *reinterpret_cast<const f32x4 *>(gx + rowc * a.in_dim + 32 * ktn + 8 * q + 4 * h);
                     }
                 }
                 {
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
                     }
                 }
-                if constexpr (PAIR) {                                 // + W_0b^T G_0b (x slots of head b are columns 0 .. in_dim-1)
+                if constexpr (PAIR || G0B) {                          // + W_0b^T G_0b (x slots of head b are columns 0 .. in_dim-1)
                     const float *W0b = ldsb + pr.b.w_off[0];
                     const int s0b = pr.b.stride[0];
 #pragma unroll
@@ -467,11 +465,11 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 }
                 if (gxr != nullptr) {               // rows of samples >= n carry zeros (their output gradient was zeroed)
                     if (!KP && a.gx_mask_rows != nullptr) {      // x is a hidden activation of the producer: d / d (its pre-activation)
-                        const unsigned mb = a.gx_mask_rows[tile * a.gx_mask_stride + (kt0 + kt) * 64 + lane];
+                        const unsigned mb = a.gx_mask_rows[tile * a.gx_mask_stride + kt * 64 + lane];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[r] = mask_keep(acc[r], mb, r);
                     }
-                    store_rows(gxr + (kt0 + kt) * 32 * 32, acc, 0, j, h);
+                    store_rows(gxr + kt * 32 * 32, acc, 0, j, h);
                     continue;
                 }
                 if constexpr (ACCUM) {
@@ -481,7 +479,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                             f32x4 v = old[q];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) v[u] += acc[4 * q + u];
-                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + 32 * (kt0 + kt) + 8 * q + 4 * h) = v;
+                            *reinterpret_cast<f32x4 *>(gx + row * a.in_dim + 32 * kt + 8 * q + 4 * h) = v;
                         }
                     }
 #pragma unroll
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(WPB * 64) void mlp_chain_kernel(MlpArgs a, const fl
                 } else if (valid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int f0 = 32 * (kt0 + kt) + 8 * q + 4 * h;
+                        const int f0 = 32 * kt + 8 * q + 4 * h;
                         if (f0 + 3 < a.in_dim && (a.in_dim & 3) == 0) {
                             f32x4 v;
 #pragma unroll
@@ -933,12 +931,11 @@ bool v2_supported(const tn_mlp_desc *d) { return two_pass_supported(d); }
 // phase bit 0: data-gradient chain, bit 1: weight gradient.  pair != nullptr: the chain also runs head `pair->b`.
 // first layer of a head without its aux columns: the stashed chain only ever reads W_0's x columns (W_0^T G_0 over the x
 // slots), and the 14 KB this saves in LDS are what the fused scatter's per-wave tiles need
-MlpArgs compact_first_layer(const MlpArgs &a, int col0 = 0, int ncols = 0)
+MlpArgs compact_first_layer(const MlpArgs &a)
 {
     MlpArgs c = a;
     const int H = a.N[0];
-    c.K0_pad = ((ncols ? ncols : a.in_dim) + 7) & ~7;
-    c.gx_col0 = col0; c.gx_ncols = ncols;
+    c.K0_pad = (a.in_dim + 7) & ~7;
     int off = 0;
     for (int l = 0; l < a.n_layers; ++l) {
         const int Kp = l == 0 ? c.K0_pad : H;
@@ -949,6 +946,34 @@ MlpArgs compact_first_layer(const MlpArgs &a, int col0 = 0, int ncols = 0)
     }
     c.lds_floats = off;
     return c;
+}
+
+// ... and nothing but that layer (G0B partner)
+MlpArgs first_layer_only(const MlpArgs &a)
+{
+    MlpArgs c = compact_first_layer(a);
+    c.n_layers = 1;
+    c.lds_floats = c.b_off[0] + ((a.N[0] + 3) & ~3);
+    return c;
+}
+
+// data gradient of the 2-layer head `b` with the first-layer part of head `a` folded into its grad_x (mlp_chain_kernel, G0B)
+int launch_chain_g0b(const MlpArgs &b, const MlpArgs &a, const float *x, const float *gy_b, int64_t n, float *gx, float *stash_b,
+                     const float *g0_rows_a, int64_t g0_stride_a, hipStream_t s)
+{
+    constexpr int WPS = 8;                     // (133 KB of LDS at 256 columns: one workgroup per CU anyway; 10 waves capped at 168 VGPRs spill 29)
+    PairArgs pr;
+    pr.b = first_layer_only(a); pr.gy = nullptr; pr.stash = const_cast<float *>(g0_rows_a); pr.g0_stride = g0_stride_a;
+    const size_t lds_bytes = ((size_t)b.lds_floats + (size_t)pr.b.lds_floats) * 4;
+    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: both first layers do not fit LDS");
+    auto kern = mlp_chain_kernel<64, 1, WPS, true, false, false, false, true>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (WPS * 64)));
+    const int64_t blocks = std::min<int64_t>((n_tiles + WPS - 1) / WPS, 256 * per_cu);
+    kern<<<dim3((unsigned)blocks), dim3(WPS * 64), lds_bytes, s>>>(b, x, nullptr, gy_b, n, gx, stash_b, pr, KpBwd());
+    return tn::check_launch("mlp_chain_kernel(g0b)");
 }
 
 template <int H, int NH>
@@ -984,38 +1009,20 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (stashed && a.accum_gx && (gx != nullptr || a.gx_rows != nullptr) && a.enc != TN_ENC_POSENC && (a.in_dim & 31) == 0) kern = mlp_chain_kernel<H, NH, WPS, true, true>;
     PairArgs pr;
     pr.gy = nullptr; pr.stash = nullptr;
-    MlpArgs a1 = a;                           // (the launch's own copy: a column window of W_0 may replace the full first layer)
-    int windows = 1;
     if (pair) {
         pr = *pair;
         if constexpr (NH == 4) kern = mlp_chain_kernel<H, NH, WPP, true, false, true>;
         else return tn::fail(TN_E_CONFIG, "mlp_bwd: the paired chain is built for the 5-layer colour head");
         wpb = WPP;
         lds_bytes += (size_t)pr.b.lds_floats * 4;
-        if (lds_bytes > (size_t)LDS_LIMIT_BYTES && stashed && (a.in_dim & 63) == 0 && a.enc == TN_ENC_AUX_CAT && pair->b.enc == TN_ENC_NONE) {
-            // heads behind a 256-wide stack: W_0 of both heads (2 x 64 x 256 floats) and the hidden layers do not fit LDS together.
-            // The stashed chain reads W_0 only for grad_x = W_0^T G_0, one 32-column block at a time: two launches, each with one half of
-            // the x columns of both first layers in LDS; the second one reads both heads' G_0 rows, which the first one wrote (the hidden chain is 60 % of a launch's fp32 MFMAs: not repeated).
-            windows = 2;
-            a1 = compact_first_layer(a, 0, a.in_dim / 2);
-            pr.b = compact_first_layer(pair->b, 0, a.in_dim / 2);
-            lds_bytes = ((size_t)a1.lds_floats + (size_t)pr.b.lds_floats) * 4;
-        }
     } else pr.b = a;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd: weights do not fit LDS");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(LDS_LIMIT_BYTES / lds_bytes, 2048 / (wpb * 64)));
     const int64_t blocks = std::min<int64_t>((n_tiles + wpb - 1) / wpb, 256 * per_cu);
-    for (int w = 0; w < windows; ++w) {
-        if (w == 1) {
-            a1 = compact_first_layer(a, a.in_dim / 2, a.in_dim / 2);
-            pr.b = compact_first_layer(pair->b, a.in_dim / 2, a.in_dim / 2);
-            a1.skip_g_rows = 1;
-        }
-        kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a1, x, aux, gy, n, gx, stash, pr, KpBwd());
-        if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
-    }
+    kern<<<dim3((unsigned)blocks), dim3(wpb * 64), lds_bytes, s>>>(a, x, aux, gy, n, gx, stash, pr, KpBwd());
+    if (int rc = tn::check_launch("mlp_chain_kernel")) return rc;
     }
     if (!(phase & 2)) return TN_OK;
 
@@ -1035,7 +1042,8 @@ int launch_v2(const MlpArgs &a, const tn_mlp_desc *d, const float *x, const floa
     if (x_rows) {
         const int extra_r = extra_rows(a.enc, a.in_dim, a.K0_pad);
         const int col0 = (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) ? a.K0 - a.in_dim : 0;      // torch order [PE(d), d, x]
-        if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)NH * H * 32, (int64_t)stash_rows(H, NH, extra_r) * 32, H, a.x_rows, a.x_rows_stride,
+        if (a.x_wgrad_done) {}              // (tn_mlp_bwd_pair: both heads' x columns went out in one launch, tn_mlp_wgrad_rows2)
+        else if (int rc = tn_mlp_wgrad_rows(stash + (int64_t)NH * H * 32, (int64_t)stash_rows(H, NH, extra_r) * 32, H, a.x_rows, a.x_rows_stride,
                                        a.in_dim, gw[0], a.K0, col0, a.in_dim, gb[0], n, s)) return rc;
         w.tk_skip = a.in_dim / 32;
     }
@@ -1196,10 +1204,58 @@ static int bwd_pair_common(const tn_mlp_desc *desc, const tn_mlp_desc *partner, 
         return tn_mlp_wgrad_lean_pair(desc, partner, x, aux, n, grad_weights, grad_biases, partner_grad_weights, partner_grad_biases,
                                       (const float *)workspace, (const float *)partner_workspace, stream);
     }
-    if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr,
-                                 (chain ? 1 : 0) | (wgrad ? 2 : 0), kpb)) return rc;
+    // Heads behind a wide stack (x and grad_x as rows of its workspace): the colour head's chain runs WITHOUT its grad_x part (no first
+    // layer in LDS), and the sigma head's launch adds W_0c^T G_0c -- G_0c read back as rows -- to its own W_0s^T G_0s and writes the sum
+    // once (mlp_chain_kernel, G0B).  Before: the colour launch wrote grad_x, the sigma launch read it, added and wrote it again
+    // (0.67 + 0.54 ms per 2^20 samples at 256 columns; one paired launch does not fit LDS there and, as two column windows, was slower).
+    const bool rows_split = kpb == nullptr && a.gx_rows != nullptr && b.gx_rows == a.gx_rows && a.x_rows != nullptr && grad_x == nullptr &&
+                            a.enc == TN_ENC_AUX_CAT && (a.in_dim & 31) == 0 &&
+                            ((size_t)b.lds_floats + (size_t)first_layer_only(a).lds_floats) * 4 <= (size_t)LDS_LIMIT_BYTES;
+    const bool fits = kpb != nullptr || ((size_t)a.lds_floats + (size_t)b.lds_floats) * 4 <= (size_t)LDS_LIMIT_BYTES;
+    if (chain) {
+        if (rows_split) {
+            MlpArgs a0 = a;
+            a0.gx_rows = nullptr;                 // (no grad_x output: the launch stops at G_0)
+            if (int rc = launch_v2_h<64>(a0, desc, x, aux, grad_y, n, grad_weights, grad_biases, nullptr, (float *)workspace, true, s, nullptr, 1)) return rc;
+            if (a.f2 && b.f2 && (a.in_dim == 128 || a.in_dim == 256)) {
+                // f16x2: the sigma head's chain stops at G_0 as well, and grad_x = W_0c[:, x]^T G_0c + W_0s^T G_0s is a launch of its own on
+                // the fp16 matrix cores (heads_dx.hip): 6 k instead of 33 k matrix-pipe cycles per tile, bound by the rows it writes
+                MlpArgs b0 = b;
+                b0.gx_rows = nullptr;
+                if (int rc = launch_v2_h<64>(b0, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
+                                             (float *)partner_workspace, true, s, nullptr, 1)) return rc;
+                const int col0 = a.K0 - a.in_dim;                    // torch order [PE(d), d, x]
+                if (int rc = tn_heads_dx_rows(desc->weights[0], a.K0, col0, partner->weights[0], b.K0, 0,
+                                              (const float *)workspace + (int64_t)4 * 64 * 32, (int64_t)stash_rows(64, 4, 0) * 32,
+                                              (const float *)partner_workspace + (int64_t)1 * 64 * 32, (int64_t)stash_rows(64, 1, 0) * 32, a.in_dim,
+                                              a.gx_rows, a.gx_rows_stride, a.gx_mask_rows, a.gx_mask_stride, n, s)) return rc;
+            } else if (int rc = launch_chain_g0b(b, a, x, partner_grad_y, n, nullptr, (float *)partner_workspace,
+                                                 (const float *)workspace + (int64_t)4 * 64 * 32, (int64_t)stash_rows(64, 4, 0) * 32, s)) return rc;
+        } else if (fits) {
+            if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr, 1, kpb)) return rc;
+        } else {
+            if (int rc = launch_v2_h<64>(a, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, nullptr, 1)) return rc;
+            MlpArgs b1 = b;
+            b1.accum_gx = 1;
+            if (int rc = launch_v2_h<64>(b1, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, grad_x,
+                                         (float *)partner_workspace, true, s, nullptr, 1)) return rc;
+        }
+    }
     if (!wgrad) return TN_OK;
-    return launch_v2_h<64>(b, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
+    // first layers over the x columns: with x as rows of the producer's workspace both heads' tiles go out in ONE launch (x is 80 % of
+    // what a single-head launch reads at 256 columns)
+    MlpArgs aw = a, bw = b;
+    if (a.x_rows != nullptr && b.x_rows == a.x_rows && a.x_rows_stride == b.x_rows_stride && (a.in_dim == 128 || a.in_dim == 256) &&
+        x_slots(a.enc, a.in_dim) == a.in_dim && extra_rows(a.enc, a.in_dim, a.K0_pad) == 0) {
+        const int col0 = (a.enc == TN_ENC_DIR_CAT || a.enc == TN_ENC_AUX_CAT) ? a.K0 - a.in_dim : 0;      // torch order [PE(d), d, x]
+        if (int rc = tn_mlp_wgrad_rows2((const float *)workspace + (int64_t)4 * 64 * 32, (int64_t)stash_rows(64, 4, 0) * 32,
+                                        (const float *)partner_workspace + (int64_t)1 * 64 * 32, (int64_t)stash_rows(64, 1, 0) * 32,
+                                        a.x_rows, a.x_rows_stride, a.in_dim, grad_weights[0], a.K0, col0, grad_biases[0],
+                                        partner_grad_weights[0], b.K0, 0, partner_grad_biases[0], n, s)) return rc;
+        aw.x_wgrad_done = 1; bw.x_wgrad_done = 1;
+    }
+    if (int rc = launch_v2_h<64>(aw, desc, x, aux, grad_y, n, grad_weights, grad_biases, grad_x, (float *)workspace, true, s, &pr, 2, kpb)) return rc;
+    return launch_v2_h<64>(bw, partner, x, nullptr, partner_grad_y, n, partner_grad_weights, partner_grad_biases, nullptr,
                            (float *)partner_workspace, true, s, nullptr, 2);
 }
 

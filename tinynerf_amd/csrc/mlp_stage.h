@@ -29,10 +29,7 @@ struct MlpArgs {
     int f2;                // TN_MLP_F16X2: forward / data-gradient layers as fp16 two-term splits
     int rows_only;         // TN_MLP_ROWS_ONLY (producer: no row-major y)
     int x_from_rows;       // TN_MLP_X_FROM_ROWS (consumer: x only exists as x_rows)
-    // column window of the stashed chain's grad_x = W_0^T G_0 (mlp_bwd2.hip, paired heads behind a 256-wide stack: both first layers
-    // do not fit LDS at once, so the launch is split by x columns): the LDS copy of W_0 holds x slots [gx_col0, gx_col0 + gx_ncols)
-    // (gx_ncols == 0: all of them); skip_g_rows: the G / g_pre rows of the workspace are already written (second window)
-    int gx_col0 = 0, gx_ncols = 0, skip_g_rows = 0;
+    int x_wgrad_done = 0;                       // the first layer's x-column weight gradient was taken by the caller (tn_mlp_bwd_pair)
     const unsigned *gx_mask_rows = nullptr;     // tn_mlp_desc::grad_x_mask_rows: relu' bits applied to grad_x_rows
     int64_t gx_mask_stride = 0;
     int skip_last = 0;                          // TN_MLP_SKIP_LAST
@@ -59,8 +56,7 @@ __device__ inline void stage_weights(const MlpArgs &a, float *lds) {
         for (int e = threadIdx.x; e < rows * stride; e += blockDim.x) {
             const int r = e / stride, q = e - r * stride;
             float v = 0.0f;
-            const int qs = l == 0 ? q + a.gx_col0 : q;
-            if (r < N && qs < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, qs) : qs)];
+            if (r < N && q < K) v = a.W[l][(int64_t)r * K + (l == 0 ? layer0_col(a, q) : q)];
             w[e] = v;
         }
         float *b = lds + a.b_off[l];

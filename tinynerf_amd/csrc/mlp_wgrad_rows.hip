@@ -30,6 +30,12 @@ struct WgradRowsArgs {
     float *gW;                  // [NG][ldw]: dW[n][col0 + k]
     float *gB;                  // [NG] or nullptr
     int ldw, col0, kmax;        // columns k >= kmax are padding (not written)
+    // two heads on the same x (g_rows2 != nullptr): G rows [0, NG / 2) come from g_rows and belong to gW / gB, rows [NG / 2, NG) from
+    // g_rows2 and belong to gW2 / gB2 -- the x rows, three quarters of a tile's bytes at 64 + 64 against 256 rows, are read once
+    const float *g_rows2 = nullptr;
+    int64_t g_stride2 = 0;
+    float *gW2 = nullptr, *gB2 = nullptr;
+    int ldw2 = 0, col02 = 0;
 };
 
 __device__ __forceinline__ int frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -67,15 +73,17 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         const int row = 8 * (wave * NI + e) + (lane >> 3);
-        const int src_row = row < NG ? row : row - NG;
+        const int src_row = row < NG ? ((a.g_rows2 != nullptr && row >= NG / 2) ? row - NG / 2 : row) : row - NG;
         src_off[e] = src_row * 32 + 4 * ((lane & 7) ^ ((row >> 1) & 7));
     }
     auto fetch = [&](int64_t tile, float *buf) {
         const float *sg = a.g_rows + tile * a.g_stride, *sa = a.a_rows + tile * a.a_stride;
+        const float *sg2 = a.g_rows2 != nullptr ? a.g_rows2 + tile * a.g_stride2 : sg;
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
-            const bool is_g = 8 * (wave * NI + e) < NG;                  // wave-uniform
-            glds16((is_g ? sg : sa) + src_off[e], buf + 256 * (wave * NI + e));
+            const int r0 = 8 * (wave * NI + e);                          // wave-uniform: one source per instruction
+            const float *src = r0 < NG ? ((a.g_rows2 != nullptr && r0 >= NG / 2) ? sg2 : sg) : sa;
+            glds16(src + src_off[e], buf + 256 * (wave * NI + e));
         }
     };
     int g_off[BN], a_off[BK];
@@ -126,16 +134,21 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
         for (int bk = 0; bk < BK; ++bk) {
             tn::pin16(acc[bn][bk]);
             const int k = 32 * (tk0 + bk) + i;
+            const bool second = a.g_rows2 != nullptr && 32 * (tn0 + bn) >= NG / 2;       // (wave-uniform: NG / 2 is a multiple of 32)
+            float *gw = second ? a.gW2 : a.gW;
+            const int ldw = second ? a.ldw2 : a.ldw, col0 = second ? a.col02 : a.col0, n0 = second ? NG / 2 : 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nn = 32 * (tn0 + bn) + frow(r, h);
-                if (k < a.kmax) atomicAdd(&a.gW[(int64_t)nn * a.ldw + a.col0 + k], acc[bn][bk][r]);
+                const int nn = 32 * (tn0 + bn) + frow(r, h) - n0;
+                if (k < a.kmax) atomicAdd(&gw[(int64_t)nn * ldw + col0 + k], acc[bn][bk][r]);
             }
         }
-        if (tk0 == 0 && a.gB != nullptr) {
+        const bool second = a.g_rows2 != nullptr && 32 * (tn0 + bn) >= NG / 2;
+        float *gb = second ? a.gB2 : a.gB;
+        if (tk0 == 0 && gb != nullptr) {
             float s = dbacc[bn];
             s += __shfl_xor(s, 32, 64);
-            if (h == 0) atomicAdd(&a.gB[32 * (tn0 + bn) + i], s);
+            if (h == 0) atomicAdd(&gb[32 * (tn0 + bn) + i - (second ? NG / 2 : 0)], s);
         }
     }
 }
@@ -172,4 +185,20 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows(const flo
     if (ng == 256 && na == 64) return launch_rows<256, 64, 2, 1>(w, n, s);       // 8 x 2 tiles: wave = two row blocks, one k block
     if (ng == 128 && na == 64) return launch_rows<128, 64, 1, 1>(w, n, s);       // 4 x 2 tiles: one per wave
     return tn::fail(TN_E_CONFIG, "mlp_bwd: row-operand weight gradient is built for 64 x 256, 64 x 128, 256 x 64 and 128 x 64");
+}
+
+// ... of TWO width-64 heads on the same x rows in one launch (the heads behind a 256- / 128-wide stack: x is 80 % / 67 % of what a
+// single-head launch reads)
+extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows2(const float *g_rows, int64_t g_stride, const float *g_rows2, int64_t g_stride2,
+                                                                       const float *a_rows, int64_t a_stride, int na, float *gW, int ldw, int col0,
+                                                                       float *gB, float *gW2, int ldw2, int col02, float *gB2, int64_t n, void *stream)
+{
+    WgradRowsArgs w;
+    w.g_rows = g_rows; w.a_rows = a_rows; w.g_stride = g_stride; w.a_stride = a_stride; w.gW = gW; w.gB = gB; w.ldw = ldw; w.col0 = col0;
+    w.kmax = na;
+    w.g_rows2 = g_rows2; w.g_stride2 = g_stride2; w.gW2 = gW2; w.gB2 = gB2; w.ldw2 = ldw2; w.col02 = col02;
+    hipStream_t s = (hipStream_t)stream;
+    if (na == 256) return launch_rows<128, 256, 2, 2>(w, n, s);       // 4 x 8 tiles: wave = two row blocks x two k blocks
+    if (na == 128) return launch_rows<128, 128, 2, 1>(w, n, s);       // 4 x 4 tiles: wave = two row blocks, one k block
+    return tn::fail(TN_E_CONFIG, "mlp_bwd: the two-head row-operand weight gradient is built for 128 or 256 x columns");
 }

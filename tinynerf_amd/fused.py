@@ -38,11 +38,9 @@ PAIR_FORWARD = True       # both heads' training forwards in one launch (tn_mlp_
 FUSE_GATHER = True        # ... with the K-Planes gather inside that launch (tn_kplanes_mlp_fwd_pair)
 FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient chain launch (tn_kplanes_mlp_bwd_pair)
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
-# ... also behind the wide stacks (_RenderHeads; round 5): "128" (default) = behind Cobafa's 128-wide stack, where one launch holds both
-# first layers (0.67 against 0.43 + 0.28 ms per 2^20 samples); "all" = also behind the 256-wide stack, in two column windows -- measured
-# SLOWER there (0.71 + 0.45 against 0.61 + 0.49 ms: 137 GFLOP of W_0^T G_0 on the fp32 MFMA either way, and the window form adds the G_0
-# re-read), kept for the parity test; "0" = never
-HEADS_PAIR_BACKWARD = os.environ.get("TN_HEADS_PAIR", "128")
+# ... also behind the wide stacks (_RenderHeads; round 5): tn_mlp_bwd_pair takes both heads' first-layer weight gradients over the x
+# columns in ONE launch (x rows read once) and, where both first layers fit LDS (128-wide stack), both data gradients in one pass; "0": off
+HEADS_PAIR_BACKWARD = os.environ.get("TN_HEADS_PAIR", "1") != "0"
 # schedule of the K-Planes backward: "fused" = chain + scatter in one kernel, then the weight gradients; "split" = chain, then the
 # stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
 # second stream BESIDE the weight-gradient kernels (bound by HBM)
@@ -581,9 +579,9 @@ class _RenderHeads(Function):
                 d.x_rows_tile_stride = d.grad_x_rows_tile_stride = link["stride"]
                 if link.get("skipped_last"):     # x is the producer's last HIDDEN activation: d / d (its pre-activation) = relu' * ...
                     d.grad_x_mask_rows, d.grad_x_mask_tile_stride = link["mask_rows"], link["stride"]
-        if link is not None and (HEADS_PAIR_BACKWARD == "all" or (HEADS_PAIR_BACKWARD == "128" and F == 128)) and F % 64 == 0 and ns == 2 and nr == 5 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
-            # both heads' data gradients in one pass (two column windows at 256 inputs: mlp_bwd2.hip): d loss / d feat is written once as
-            # the sum of the two instead of written by the colour head and read, added to and written again by the sigma head
+        if link is not None and HEADS_PAIR_BACKWARD and F % 64 == 0 and ns == 2 and nr == 5 and sig_p[0].size(0) == 64 and rgb_p[0].size(0) == 64:
+            # one call for both heads: their first layers' x-column weight gradients share a launch (and the x rows), and behind the
+            # 128-wide stack d loss / d feat is written once as the sum of the two data gradients (mlp_bwd2.hip, bwd_pair_common)
             sdesc.flags &= ~L.MLP_ACCUM_GRAD_X
             L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
                    C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))

@@ -393,3 +393,116 @@ def test_f16x2_weight_gradient_with_an_outlier_sample(log2_outlier, monkeypatch)
         err[mode] = [float((p.grad.double().cpu() - r).abs().max() / r.abs().max()) for p, r in zip(params, ref)]
     for e16, e32, name in zip(err["f16x2"], err["fp32"], names):
         assert e16 <= 4 * e32 + 1e-6, (name, e16, e32)
+
+
+def _bit_rows(x_pos: torch.Tensor, tiles: int, F: int) -> torch.Tensor:
+    """the layer kernels' ReLU bit rows of a [tiles * 32, F] boolean matrix: per tile and 32-feature block two 128-byte rows = 64 dwords,
+    dword `lane` (sample j = lane & 31, half h = lane >> 5) holds bit r for feature 32 b + (r & 3) + 8 (r >> 2) + 4 h"""
+    p = x_pos.view(tiles, 32, F // 32, 32).cpu().numpy()                # [tile][j][block][feature in block]
+    out = np.zeros((tiles, F // 32, 64), dtype=np.uint32)
+    for r in range(16):
+        for h in range(2):
+            f = (r & 3) + 8 * (r >> 2) + 4 * h
+            out[:, :, 32 * h:32 * h + 32] |= (p[:, :, :, f].transpose(0, 2, 1).astype(np.uint32) << r)
+    return torch.from_numpy(out.view(np.int32)).to(DEV)
+
+
+@pytest.mark.parametrize("in_dim,n,hidden", [(256, 33, False), (256, 2000, True), (128, 777, True), (256, 40037, True), (128, 40037, False)])
+def test_heads_pair_backward_over_row_views(in_dim, n, hidden):
+    """Round 5: tn_mlp_bwd_pair of the two width-64 heads with x / grad_x as workspace rows -- both chains stop at G_0, grad_x = W_0c[:, x]^T
+    G_0c + W_0s^T G_0s is one f16x2 launch from the G_0 rows (heads_dx.hip; `hidden`: x is a ReLU output of the producer and the rows
+    leave multiplied by relu'(x) through grad_x_mask_rows), both first layers' x-column weight gradients share one launch
+    (tn_mlp_wgrad_rows2).  Oracle: the two single-head tn_mlp_bwd calls (fp32 MFMA, the path G8 / G14 pin) on the same workspaces, and
+    fp64 autograd for grad_x."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    if m.MATMUL != "f16x2":
+        pytest.skip("the row views are the f16x2 heads' path")
+    torch.manual_seed(7 * n + in_dim)
+    sig = m.MLP(in_dim, 64, 0, 1).to(DEV)
+    rgb = m.MLP(in_dim + 51, 64, 3, 3).to(DEV)
+    x = torch.randn(n, in_dim, device=DEV) * 2.0
+    if hidden:
+        x = torch.relu(x)
+    tiles = (n + 31) // 32
+    xp = torch.zeros(tiles * 32, in_dim, device=DEV)
+    xp[:n] = x
+    rows = xp.view(tiles, 32, in_dim).transpose(1, 2).contiguous()
+    bits = _bit_rows(xp > 0, tiles, in_dim) if hidden else None
+    table = torch.randn(9, 56, device=DEV)
+    table[:, 51:] = 0.0
+    idx = torch.randint(0, 9, (n,), dtype=torch.int32, device=DEV)
+    mag = torch.exp(torch.empty(n, 1, device=DEV).uniform_(-10.0, 0.0))          # upstream gradients over four orders of magnitude
+    g_rgb, g_sig = (torch.randn(n, 3, device=DEV) * mag).contiguous(), (torch.randn(n, 1, device=DEV) * mag).contiguous()
+    sp, rp = sig.params(), rgb.params()
+    wsfn = L.lib().tn_mlp_bwd_workspace_bytes
+    wsfn.restype = C.c_int64
+
+    def descs(flags_r, flags_s, gx_rows):
+        rd = m._mlp_desc(rp, in_dim, L.ENC_AUX_CAT, 8, L.ACT_SIGMOID, None, flags_r, idx, 56)
+        sd = m._mlp_desc(sp, in_dim, L.ENC_NONE, 0, L.ACT_EXP_M1, None, flags_s)
+        for d in (rd, sd):
+            d.x_rows, d.x_rows_tile_stride = rows.data_ptr(), in_dim * 32
+            if gx_rows is not None:
+                d.grad_x_rows, d.grad_x_rows_tile_stride = gx_rows.data_ptr(), in_dim * 32
+                if bits is not None:
+                    d.grad_x_mask_rows, d.grad_x_mask_tile_stride = bits.data_ptr(), (in_dim // 32) * 64
+        return rd, sd
+    out = {}
+    for mode in ("two calls", "pair"):
+        rd, sd = descs(L.MLP_X_FROM_ROWS, L.MLP_X_FROM_ROWS, None)
+        rb, sb = int(wsfn(C.byref(rd), C.c_int64(n))), int(wsfn(C.byref(sd), C.c_int64(n)))
+        ws_r, ws_s = torch.zeros(rb // 4, device=DEV), torch.zeros(sb // 4, device=DEV)
+        y_r, y_s = torch.empty(n, 3, device=DEV), torch.empty(n, 1, device=DEV)
+        nan_x = torch.full_like(x, float("nan"))
+        L.call("tn_mlp_fwd_stash", x.device, C.byref(rd), L.ptr(nan_x), L.ptr(table), C.c_int64(n), L.ptr(y_r), L.ptr(ws_r), C.c_int64(rb))
+        L.call("tn_mlp_fwd_stash", x.device, C.byref(sd), L.ptr(nan_x), C.c_void_p(None), C.c_int64(n), L.ptr(y_s), L.ptr(ws_s), C.c_int64(sb))
+        gx_rows = torch.full((tiles, in_dim, 32), float("nan"), device=DEV)
+        g_r, g_s = [torch.zeros_like(p) for p in rp], [torch.zeros_like(p) for p in sp]
+        gw_r = (C.c_void_p * 5)(*[g.data_ptr() for g in g_r[0::2]]); gb_r = (C.c_void_p * 5)(*[g.data_ptr() for g in g_r[1::2]])
+        gw_s = (C.c_void_p * 2)(*[g.data_ptr() for g in g_s[0::2]]); gb_s = (C.c_void_p * 2)(*[g.data_ptr() for g in g_s[1::2]])
+        if mode == "pair":
+            rd, sd = descs(L.MLP_STASHED, L.MLP_STASHED, gx_rows)
+            L.call("tn_mlp_bwd_pair", x.device, C.byref(rd), C.byref(sd), L.ptr(nan_x), L.ptr(table), L.ptr(g_rgb), L.ptr(g_sig), C.c_int64(n),
+                   gw_r, gb_r, gw_s, gb_s, C.c_void_p(None), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
+        else:
+            rd, sd = descs(L.MLP_STASHED, L.MLP_STASHED | L.MLP_ACCUM_GRAD_X, gx_rows)
+            L.call("tn_mlp_bwd", x.device, C.byref(rd), L.ptr(nan_x), L.ptr(table), L.ptr(g_rgb), C.c_int64(n), gw_r, gb_r, C.c_void_p(None),
+                   L.ptr(ws_r), C.c_int64(rb))
+            L.call("tn_mlp_bwd", x.device, C.byref(sd), L.ptr(nan_x), C.c_void_p(None), L.ptr(g_sig), C.c_int64(n), gw_s, gb_s, C.c_void_p(None),
+                   L.ptr(ws_s), C.c_int64(sb))
+        gx = gx_rows.transpose(1, 2).reshape(tiles * 32, in_dim)[:n]
+        out[mode] = (gx, g_r, g_s, y_r, y_s)
+    for a_, b_ in zip(out["pair"][3:], out["two calls"][3:]):
+        assert torch.equal(a_, b_)
+    gx_p, gx_t = out["pair"][0], out["two calls"][0]
+    assert torch.isfinite(gx_p).all()
+    scale = float(gx_t.abs().max())
+    assert float((gx_p - gx_t).abs().max()) <= 2e-5 * scale
+    if hidden:
+        assert float(gx_p[x <= 0].abs().max()) == 0.0           # relu'(x) = 0: exactly zero
+    for name, (ga, gb_) in {"rgb": (out["pair"][1], out["two calls"][1]), "sigma": (out["pair"][2], out["two calls"][2])}.items():
+        for k, (a_, b_) in enumerate(zip(ga, gb_)):
+            assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-12), (name, k)
+    # fp64: grad_x through the forward's own ReLU masks (the heads' hidden units at a tie are the same on both sides of this comparison)
+    xd = x.double().requires_grad_(True)
+    dirs_cols = table[idx.long()][:, :51].double()
+    z = torch.cat([dirs_cols, xd], 1)
+    hr = z
+    ps64 = [p.detach().double() for p in rp]
+    for l in range(4):
+        hr = torch.relu(hr @ ps64[2 * l].t() + ps64[2 * l + 1])
+    yr = torch.sigmoid(hr @ ps64[8].t() + ps64[9])
+    ss64 = [p.detach().double() for p in sp]
+    pre_s = torch.relu(xd @ ss64[0].t() + ss64[1]) @ ss64[2].t() + ss64[3]
+    ys = torch.exp(pre_s - 1.0)
+    (yr * g_rgb.double()).sum().backward(retain_graph=True)
+    gref = xd.grad.clone()
+    xd.grad = None
+    (ys * g_sig.double()).sum().backward()
+    gref = gref + xd.grad
+    if hidden:
+        gref = gref * (x > 0).double()
+    err = float((gx_p.double() - gref).abs().max()) / float(gref.abs().max())
+    err_t = float((gx_t.double() - gref).abs().max()) / float(gref.abs().max())
+    assert err <= max(1e-4, 2.0 * err_t), (err, err_t)

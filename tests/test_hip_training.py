@@ -589,6 +589,33 @@ def test_linear_merge_kernels_against_autograd():
 
 
 @pytest.mark.gpu
+def test_planes_optimizer_pass_beside_the_weight_gradient_kernels(monkeypatch):
+    """TN_ADAM_OVERLAP=1 (opt-in, N == 1): the planes' optimizer pass starts on a stream of its own once the chain + scatter launch has made
+    their gradients final, beside the heads' weight-gradient kernels; the remaining parameters follow as before.  Same arithmetic on the
+    same values: losses and parameters equal the serial run's to the order noise of the gradient atomics."""
+    from tinynerf_amd import run
+    from tinynerf_amd.run import TrainConfig, Trainer
+    o, d, rgb = _scene()
+    out = {}
+    for overlap in (False, True):
+        monkeypatch.setattr(run, "ADAM_OVERLAP", overlap)
+        cfg = TrainConfig(method="kplanes", scene_type="aabb", batch_size=256, n_samples=32, seed=3, occupancy_res=32, deterministic=True,
+                          kplanes_resolutions=(32, 64))
+        tr = Trainer(cfg, o.to(DEV), d.to(DEV), rgb.to(DEV), torch.ones(3, device=DEV), torch.device(DEV))
+        ls = []
+        for _ in range(4):
+            tr.step()
+            ls.append(tr.loss_value())
+        torch.cuda.synchronize()
+        assert (tr._side2 is not None) == overlap
+        out[overlap] = (ls, {k: v.detach().float().cpu().numpy().copy() for k, v in tr.renderer.state_dict().items()})
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4)
+    for k, v in out[False][1].items():
+        diff = np.abs(out[True][1][k] - v)
+        assert float((diff > 1e-4 * max(1e-3, float(np.abs(v).max()))).mean()) < 5e-3, k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("where", ["plane", "colour_weight", "sigma_bias"])
 def test_a_non_finite_parameter_surfaces_as_the_reference_nan_loss(where):
     """torch.relu hands a NaN on (models.py:7-28), so in the reference ONE non-finite parameter makes the loss NaN at the next step

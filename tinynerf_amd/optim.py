@@ -22,7 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._gated_params = {}      # device -> the parameters that share that count
 
     @torch.no_grad()
-    def step(self, closure=None, plane_reg=None, gate=None):
+    def step(self, closure=None, plane_reg=None, gate=None, only=None):
         """``gate`` (harness): device float scalar; tensors outside ``plane_reg`` are only updated -- and their step count only
         advances -- when it is > 0 (tn_adam_multi_gated).  This is what torch.optim.Adam does with the ``grad is None`` parameters
         of the reference's "Empty iteration" (core.py:251-254), decided on the device instead of by a host read-back.
@@ -30,7 +30,10 @@ class FusedAdam(torch.optim.Optimizer):
         ``plane_reg`` (harness): dict(spec=[(plane, H, W, C, cy, cx, cl1)], upstream=float, sums=fp64 tensor or None[, rows={id(plane):
         (row0, row1)}: the sharded pass of N > 1 -- only these rows are updated and summed, the caller all-gathers them]) folds
         the K-Planes regulariser's gradient (and its sums) into the update of those planes (tn_adam_reg_multi): the planes are
-        streamed once per step.  Their new values are written to a second buffer which then becomes ``plane.data``."""
+        streamed once per step.  Their new values are written to a second buffer which then becomes ``plane.data``.
+
+        ``only`` (harness): "reg" = the ``plane_reg`` tensors alone, "rest" = everything else (the trainer may run the planes' pass on a
+        stream of its own as soon as their gradients are final, beside the heads' weight-gradient kernels)."""
         loss = closure() if closure is not None else None
         reg = {}
         if plane_reg is not None:
@@ -45,6 +48,8 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("tinynerf_amd.FusedAdam: parameters must be CUDA (HIP) tensors -- there is no CPU path")
+                if only is not None and (id(p) in reg) != (only == "reg"):
+                    continue
                 st = self.state[p]
                 if not st:
                     st["step"] = 0

@@ -36,6 +36,9 @@ def psnr(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return -10. * torch.log10(torch.mean((x - y) ** 2))
 
 
+ADAM_OVERLAP = os.environ.get("TN_ADAM_OVERLAP", "0") == "1"
+
+
 @dataclass
 class TrainConfig:
     method: str = "kplanes"            # vanilla | kplanes | cobafa   (run.py:130-152)
@@ -180,6 +183,7 @@ class Trainer:
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
         self._side: Optional[torch.cuda.Stream] = None
+        self._side2: Optional[torch.cuda.Stream] = None          # TN_ADAM_OVERLAP: the planes' optimizer pass
         self._gate_ring = torch.zeros(256, device=device)
         self._gate_tick = 0
         self._acc_ring = torch.zeros((64, 1 + 32 * 3), dtype=torch.float64, device=device)
@@ -338,7 +342,8 @@ class Trainer:
         if slot == 0 and self._gate_tick > 1:
             self._gate_ring.zero_()
         self.renderer._batch_aux = {"key": (packed.data_ptr(), n, R), "ray_ids": ray_ids, "steps": steps, "dirs": pend["d"][:R],
-                                    "planes_ready": self._planes_ready if self.world > 1 else None, "gate": self._gate_ring[slot:slot + 1]}
+                                    "planes_ready": self._planes_ready if self.world > 1 else (self._planes_adam_early if ADAM_OVERLAP else None),
+                                    "gate": self._gate_ring[slot:slot + 1]}
         return packed, info, pend["rgb"][:R], k
 
     # ------------------------------------------------------------------ one optimizer step
@@ -418,6 +423,10 @@ class Trainer:
         else:
             L.call("tn_mse_grad", self.device, L.ptr(rendered.detach()), L.ptr(target), C.c_int64(3 * R), C.c_float(2.0 * cfg.grad_scale * inv),
                    L.ptr(inv_dev), L.ptr(grad), L.ptr(acc))
+        self._early_adam = None
+        if ADAM_OVERLAP and self.world == 1 and cfg.method == "kplanes" and self.grad_hook is None:
+            spec0, _ = self.renderer.feature_module.regulariser_spec(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
+            self._early_adam = {"plane_reg": {"spec": spec0, "upstream": cfg.grad_scale, "sums": acc[1:]}, "gate": gate, "done": False}
         try:
             rendered.backward(grad)
         finally:
@@ -435,7 +444,11 @@ class Trainer:
             self.all_reduce_grads(gate)
         if self.grad_hook is not None:
             self.grad_hook(self)
-        self.optimizer.step(plane_reg=plane_reg, gate=gate)
+        if self._early_adam is not None and self._early_adam.get("done"):
+            self.optimizer.step(plane_reg=plane_reg, gate=gate, only="rest")      # (the planes' pass is on its way on the side stream)
+            torch.cuda.current_stream(self.device).wait_stream(self._side2)
+        else:
+            self.optimizer.step(plane_reg=plane_reg, gate=gate)
         if self._sharded:                    # the updated rows of every rank to every rank (all of them: weight decay and TV move dead rows too)
             works = []
             for p in self.renderer.feature_module.plane_tensors():
@@ -589,6 +602,19 @@ class Trainer:
         if torch.distributed.get_backend() == "nccl" or not flat.is_cuda:
             return [torch.distributed.all_gather_into_tensor(flat, flat[rank * chunk:(rank + 1) * chunk], async_op=True)]
         return [torch.distributed.broadcast(flat[r * chunk:(r + 1) * chunk], src=r, async_op=True) for r in range(world)]
+
+    def _planes_adam_early(self, grads) -> None:
+        """N == 1 (TN_ADAM_OVERLAP=1): the planes' gradients are final behind the chain + scatter launch -- their optimizer pass (HBM-bound, no
+        LDS, few registers) goes to a stream of its own beside the heads' weight-gradient kernels (VALU / LDS-bound)."""
+        pend = getattr(self, "_early_adam", None)
+        if pend is None or pend.get("done"):
+            return
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream(self.device)
+        self._side2.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side2):
+            self.optimizer.step(plane_reg=pend["plane_reg"], gate=pend["gate"], only="reg")
+        pend["done"] = True
 
     def _planes_ready(self, grads) -> None:
         """Called by the fused render node in the middle of the backward pass (N > 1), as soon as the plane gradients are

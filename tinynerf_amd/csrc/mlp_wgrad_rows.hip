@@ -16,6 +16,7 @@
 // whole launch and flushes them with full-line atomics.  2 * 64 * NA FLOP against 4 * (64 + NA) * 32 bytes per tile:
 // 25.6 FLOP/B at NA = 256 -- on the ridge of the fp32-MFMA / HBM roofline (157 TFLOP/s : 6.3 TB/s = 25).
 #include "mlp_stage.h"
+#include "b3_device.h"
 #include <algorithm>
 
 namespace {
@@ -44,7 +45,10 @@ __device__ __forceinline__ void glds16(const float *src, float *dst) {
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 }
 
-template <int NG, int NA, int BN, int BK>
+// B3: the products as exact bf16 triplets (b3_device.h: six 32 x 32 x 16 MFMAs per 16 samples instead of eight 32 x 32 x 2 fp32 ones per
+// 16 -- 2.7 x less matrix time, results equal to fp32 rounding): the two-head form owns four tiles per wave and is matrix-bound on the fp32
+// MFMA (4 096 pipe cycles per tile against 2.1 us of HBM time).
+template <int NG, int NA, int BN, int BK, bool B3 = false>
 __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_t n)
 {
     constexpr int NR = NG + NA;                           // rows per tile buffer
@@ -104,6 +108,32 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
         for (int bn = 0; bn < BN; ++bn)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gv[bn][e] = *reinterpret_cast<const f32x4 *>(buf + g_off[bn] + 4 * ((4 * h + e) ^ swz));
+        if constexpr (B3) {
+            // k block sb of the 32 x 32 x 16 products: lane (i, h) supplies samples 16 h + 8 sb .. + 7 of its row (chunks 2 sb, 2 sb + 1 of
+            // its half) -- the same eight samples on both operands, every sample of the tile in exactly one (h, sb)
+            tn::b3::Op gt[BN][2];
+#pragma unroll
+            for (int bn = 0; bn < BN; ++bn)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const float v[8] = {gv[bn][2 * sb][0], gv[bn][2 * sb][1], gv[bn][2 * sb][2], gv[bn][2 * sb][3],
+                                        gv[bn][2 * sb + 1][0], gv[bn][2 * sb + 1][1], gv[bn][2 * sb + 1][2], gv[bn][2 * sb + 1][3]};
+                    gt[bn][sb] = tn::b3::split8(v);
+                }
+#pragma unroll
+            for (int bk = 0; bk < BK; ++bk) {
+                f32x4 av[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = *reinterpret_cast<const f32x4 *>(buf + a_off[bk] + 4 * ((4 * h + e) ^ swz));
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const float v[8] = {av[2 * sb][0], av[2 * sb][1], av[2 * sb][2], av[2 * sb][3], av[2 * sb + 1][0], av[2 * sb + 1][1], av[2 * sb + 1][2], av[2 * sb + 1][3]};
+                    const tn::b3::Op at = tn::b3::split8(v);
+#pragma unroll
+                    for (int bn = 0; bn < BN; ++bn) acc[bn][bk] = tn::b3::mfma6(gt[bn][sb], at, acc[bn][bk]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int bk = 0; bk < BK; ++bk) {
             f32x4 av[4];
@@ -115,6 +145,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc[bn][bk] = tn::mfma32(gv[bn][e][u], av[e][u], acc[bn][bk]);
+        }
         }
         if (tk0 == 0) {
 #pragma unroll
@@ -153,11 +184,11 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(WgradRowsArgs a, int64_
     }
 }
 
-template <int NG, int NA, int BN, int BK>
+template <int NG, int NA, int BN, int BK, bool B3 = false>
 int launch_rows(const WgradRowsArgs &w, int64_t n, hipStream_t s)
 {
     constexpr size_t lds_bytes = (size_t)2 * (NG + NA) * 32 * sizeof(float);
-    auto kern = wgrad_rows_kernel<NG, NA, BN, BK>;
+    auto kern = wgrad_rows_kernel<NG, NA, BN, BK, B3>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
@@ -198,7 +229,7 @@ extern "C" __attribute__((visibility("hidden"))) int tn_mlp_wgrad_rows2(const fl
     w.kmax = na;
     w.g_rows2 = g_rows2; w.g_stride2 = g_stride2; w.gW2 = gW2; w.gB2 = gB2; w.ldw2 = ldw2; w.col02 = col02;
     hipStream_t s = (hipStream_t)stream;
-    if (na == 256) return launch_rows<128, 256, 2, 2>(w, n, s);       // 4 x 8 tiles: wave = two row blocks x two k blocks
-    if (na == 128) return launch_rows<128, 128, 2, 1>(w, n, s);       // 4 x 4 tiles: wave = two row blocks, one k block
+    if (na == 256) return launch_rows<128, 256, 2, 2, true>(w, n, s);       // 4 x 8 tiles: wave = two row blocks x two k blocks
+    if (na == 128) return launch_rows<128, 128, 2, 1, true>(w, n, s);       // 4 x 4 tiles: wave = two row blocks, one k block
     return tn::fail(TN_E_CONFIG, "mlp_bwd: the two-head row-operand weight gradient is built for 128 or 256 x columns");
 }

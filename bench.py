@@ -357,6 +357,15 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
         out["flop_per_sample_step"] = flop
         out["tflops_fp32_equivalent"] = tf
         out["matmul"] = mode
+        # TN_MLP_SKIP_LAST: the stack's last Linear(F, F) is merged into the decoders' first layers -- the reference model's FLOP above
+        # are what the step is worth, the launches execute 6 F^2 per sample less (one layer's forward, data and weight gradient)
+        prod = t2.renderer.__dict__.get("_rows_producer")
+        sc = prod.__dict__.get("scratch") if prod is not None else None
+        if sc is not None and len(sc) > 2 and sc[2].get("skipped_last"):
+            F = prod.params()[-2].size(0)
+            out["merged_last_layer"] = {"flop_per_sample_step_executed": flop - 6 * F * F,
+                                        "note": "TN_MLP_SKIP_LAST: flop_per_sample_step / tflops_fp32_equivalent count the reference model's "
+                                                "products; the merged form skips the last layer's three"}
         if mode == "f16x2":
             # every layer of the stack and the heads' forward as two-term fp16 splits with power-of-two scales (TN_MLP_F16X2): THREE fp16
             # MFMAs per fp32 product block; the heads' backward and the first-layer weight gradients stay on the fp32 MFMA

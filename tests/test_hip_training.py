@@ -590,7 +590,7 @@ def test_linear_merge_kernels_against_autograd():
 
 @pytest.mark.gpu
 def test_planes_optimizer_pass_beside_the_weight_gradient_kernels(monkeypatch):
-    """TN_ADAM_OVERLAP=1 (opt-in, N == 1): the planes' optimizer pass starts on a stream of its own once the chain + scatter launch has made
+    """TN_ADAM_OVERLAP (default on, N == 1): the planes' optimizer pass starts on a stream of its own once the chain + scatter launch has made
     their gradients final, beside the heads' weight-gradient kernels; the remaining parameters follow as before.  Same arithmetic on the
     same values: losses and parameters equal the serial run's to the order noise of the gradient atomics."""
     from tinynerf_amd import run

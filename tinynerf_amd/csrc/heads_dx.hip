@@ -31,10 +31,17 @@ struct DxArgs {
     int64_t mask_stride;
 };
 
+// WAVES per workgroup (one workgroup per CU: the weight planes fill LDS): 16 waves without a register prefetch (four per SIMD hide each
+// other's round trips, and a wave may only have 64 vector-memory operations in flight: 200 per tile here) against 8 with the next tile's
+// rows requested a tile ahead -- TN_DX_WAVES
+#ifndef TN_DX_WAVES
+#define TN_DX_WAVES 16
+#endif
 template <int F>
-__global__ __launch_bounds__(512) void heads_dx_f2_kernel(DxArgs a, int64_t n)
+__global__ __launch_bounds__(TN_DX_WAVES * 64) void heads_dx_f2_kernel(DxArgs a, int64_t n)
 {
-    constexpr int NOB = F / 32;
+    constexpr int NOB = F / 32, NW = TN_DX_WAVES;
+    constexpr bool PREFETCH = NW <= 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     _Float16 *whi = reinterpret_cast<_Float16 *>(lds_raw), *wlo = whi + 128 * F;
     float *scratch = reinterpret_cast<float *>(lds_raw + (size_t)2 * 128 * F * 2);
@@ -43,16 +50,16 @@ __global__ __launch_bounds__(512) void heads_dx_f2_kernel(DxArgs a, int64_t n)
     // ---- stage W' = [W_a[:, x]; W_b[:, x]] (128 x F) as fp16 hi / lo planes in A-operand order [ob][k block][h][column][8] ----
     auto wv = [&](int nn, int col) { return nn < 64 ? a.w_a[(int64_t)nn * a.ld_a + a.col0_a + col] : a.w_b[(int64_t)(nn - 64) * a.ld_b + a.col0_b + col]; };
     float m = 0.0f;
-    for (int e = threadIdx.x; e < 128 * F; e += 512) m = fmaxf(m, fabsf(wv(e / F, e % F)));
+    for (int e = threadIdx.x; e < 128 * F; e += NW * 64) m = fmaxf(m, fabsf(wv(e / F, e % F)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) scratch[wave] = m;
     __syncthreads();
     float g = 0.0f;
-    for (int w = 0; w < 8; ++w) g = fmaxf(g, scratch[w]);
+    for (int w = 0; w < NW; ++w) g = fmaxf(g, scratch[w]);
     float s_w, inv_w;
     f2_scales(g, s_w, inv_w);
-    for (int e = threadIdx.x; e < 128 * F; e += 512) {
+    for (int e = threadIdx.x; e < 128 * F; e += NW * 64) {
         const int nn = e / F, col = e % F;
         const float v = wv(nn, col) * s_w;
         const _Float16 vh = (_Float16)v;
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(512) void heads_dx_f2_kernel(DxArgs a, int64_t n)
     }
     __syncthreads();
     const int64_t n_tiles = (n + 31) >> 5;
-    const int64_t stride = (int64_t)gridDim.x * 8;
+    const int64_t stride = (int64_t)gridDim.x * NW;
     // G_0 of a tile: k block b = rows 16 b .. + 15 (b < 4: head a, else head b); lane (j, h) takes rows 16 b + 8 h + e of sample j
     auto fetch = [&](int64_t t, float (&v)[8][8]) {
         const float *ga = a.g_a + t * a.gs_a + (8 * h) * 32 + j, *gb = a.g_b + t * a.gs_b + (8 * h) * 32 + j;
@@ -73,21 +80,27 @@ __global__ __launch_bounds__(512) void heads_dx_f2_kernel(DxArgs a, int64_t n)
             for (int e = 0; e < 8; ++e) v[b][e] = src[e * 32];
         }
     };
-    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
-    float nxt[8][8];
-    if (tile < n_tiles) fetch(tile, nxt);
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    float nxt[PREFETCH ? 8 : 1][8];
+    if constexpr (PREFETCH) { if (tile < n_tiles) fetch(tile, nxt); }
 #pragma clang loop unroll(disable)
     for (; tile < n_tiles; tile += stride) {
         float mx = 0.0f;
         u32x4h bh[8], bl[8];
         {
             float cur[8][8];
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cur[b][e] = nxt[b][e];
+                const int64_t tn_ = tile + stride;
+                fetch(tn_ < n_tiles ? tn_ : tile, nxt);                // next tile's rows travel under this tile's products
+            } else fetch(tile, cur);
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { cur[b][e] = nxt[b][e]; mx = fmaxf(mx, fabsf(cur[b][e])); }
-            const int64_t tn_ = tile + stride;
-            fetch(tn_ < n_tiles ? tn_ : tile, nxt);                    // next tile's rows travel under this tile's products
+                for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(cur[b][e]));
             float s_g, inv_g;
             f2_scales(f2_xmax(mx), s_g, inv_g);
             mx = inv_g;
@@ -123,12 +136,12 @@ __global__ __launch_bounds__(512) void heads_dx_f2_kernel(DxArgs a, int64_t n)
 template <int F>
 int launch_dx(const DxArgs &a, int64_t n, hipStream_t s)
 {
-    constexpr size_t lds_bytes = (size_t)2 * 128 * F * 2 + 64;
+    constexpr size_t lds_bytes = (size_t)2 * 128 * F * 2 + 128;
     auto kern = heads_dx_f2_kernel<F>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("heads_dx: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
-    kern<<<dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, 256))), dim3(512), lds_bytes, s>>>(a, n);
+    kern<<<dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + TN_DX_WAVES - 1) / TN_DX_WAVES, 256))), dim3(TN_DX_WAVES * 64), lds_bytes, s>>>(a, n);
     return tn::check_launch("heads_dx_f2_kernel");
 }
 

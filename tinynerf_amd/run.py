@@ -36,7 +36,7 @@ def psnr(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return -10. * torch.log10(torch.mean((x - y) ** 2))
 
 
-ADAM_OVERLAP = os.environ.get("TN_ADAM_OVERLAP", "0") == "1"
+ADAM_OVERLAP = os.environ.get("TN_ADAM_OVERLAP", "1") != "0"      # N == 1: the planes' optimizer pass beside the weight-gradient kernels (_planes_adam_early)
 
 
 @dataclass
@@ -604,7 +604,7 @@ class Trainer:
         return [torch.distributed.broadcast(flat[r * chunk:(r + 1) * chunk], src=r, async_op=True) for r in range(world)]
 
     def _planes_adam_early(self, grads) -> None:
-        """N == 1 (TN_ADAM_OVERLAP=1): the planes' gradients are final behind the chain + scatter launch -- their optimizer pass (HBM-bound, no
+        """N == 1 (TN_ADAM_OVERLAP, default on): the planes' gradients are final behind the chain + scatter launch -- their optimizer pass (HBM-bound, no
         LDS, few registers) goes to a stream of its own beside the heads' weight-gradient kernels (VALU / LDS-bound)."""
         pend = getattr(self, "_early_adam", None)
         if pend is None or pend.get("done"):

@@ -354,7 +354,11 @@ int tn_mlp_bwd(const tn_mlp_desc *desc, const float *x, const float *aux, const 
 /* Backward of TWO heads that read the same x in one data-gradient pass (the K-Planes colour head `desc` and its
  * 2-layer sigma head `partner`, models.py:70-89): grad_x = d/dx of both, written once.  Both descriptors carry
  * TN_MLP_STASHED (workspaces written by tn_mlp_fwd_stash); partner: 2 layers, TN_ENC_NONE, same in_dim (multiple of
- * 32) and hidden width 64.  Parameter gradients accumulate (+=) as in tn_mlp_bwd. */
+ * 32) and hidden width 64.  Parameter gradients accumulate (+=) as in tn_mlp_bwd.
+ * With row views on both descriptors (the heads behind a wide stack: the same x_rows / grad_x_rows [/ grad_x_mask_rows], TN_ENC_AUX_CAT on
+ * `desc`, grad_x == NULL) and TN_MLP_F16X2, both chains stop at their G_0 rows, grad_x_rows = W_0[:, x]^T G_0 of both heads is one launch
+ * on the fp16 matrix cores (two-term splits, 2^-22 relative; the fp32 / bf16x3 modes keep the fp32 MFMA), and both first layers' x-column
+ * weight gradients share one launch. */
 int tn_mlp_bwd_pair(const tn_mlp_desc *desc, const tn_mlp_desc *partner, const float *x, const float *aux,
                     const float *grad_y, const float *partner_grad_y, int64_t n, float *const *grad_weights,
                     float *const *grad_biases, float *const *partner_grad_weights, float *const *partner_grad_biases,

@@ -506,3 +506,75 @@ def test_heads_pair_backward_over_row_views(in_dim, n, hidden):
     err = float((gx_p.double() - gref).abs().max()) / float(gref.abs().max())
     err_t = float((gx_t.double() - gref).abs().max()) / float(gref.abs().max())
     assert err <= max(1e-4, 2.0 * err_t), (err, err_t)
+
+
+@pytest.mark.parametrize("which,n", [("vanilla", 1000), ("vanilla", 40037), ("cobafa", 4097)])
+def test_stack_without_its_last_layer(which, n):
+    """TN_MLP_SKIP_LAST through the C ABI: the stack's training forward stops at its last hidden activation h (bit-identical to the full
+    run's: same launches), tn_mlp_rows_view_hidden says where h, the slot for d loss / d (its pre-activation) and its ReLU bit rows are,
+    and tn_mlp_bwd started from that slot gives layers 0 .. L - 2 the gradients of the full run, in which the last layer and a linear
+    consumer sit behind h (d loss / d y = R: the full run gets R as rows, the short run relu'(h) * (W_last^T R))."""
+    import ctypes as C
+    from tinynerf_amd import _lib as L, models as m
+    if m.MATMUL != "f16x2":
+        pytest.skip("TN_MLP_SKIP_LAST rides on the f16x2 layer kernels")
+    torch.manual_seed(n)
+    if which == "vanilla":
+        fm = m.VanillaFeatureMLP(10, 256, 8).to(DEV)
+        ps, F, enc, nf, freqs = fm.net.params(), 256, L.ENC_POSENC, 10, fm.encoding.freqs
+        x = (torch.rand(n, 3, device=DEV) * 2 - 1).contiguous()
+    else:
+        net = m.MLP(36, 128, 5).to(DEV)
+        ps, F, enc, nf, freqs = net.params(), 128, L.ENC_NONE, 0, None
+        x = torch.rand(n, 36, device=DEV).contiguous()
+    tiles = (n + 31) // 32
+    R = torch.randn(n, F, device=DEV)
+    Rp = torch.zeros(tiles * 32, F, device=DEV)
+    Rp[:n] = R
+    wsfn = L.lib().tn_mlp_bwd_workspace_bytes
+    wsfn.restype = C.c_int64
+    res = {}
+    for skip in (False, True):
+        flags = L.MLP_ROWS_ONLY | (L.MLP_SKIP_LAST if skip else 0)
+        d = m._mlp_desc(ps, x.size(1), enc, nf, L.ACT_NONE, freqs, flags)
+        nb = int(wsfn(C.byref(d), C.c_int64(n)))
+        ws = torch.zeros(nb // 4, device=DEV)
+        y = torch.full((n, F), float("nan"), device=DEV)
+        L.call("tn_mlp_fwd_stash", x.device, C.byref(d), L.ptr(x), C.c_void_p(None), C.c_int64(n), L.ptr(y), L.ptr(ws), C.c_int64(nb))
+        assert torch.isnan(y).all()                                   # TN_MLP_ROWS_ONLY: the row-major output stays unwritten
+        a_off, g_off, m_off, st = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        if skip:
+            L.call_plain("tn_mlp_rows_view_hidden", C.byref(d), C.c_int64(n), C.byref(a_off), C.byref(g_off), C.byref(m_off), C.byref(st))
+        else:
+            L.call_plain("tn_mlp_rows_view", C.byref(d), C.c_int64(n), C.byref(a_off), C.byref(g_off), C.byref(st))
+        assert st.value == F * 32
+
+        def rows(off, count=F):           # `count` rows of every tile, from float offset `off` (a row set may start inside a shared slab)
+            return torch.as_strided(ws, (tiles, count, 32), (st.value, 32, 1), off)
+        if skip:
+            h = rows(a_off.value).transpose(1, 2).reshape(tiles * 32, F)          # the last hidden activation
+            assert float(h.min()) >= 0.0
+            bits = rows(m_off.value, 2 * (F // 32)).reshape(tiles, F // 32, 64).view(torch.int32)
+            assert torch.equal(bits, _bit_rows(h > 0, tiles, F))                   # its ReLU bit rows
+            gh = (Rp @ ps[-2].detach()) * (h > 0)                                  # relu'(h) * (W_last^T R)
+            rows(g_off.value).copy_(gh.view(tiles, 32, F).transpose(1, 2))
+            res["h"] = h
+        else:
+            rows(g_off.value).copy_(Rp.view(tiles, 32, F).transpose(1, 2))
+            res["y"] = rows(a_off.value).transpose(1, 2).reshape(tiles * 32, F)[:n].clone()
+        d.flags = L.MLP_STASHED | L.MLP_GRAD_Y_ROWS | (L.MLP_SKIP_LAST if skip else 0) | (d.flags & (L.MLP_F16X2 | L.MLP_BF16X3))
+        gs = [torch.zeros_like(p) for p in ps]
+        nl = len(ps) // 2
+        gw = (C.c_void_p * nl)(*[g.data_ptr() for g in gs[0::2]]); gb = (C.c_void_p * nl)(*[g.data_ptr() for g in gs[1::2]])
+        gx = torch.zeros_like(x) if enc == L.ENC_NONE else None
+        L.call("tn_mlp_bwd", x.device, C.byref(d), L.ptr(x), C.c_void_p(None), C.c_void_p(None), C.c_int64(n), gw, gb, L.ptr(gx), L.ptr(ws), C.c_int64(nb))
+        res[skip] = (gs, gx)
+    # forward: y of the full run = W_last h + b_last of the short run's h (to the f16x2 products' 2^-22)
+    y_ref = (res["h"][:n] @ ps[-2].t() + ps[-1]).detach()
+    assert float((res["y"] - y_ref).abs().max()) <= 2e-5 * float(y_ref.abs().max())
+    full, short = res[False][0], res[True][0]
+    assert float(short[-2].abs().max()) == 0.0 and float(short[-1].abs().max()) == 0.0      # the last layer's gradients are the caller's business
+    for k in range(len(ps) - 2):
+        assert float((short[k] - full[k]).abs().max()) <= 3e-5 * max(float(full[k].abs().max()), 1e-12), k
+    if res[False][1] is not None:
+        assert float((res[True][1] - res[False][1]).abs().max()) <= 3e-5 * float(res[False][1].abs().max())

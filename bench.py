@@ -74,7 +74,7 @@ KERNEL_MODEL = {
 # kernel-name prefixes (scripts/pmc_mfma.sh output) behind each timed tag, for the counter-derived matrix-pipe fraction
 MFMA_KERNELS = {
     "tn_kplanes_mlp_fwd_pair": ["mlp_fwd_kernel<64, true, 12, true, true, true, true", "mlp_fwd_kernel<64, true, 8, true, true, true, true"],
-    "tn_kplanes_mlp_bwd_pair:chain": ["mlp_chain_kernel<64, 4, 8, true, false, true, true>"],
+    "tn_kplanes_mlp_bwd_pair:chain": ["mlp_chain_kernel<64, 4, 8, true, false, true, true"],
     "tn_kplanes_mlp_bwd_pair:wgrad": ["mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1", "wgrad_first_kernel", "wgrad_rc_kernel"],
 }
 # Which matrix instructions a timed launch issues, and the dense peak of THAT class in fp32-equivalent TFLOP/s (a fraction of the fp32 MFMA

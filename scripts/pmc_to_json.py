@@ -37,14 +37,14 @@ def find(sub):
     return next((v for k, v in per.items() if k.startswith(sub)), None)
 
 
-chain = find("mlp_chain_kernel<64, 4, 8, true, false, true, true>")
+chain = find("mlp_chain_kernel<64, 4, 8, true, false, true, true")
 steps = chain["launches_seen"] if chain else 1
 entry = {
     "tn_kplanes_mlp_fwd_pair": total("mlp_fwd_kernel<64, true, 12, true, true, true, true", "mlp_fwd_kernel<64, true, 8, true, true, true, true"),
-    "tn_kplanes_mlp_bwd_pair:chain": total("mlp_chain_kernel<64, 4, 8, true, false, true, true>"),
+    "tn_kplanes_mlp_bwd_pair:chain": total("mlp_chain_kernel<64, 4, 8, true, false, true, true"),
     "tn_kplanes_mlp_bwd_pair:wgrad": total("mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1", "wgrad_first_kernel", "wgrad_rc_kernel"),
     "tn_adam_reg_multi": total("adam_reg_multi_kernel"),
-    "tn_mlp_bwd_pair": total("mlp_chain_kernel<64, 4, 8, true, false, true, false>", "mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1"),
+    "tn_mlp_bwd_pair": total("mlp_chain_kernel<64, 4, 8, true, false, true, false", "mlp_wgrad4_kernel<4", "mlp_wgrad_kernel<64, 1"),
     "tn_mlp_fwd_stash_pair": total("mlp_fwd_kernel<64, true, 16, true, true, true, false", "mlp_fwd_kernel<64, true, 12, true, true, true, false"),
     "tn_kplanes_bwd": total("kplanes_bwd_kernel"), "tn_kplanes_fwd": total("kplanes_fwd_kernel"),
 }

@@ -643,6 +643,7 @@ def main():
             return busy / act if act else None
 
         from tinynerf_amd import fused as _fused
+        from tinynerf_amd import run as _run_mod
         mode = _matmul_mode()
         lean = bool(_fused.KP_LEAN and mode == "f16x2")
 
@@ -653,6 +654,8 @@ def main():
             traffic = pmc.get("per_entry", {}).get(tag) if pmc else None
             cls, limit = launch_class(tag, mode, lean)
             r = {"kernel": tag, "kernels": kernels, "avg_launch_ms": k["avg_ms"], "ms_per_step": k["total_ms"] / args.steps,
+                 **({"shares_the_chip": "TN_ADAM_OVERLAP: tn_adam_reg_multi (side stream) runs beside the first weight-gradient launch; serial: "
+                                        "0.22 ms / 0.83 ms"} if (_run_mod.ADAM_OVERLAP and world == 1 and tag in ("tn_adam_reg_multi", "tn_kplanes_mlp_bwd_pair:wgrad")) else {}),
                  "rows_per_launch": k["avg_rows"], "row": unit, "algorithmic_per_row": unit_work, "traffic": traffic,
                  "traffic_source": PMC_PROFILE if traffic is not None else None, "instructions": cls, "limited_by": limit}
             tflops = unit_work * k["avg_rows"] / sec / 1e12 if bound in ("mfma", "atomic") and unit_work else None
@@ -728,6 +731,9 @@ def main():
                                            "v_mfma_f32_32x32x16_bf16; data-gradient chain and first-layer weight gradients on v_mfma_f32_32x32x2_f32",
                                   "fp32": "every product on v_mfma_f32_32x32x2_f32", "bf16x3": "heads as fp32; wide stacks (other_configs) as exact bf16 triplets"}[mode],
                        "TN_MATMUL": mode, "TN_KP_LEAN": lean,
+                       # N == 1: the planes' optimizer pass runs on a stream of its own beside the weight-gradient launches -- the per-launch times
+                       # of tn_adam_reg_multi and tn_kplanes_mlp_bwd_pair:wgrad below are times SHARING the chip (their sum is not step time)
+                       "TN_ADAM_OVERLAP": bool(_run_mod.ADAM_OVERLAP and world == 1),
                        "parallelism": (f"dp{world} ({args.scaling} scaling: " + ("every rank runs the recipe's batch" if args.scaling == "weak" else
                                                                                  f"the recipe's B*S samples per step split over the ranks, {1024 // world} rays per loader batch and rank")
                                        + f"): rays sharded over {world} ranks (one per GPU), RCCL all-reduce of plane / MLP gradients"

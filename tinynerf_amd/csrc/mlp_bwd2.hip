@@ -776,7 +776,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_wgrad4_kernel(WgradArgs a, const 
             e = e < 0 ? 0 : (e > xlast ? xlast : e);
             const f32x4 *px = reinterpret_cast<const f32x4 *>(x + e);
             const f32x4 *pr = src + (c < g_chunks ? c : 0);
-            pre[k] = *(c < g_chunks ? pr : px);
+            // (xw == 0: x lives in a producer's row view -- the idle chunk slots re-read workspace chunk 0 instead of streaming 20 KB of an x
+            // nobody stages per tile; x may then be a placeholder of any size)
+            pre[k] = *((c < g_chunks || xw == 0) ? pr : px);
         }
         if constexpr (AUX) {
             const int s_ = (threadIdx.x >> 4) & 31, part = threadIdx.x & 15;

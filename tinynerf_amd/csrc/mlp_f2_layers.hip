@@ -42,6 +42,9 @@ struct Op2 { u32x4 hi, lo; };            // 8 values as two packed-fp16 operands
 // TN_F2_NT: non-temporal hints on the row streams of these kernels (bit 0: LDS-direct loads of the forward / data gradient,
 // bit 1: row stores).  In the slab layout a layer launch reads one dense 1 GB array and writes another; nothing is re-read from a
 // cache, and the same copy runs at 5.9 instead of 5.5 TB/s with the hints (scripts/microbench/row_copy.hip).
+// Ablation switches of DESIGN 4.2 (round 5; scripts/build_dev_lib.sh builds a second library with one of them set): TN_ABL_NOMFMA /
+// TN_ABL_NOSTORE / TN_ABL_NOMAX / TN_ABL_NOEPI take the matrix products / row stores / column maxima / epilogue arithmetic out of the
+// forward kernel, TN_F2_SB=(void)0 the scheduling barriers out of the k loop.  None is set in the shipped build.
 #ifndef TN_F2_SB
 #define TN_F2_SB __builtin_amdgcn_sched_barrier(0)
 #endif

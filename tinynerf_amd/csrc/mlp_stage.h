@@ -137,18 +137,13 @@ __device__ __forceinline__ global_char *wave_uniform_global(const void *p) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return reinterpret_cast<global_char *>(((uint64_t)hi << 32) | lo);
 }
-#ifndef TN_ROWS_NT
-#define TN_ROWS_NT 0
-#endif
 __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x16 &t, int ob, int j, int h) {
     global_char *base = wave_uniform_global(rows + 32 * ob * 32);
     unsigned off = (unsigned)(4 * h * 32 + j) * 4u;
     asm volatile("" : "+v"(off));                          // (keeps the zero-extension at the access)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        auto *d = reinterpret_cast<__attribute__((address_space(1))) float *>(base + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128));
-        if (TN_ROWS_NT) __builtin_nontemporal_store(t[r], d); else *d = t[r];
-    }
+    for (int r = 0; r < 16; ++r)          // (nt hints on these stores: no effect on the heads' launches, measured on all three configurations)
+        *reinterpret_cast<__attribute__((address_space(1))) float *>(base + off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128)) = t[r];
 }
 
 // the same rows back into the D layout

@@ -262,12 +262,55 @@ def grads_of(sd: Dict[str, torch.Tensor], loss_fn) -> Dict[str, np.ndarray]:
     return {k: v.grad.numpy() for k, v in leaves.items() if isinstance(v, torch.Tensor) and v.grad is not None}, float(loss)
 
 
+def initial_state(method: str, seed: int, kplanes_resolutions=(128, 256, 512)) -> Dict[str, torch.Tensor]:
+    """The ``state_dict`` the reference's constructors leave behind ``torch.manual_seed(seed)`` (train.py:68-72, run.py:130-152): the
+    same ``torch.nn`` initialisers drawing from the global CPU generator in the same order -- feature module (models.py:59-68 /
+    123-151 / 234-250), ``VanillaOpacityDecoder(dim)`` (models.py:70-77), ``VanillaColorDecoder(8, dim, 64, 3)`` (models.py:79-89).
+    Pinned bit for bit by the sha256 of every initial tensor of the reference's own ``train()`` (golden G22,
+    tests/test_oracle_train_trace.py); the caller's RNG stream is left untouched."""
+    sd: Dict[str, torch.Tensor] = {}
+
+    def mlp_(prefix, n_in, hidden, n_hidden, n_out=None):             # models.py:7-26: Linear, ReLU, n x Sequential(Linear, ReLU), Linear
+        n_out = hidden if n_out is None else n_out
+        dims = [(prefix + "0", n_in, hidden)] + [(prefix + f"{2 + i}.0", hidden, hidden) for i in range(n_hidden)] + \
+               [(prefix + f"{2 + n_hidden}", hidden, n_out)]
+        for name, i, o in dims:
+            lin = torch.nn.Linear(i, o)
+            sd[name + ".weight"], sd[name + ".bias"] = lin.weight.detach(), lin.bias.detach()
+
+    def freqs_(n):                                                    # models.py:33
+        return 2 ** torch.arange(0, n) * torch.pi
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        if method == "vanilla":
+            sd["feature_module.encoding.freqs"] = freqs_(10)
+            mlp_("feature_module.net.net.", 60, 256, 8)
+            dim = 256
+        elif method == "kplanes":
+            for s, r in enumerate(kplanes_resolutions):
+                for p in range(3):
+                    sd[f"feature_module.planes.{s}.{p}.plane"] = torch.nn.init.uniform_(torch.empty(1, 32, r, r))
+            dim = 32 * len(kplanes_resolutions)
+        elif method == "cobafa":
+            for i, (r, c) in enumerate(zip(torch.linspace(32., 128, 6).int().tolist(), [8, 8, 8, 4, 4, 4])):
+                sd[f"feature_module.basis_grids.{i}.grid"] = torch.nn.init.uniform_(torch.empty(1, c, r, r, r))
+            sd["feature_module.coef_grid.grid"] = torch.nn.init.uniform_(torch.empty(1, 6, 64, 64, 64))
+            mlp_("feature_module.mlp.net.", 36, 128, 5)
+            dim = 128
+        else:
+            raise NotImplementedError(method)
+        mlp_("sigma_decoder.net.net.", dim, 64, 0, 1)
+        sd["rgb_decoder.pe.freqs"] = freqs_(8)
+        mlp_("rgb_decoder.net.net.", dim + 8 * 2 * 3 + 3, 64, 3, 3)
+    return sd
+
+
 def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d: np.ndarray, rgbs: np.ndarray, *,
                        method: str, batch_size: int, n_samples: int, n_steps: int, occupancy_res: int = 128,
                        bg=(1.0, 1.0, 1.0), grad_scale: float = 1024.0, vanilla_freqs: int = 10, scene_type: str = "aabb",
                        scene_scale: float = 1.0, cobafa_freqs=None, occ_updates: int = 0, grid0=None, grids_out=None,
                        stochastic_seed: Optional[int] = None, eval_at=(), eval_fn=None, on_step=None, replay: Optional[dict] = None,
-                       lr: float = 1e-2):
+                       lr: float = 1e-2, loader: str = "stream", lrs_out=None):
     """The reference's train() loop (run.py:97-319) on CPU in deterministic form: consecutive rays instead of a
     shuffled loader, no sampling jitter, voxel-centre occupancy refresh.  Literals as in run.py:100-114,186-202,
     including the scaled-and-never-unscaled loss.  Returns (losses, final state dict, per-step sample counts).
@@ -286,7 +329,11 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
     last batch of a DataLoader); sampling jitter of the step's b-th loader batch, ray i, candidate k = ``orc.uniform01(jitter_seed(s,
     step, r), (b * B + i) * S + k)``; voxel jitter of a refresh = ``orc.uniform01(refresh_seed(s, step), ((slice * H * W + h * W + w) * 3
     + c)``.  With the same parameters the two sides then walk the SAME rays with the SAME jitter: their trajectories differ by fp32
-    summation order only (tests/test_hip_psnr.py, golden G18)."""
+    summation order only (tests/test_hip_psnr.py, golden G18).
+    ``loader="dataloader"`` (round 6, with ``replay``): the permutations are walked as ``DataLoader(shuffle=True)`` walks them
+    (run.py:116-122,221-225) -- the partial last batch of an epoch is handed out as it is and the next epoch starts with a fresh
+    permutation -- which is how ``oracle/make_train_trace.py`` drives the reference's own ``train()``: golden G22 holds this function
+    to that run (tests/test_oracle_train_trace.py).  ``lrs_out`` (a list) receives the learning rate after every ``scheduler.step()``."""
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("freqs") else v.clone())
           for k, v in sd0.items()}
     params = [v for v in sd.values() if v.requires_grad]
@@ -325,6 +372,11 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
 
         def replay_loader():            # tinynerf_amd/run.py Trainer._epoch_block with cfg.host_shuffle
             buf = np.empty(0, np.int64)
+            while loader == "dataloader":
+                perm = torch.randperm(M, generator=host_gen, dtype=torch.int32).numpy().astype(np.int64)
+                for b0 in range(0, M, batch_size):
+                    idx = perm[b0:b0 + batch_size]
+                    yield rays_o[idx], rays_d[idx], rgbs[idx]
             while True:
                 while buf.shape[0] < batch_size:
                     buf = np.concatenate([buf, torch.randperm(M, generator=host_gen, dtype=torch.int32).numpy().astype(np.int64)])
@@ -395,6 +447,8 @@ def reference_training(sd0: Dict[str, torch.Tensor], rays_o: np.ndarray, rays_d:
         (loss * grad_scale).backward()
         opt.step()
         sched.step()
+        if lrs_out is not None:
+            lrs_out.append(float(opt.param_groups[0]["lr"]))
         losses.append(float(loss.detach()))
         counts.append((int(packed.shape[0]), int(info.shape[0])))
     if n_steps in eval_at and eval_fn is not None:

@@ -1,0 +1,112 @@
+"""G22 on the GPU: the HIP harness against the record of the reference's OWN ``train()`` (oracle/make_train_trace.py ran
+``src.run.train`` on the reference's hotdog fixture with regenerable random streams; tests/test_oracle_train_trace.py holds the CPU
+port to the same record, bit for bit).
+
+The test body is the reference's loop (run.py:205-261) with the HIP objects in place of the reference's: loader batches walked as
+``DataLoader(shuffle=True)`` walks a permutation (partial last batch, fresh permutation per epoch), ``RayProvider`` per loader batch
+with the recorded jitter stream, the projection rule, ``Trainer.step_on_batch`` for everything behind the batch (refresh, render,
+loss, TV, scaled-never-unscaled backward, Adam, MultiStepLR).  Nothing of the reference is needed at run time: the golden carries
+what it did."""
+import numpy as np
+import pytest
+import torch
+
+import _g22
+from oracle import tinynerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _loader(M, B, seed):
+    """run.py:116-122,221-225 with the trace's permutation stream (oracle/make_train_trace.py LoaderRec)"""
+    gen = torch.Generator().manual_seed(seed * 1000003 + 1)
+    while True:
+        perm = torch.randperm(M, generator=gen, dtype=torch.int32).to(torch.int64)
+        for b0 in range(0, M, B):
+            yield perm[b0:b0 + B]
+
+
+def _run(name, n_steps=None):
+    from tinynerf_amd.run import TrainConfig, Trainer, jitter_seed
+    g = _g22.trace(name)
+    o, d, rgbs, bg = _g22.ray_table()
+    method, seed, B, S = str(g["method"]), int(g["seed"]), int(g["batch_size"]), int(g["n_samples"])
+    K = int(g["steps"]) if n_steps is None else n_steps
+    dev = torch.device(DEV)
+    o_t, d_t, rgb_t = (torch.from_numpy(a).to(dev) for a in (o, d, rgbs))
+    cfg = TrainConfig(method=method, scene_type="aabb", batch_size=B, n_samples=S, seed=seed)
+    tr = Trainer(cfg, o_t, d_t, rgb_t, torch.from_numpy(bg).to(dev), dev)
+    assert tr.steps == int(g["total_steps"])
+    stream = _loader(o.shape[0], B, seed)
+    target_size = B * S
+    ladder = _g22.decay_ladder()
+    losses, lrs, counts, flips, occ = [], [], [], [], []
+    for step in range(K):
+        refresh = step % tr.occupancy_grid_updates == 0
+        # ---- run.py:215-244, literally ----
+        current_size, projected_size, tmp_count = 0, 0, 0
+        acc_info, acc_samples, acc_rgbs = [], [], []
+        while projected_size < target_size:
+            idx = next(stream).to(dev)
+            r0 = tmp_count * B
+            ctr = np.arange(r0, r0 + idx.numel(), dtype=np.uint64)[:, None] * np.uint64(S) + np.arange(S, dtype=np.uint64)[None, :]
+            jit = torch.from_numpy(orc.uniform01(jitter_seed(seed, step), ctr)).to(dev)          # the trace's stand-in for core.py:173
+            samples, info = tr.ray_provider(o_t[idx], d_t[idx], training=True, jitter=jit)
+            info = info.clone()
+            info[:, 0] += current_size
+            acc_info.append(info); acc_samples.append(samples); acc_rgbs.append(rgb_t[idx])
+            current_size += samples.size(0)
+            tmp_count += 1
+            projected_size = int(current_size * (1 + 1 / tmp_count))
+        packed, target, info = torch.cat(acc_samples, 0), torch.cat(acc_rgbs, 0), torch.cat(acc_info, 0)
+        counts.append((packed.size(0), info.size(0), tmp_count))
+        tr.renderer._batch_aux = None            # (a hand-built batch: the fused node derives ray ids / steps itself)
+        tr.step_on_batch(packed, info, target, tmp_count, prefetch=False)
+        losses.append(tr.loss_value())
+        lrs.append(float(tr.optimizer.param_groups[0]["lr"]))
+        occ.append(tr.occupancy_grid.occupancy())
+        if refresh:
+            i = int(np.nonzero(g["grid_steps"] == step)[0][0])
+            got = tr.occupancy_grid.grid.cpu().numpy()
+            flips.append(float((got != ladder[g["grid_decays"][i]]).mean()))
+            assert abs(tr.occupancy_grid.mean - g["grid_means"][i]) < 2e-3
+    return g, K, tr, np.array(losses), lrs, counts, flips, occ
+
+
+def _check(name, n_exact, loss_rel, param_rel, flip_bound):
+    g, K, tr, losses, lrs, counts, flips, occ = _run(name)
+    ref = g["loss"][:K]
+    # batch structure: bit-exact sampler + rule on the same rays / jitter, for as long as the occupancy grids agree cell for cell
+    # (a cell whose alpha sits within rounding of the threshold may flip: then a handful of samples differ)
+    exact = [c[0] for c in counts[:n_exact]]
+    np.testing.assert_array_equal(exact, g["n_samples_per_step"][:n_exact])
+    np.testing.assert_array_equal([c[1] for c in counts], g["n_rays_per_step"][:K])          # rays and loader batches: always
+    np.testing.assert_array_equal([c[2] for c in counts], g["loader_batches_per_step"][:K])
+    assert np.abs(np.array([c[0] for c in counts]) / g["n_samples_per_step"][:K] - 1).max() < 2e-3
+    np.testing.assert_array_equal(lrs, g["lr_after_step"][:K])                               # run.py:188-199
+    assert max(flips) <= flip_bound, flips
+    np.testing.assert_allclose(occ, g["occupancy"][:K], atol=2e-3)
+    np.testing.assert_allclose(losses[0], ref[0], rtol=1e-5)
+    rel = np.abs(losses / ref - 1)
+    print(name, "loss rel diff: first 8", rel[:8], "max", rel.max(), "flips", flips)
+    assert rel.max() <= loss_rel, rel
+    sd = {k: v.detach().cpu().contiguous().numpy() for k, v in tr.renderer.state_dict().items()}
+    worst = _g22.compare_final_state(g, sd, param_rel, "tinynerf_amd.run.Trainer")
+    print(name, "parameters after", K, "steps, largest difference / largest value:", max(worst.values()), max(worst, key=worst.get))
+
+
+def test_hip_trainer_follows_the_reference_train_loop_kplanes():
+    # tolerances of tests/test_hip_training.py (free-running trajectories: Adam turns ulp differences of a gradient into lr-sized
+    # differences of a parameter wherever |g| is rounding noise): loss 3e-2; parameters within 36 steps x lr 1e-2 of travel
+    _check("kplanes", n_exact=36, loss_rel=3e-2, param_rel=5e-2, flip_bound=2e-3)
+
+
+def test_hip_trainer_follows_the_reference_train_loop_vanilla(matmul):
+    _check("vanilla", n_exact=36, loss_rel=3e-2, param_rel=5e-2, flip_bound=2e-3)
+
+
+def test_hip_trainer_follows_the_reference_across_refreshes_and_an_lr_milestone():
+    """B = 65536: 128 recipe steps, a refresh EVERY step (run.py:103: int(16 * 4096 / B) = 1) -- cells cross the threshold after 16 of
+    them and the sampler starts culling -- and the first MultiStepLR milestone at step 64 (run.py:188-199)"""
+    _check("kplanes_lr", n_exact=16, loss_rel=3e-2, param_rel=5e-2, flip_bound=2e-3)

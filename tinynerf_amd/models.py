@@ -485,9 +485,10 @@ class KPlanesFeaturePlane(torch.nn.Module):
     ):
         super().__init__()
         self.feature_dim = feature_dim
-        # logical [1,C,H,W] like the reference; physically channel-last so a texel is one cache line
-        self.plane = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution).contiguous(memory_format=torch.channels_last))
-        init(self.plane)
+        # logical [1,C,H,W] like the reference; physically channel-last so a texel is one cache line.  The initialiser fills a
+        # tensor in MEMORY order, so it runs on the reference's contiguous layout first: the same seed then gives the same logical
+        # values as models.py:102-103 (golden G22 holds the constructors to the reference's, bit for bit)
+        self.plane = torch.nn.Parameter(init(torch.empty(1, feature_dim, *resolution)).contiguous(memory_format=torch.channels_last))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (..., 2) -> (..., C).  A single plane is the field kernel with one scale whose other two
@@ -736,9 +737,9 @@ class CobafaGrid(torch.nn.Module):
         resolution = (res, res, res) if isinstance(res, int) else tuple(res)
         if feature_dim > 8:
             raise ValueError("CobafaGrid: the gather kernel holds at most 8 channels per voxel")
-        self.grid = torch.nn.Parameter(torch.empty(1, feature_dim, *resolution).contiguous(memory_format=torch.channels_last_3d))
+        # (initialised in the reference's contiguous layout, then re-laid out: same seed -> same logical values as models.py:224-225)
+        self.grid = torch.nn.Parameter(init(torch.empty(1, feature_dim, *resolution)).contiguous(memory_format=torch.channels_last_3d))
         self.feature_dim = feature_dim
-        init(self.grid)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         one = torch.ones((1, 1, 1, 1, 1), device=x.device)

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
     from tinynerf_amd import _lib as L
-    assert lib.tn_abi_version() == L.ABI_VERSION == 5          # (header TN_ABI_VERSION; _lib.lib() refuses any other library)
+    assert lib.tn_abi_version() == L.ABI_VERSION == 6          # (header TN_ABI_VERSION; _lib.lib() refuses any other library)
 
 
 def test_integration_guide_covers_every_entry_point():

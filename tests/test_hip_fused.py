@@ -1,0 +1,122 @@
+"""The wide stacks as ONE persistent launch (csrc/mlp_fused_f2.hip, round 6: activations in registers across all layers, weights
+streamed through LDS) against the CPU port of the reference's modules (models.py:7-28,59-68,239-247) and against the layer-by-layer
+launches of rounds 3 - 5 on the same inputs.  Tolerance: the north star's 1e-5 of the largest output, as for every MLP-class test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_port as tp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _vanilla(seed, scale=1.0):
+    from tinynerf_amd import models
+    torch.manual_seed(seed)
+    m = models.VanillaFeatureMLP(10, 256, 8).to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(scale)
+    return m
+
+
+def _ref_vanilla(m, x):
+    sd = {"feature_module." + k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        return tp.mlp(sd, "feature_module.net.net.", tp.posenc(x.cpu(), sd["feature_module.encoding.freqs"])).numpy()
+
+
+def _both(module, x):
+    from tinynerf_amd.models import _FusedMLP
+    with torch.no_grad():
+        fused = module(x).cpu().numpy()
+        _FusedMLP.layerwise_inference = True
+        try:
+            layer = module(x).cpu().numpy()
+        finally:
+            _FusedMLP.layerwise_inference = False
+    return fused, layer
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 129, 4097, 100003])
+def test_vanilla_stack_in_one_launch(n):
+    """ragged sizes: one sample, partial tiles, fewer tiles than waves of a workgroup, more rounds than one"""
+    from tinynerf_amd import models
+    if models.MATMUL != "f16x2":
+        pytest.skip("the cross-layer launch is the f16x2 form")
+    m = _vanilla(3)
+    torch.manual_seed(n)
+    x = (torch.rand(n, 3, device=DEV) * 2 - 1)
+    fused, layer = _both(m, x)
+    ref = _ref_vanilla(m, x)
+    tol = 1e-5 * np.abs(ref).max()
+    assert np.isfinite(fused).all()
+    assert np.abs(fused - ref).max() <= tol, (np.abs(fused - ref).max(), tol)
+    assert np.abs(layer - ref).max() <= tol
+    assert np.abs(fused - layer).max() <= tol
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 30.0])
+def test_vanilla_stack_scales(scale):
+    """weights 1000 x smaller / 30 x larger than torch's initialisation: activations shrink / grow by that factor per layer (1e-30 ..
+    1e+14 over ten layers); the a-priori bound behind the per-sample scales must neither overflow fp16 nor lose the small columns"""
+    from tinynerf_amd import models
+    if models.MATMUL != "f16x2":
+        pytest.skip("the cross-layer launch is the f16x2 form")
+    m = _vanilla(5, scale)
+    x = torch.rand(5000, 3, device=DEV) * 2 - 1
+    fused, layer = _both(m, x)
+    sd = {"feature_module." + k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref64 = tp.mlp(sd, "feature_module.net.net.", tp.posenc(x.cpu().double(), sd["feature_module.encoding.freqs"])).numpy()
+    ref32 = _ref_vanilla(m, x)
+    scale_ = np.abs(ref64).max()
+    e_fused, e_layer, e_torch = (np.abs(a - ref64).max() / scale_ for a in (fused, layer, ref32))
+    print(f"scale {scale}: distance to fp64 / largest output: fused {e_fused:.2e} layer-wise {e_layer:.2e} torch fp32 {e_torch:.2e}")
+    assert np.isfinite(fused).all()
+    assert e_fused <= max(1e-5, 4 * e_torch)
+
+
+def test_cobafa_stack_in_one_launch():
+    """Cobafa's 128-wide stack (models.py:247: MLP(36, 128, 5)) on plain inputs"""
+    from tinynerf_amd import models
+    if models.MATMUL != "f16x2":
+        pytest.skip("the cross-layer launch is the f16x2 form")
+    torch.manual_seed(11)
+    m = models.MLP(36, 128, 5).to(DEV)
+    x = torch.randn(70001, 36, device=DEV) * 0.3
+    fused, layer = _both(m, x)
+    sd = {"m." + k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = tp.mlp(sd, "m.net.", x.cpu()).numpy()
+    tol = 1e-5 * np.abs(ref).max()
+    assert np.abs(fused - ref).max() <= tol, (np.abs(fused - ref).max(), tol)
+    assert np.abs(fused - layer).max() <= tol
+
+
+def test_rows_of_one_tile_orders_of_magnitude_apart():
+    """Cobafa-style plain inputs whose rows differ by 12 orders of magnitude inside one 32-sample tile, and zero rows: scales are per
+    sample, so every row keeps fp32 accuracy relative to ITS OWN output"""
+    from tinynerf_amd import models
+    if models.MATMUL != "f16x2":
+        pytest.skip("the cross-layer launch is the f16x2 form")
+    torch.manual_seed(13)
+    m = models.MLP(36, 128, 5).to(DEV)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("bias"):
+                p.zero_()                       # (homogeneous stack: the output scales with the input row)
+    x = torch.randn(64, 36, device=DEV)
+    mag = 10.0 ** torch.linspace(-6, 6, 64, device=DEV)
+    x = x * mag[:, None]
+    x[5] = 0
+    fused, _ = _both(m, x)
+    sd = {"m." + k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = tp.mlp(sd, "m.net.", x.cpu().double()).numpy()
+    row_scale = np.abs(ref).max(axis=1)
+    err = np.abs(fused - ref).max(axis=1)
+    ok = err <= 2e-5 * row_scale + 1e-30
+    assert ok.all(), (err / np.maximum(row_scale, 1e-300))[~ok]
+    assert (fused[5] == 0).all()

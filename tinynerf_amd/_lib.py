@@ -78,7 +78,8 @@ MLP_ROWS_ONLY = 128
 MLP_X_FROM_ROWS = 256
 MLP_LEAN = 512
 MLP_SKIP_LAST = 1024
-ABI_VERSION = 5            # include/tinynerf_hip.h TN_ABI_VERSION: a stale library (TN_LIB_PATH, a forgotten rebuild) fails at load, not in a kernel
+MLP_LAYERWISE = 2048
+ABI_VERSION = 6            # include/tinynerf_hip.h TN_ABI_VERSION: a stale library (TN_LIB_PATH, a forgotten rebuild) fails at load, not in a kernel
 
 
 class PlaneRegItem(C.Structure):

@@ -42,6 +42,7 @@ SOURCES = {
     "mlp_wgrad_rc.hip": FAST + ["-munsafe-fp-atomics"],
     "linear.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_f2_layers.hip": FAST + ["-munsafe-fp-atomics"],
+    "mlp_fused_f2.hip": FAST,
     "mlp_b3_layers.hip": FAST + ["-munsafe-fp-atomics"] + (["-DTN_B3_ABLATE=" + os.environ["TN_B3_ABLATE"]] if os.environ.get("TN_B3_ABLATE") else [])
                          + os.environ.get("TN_B3_EXTRA_FLAGS", "").split(),        # (timing experiments: extra hipcc flags for this file)
 }

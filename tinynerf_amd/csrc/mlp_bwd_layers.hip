@@ -1062,6 +1062,9 @@ __host__ inline bool layer_kernel_path(int H, int L, int out) { return H >= 128 
 // encoded-input rows) instead of one buffer per layer -- (2 H + rowsE) * 128 B per 32 samples (2.3 KB per sample for the
 // Vanilla stack against 11.5 KB of training workspace).
 __host__ inline int infer_rows_total(int H, const Layout &lay) { return 2 * H + lay.rowsE; }
+__host__ inline int64_t infer_ws_rows_bytes(int H, const Layout &lay, int64_t n_tiles) {       // (256-byte multiple: the packed stream of the fused form follows)
+    return ((n_tiles * (int64_t)std::max(infer_rows_total(H, lay), 64) * 32 * (int64_t)sizeof(float)) + 255) & ~(int64_t)255;
+}
 
 // Where the row sets of a training workspace live; every kernel addresses  row = tile * rows_total + off.
 //   * tile-major (make_layout; what the general-shape kernels compute for themselves): a tile holds all its row sets back to back,
@@ -1142,6 +1145,18 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 if (me != hipSuccess) { tn::set_error("mlp_fwd(f16x2): cannot clear the workspace tail: %s", hipGetErrorString(me)); return (int)me; }
             }
             const bool plain = plain_x_rows(H, L, a.enc, a.K0_pad, out) && lay.rowsE == 64;
+            if (inference && !a.layerwise && fused_fwd_ok(H, a) && ((a.enc == TN_ENC_POSENC && a.K0_pad <= 64) || plain)) {
+                // round 6: the whole stack as ONE persistent launch (mlp_fused_f2.hip) -- the workspace holds the encoded input rows (64 per
+                // tile, contiguous over the tiles) and, behind the layer-wise form's area, the packed weight stream
+                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, 64, 0, plain ? 64 : a.K0_pad);
+                if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
+                if (!plain && a.K0_pad < 64) {               // rows K0_pad .. 63 of every tile are operands too (zero weights, but 0 x NaN = NaN)
+                    hipError_t me = hipMemset2DAsync(stash + (size_t)a.K0_pad * 32, 64 * 128, 0, (size_t)(64 - a.K0_pad) * 128, (size_t)n_tiles, s);
+                    if (me != hipSuccess) { tn::set_error("mlp_fwd(fused): cannot clear the padding rows: %s", hipGetErrorString(me)); return (int)me; }
+                }
+                void *pack = reinterpret_cast<unsigned char *>(stash) + infer_ws_rows_bytes(H, lay, n_tiles);
+                return launch_fused_fwd_f2(H, a, n, stash, y, pack, s);
+            }
             if ((a.enc == TN_ENC_POSENC && a.K0_pad <= 64) || plain) {      // (encoded) inputs as rows, then the first layer like any other
                 enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE,
                                                                                                                   plain ? 64 : a.K0_pad);
@@ -1418,7 +1433,8 @@ extern "C" int64_t tn_mlp_fwd_workspace_bytes(const tn_mlp_desc *desc, int64_t n
         !(desc->encoding == TN_ENC_POSENC || plain_x_rows(H, L, desc->encoding, K0p, out))) return 0;
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
     const Layout lay = make_layout(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, out);
-    return ((n + 31) / 32) * (int64_t)infer_rows_total(H, lay) * 32 * (int64_t)sizeof(float);
+    // the layer-wise form's ping-pong rows, then the packed weight stream of the cross-layer form (mlp_fused_f2.hip; 2.4 MB for Vanilla)
+    return infer_ws_rows_bytes(H, lay, (n + 31) / 32) + fused_pack_bytes(H, L);
 }
 
 extern "C" int tn_mlp_fwd_ws(const tn_mlp_desc *desc, const float *x, const float *aux, int64_t n, float *y, void *workspace,

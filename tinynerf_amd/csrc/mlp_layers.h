@@ -101,5 +101,10 @@ int launch_fwd_first_f2(int H, const FwdLayerArgs &f, int64_t n, float *stash, h
 int launch_dgrad_f2(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s);
 int launch_wgrad_f2(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
 
+// ---- all layers of a wide stack in one persistent launch (mlp_fused_f2.hip, round 6): inference forward ----
+int64_t fused_pack_bytes(int H, int L);
+bool fused_fwd_ok(int H, const tn::mlp::MlpArgs &a);
+int launch_fused_fwd_f2(int H, const tn::mlp::MlpArgs &a, int64_t n, const float *e_rows, float *y, void *pack_area, hipStream_t s);
+
 }  // namespace layers
 }  // namespace tn

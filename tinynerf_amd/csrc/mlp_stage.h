@@ -33,6 +33,7 @@ struct MlpArgs {
     const unsigned *gx_mask_rows = nullptr;     // tn_mlp_desc::grad_x_mask_rows: relu' bits applied to grad_x_rows
     int64_t gx_mask_stride = 0;
     int skip_last = 0;                          // TN_MLP_SKIP_LAST
+    int layerwise = 0;     // TN_MLP_LAYERWISE: no cross-layer persistent launch (mlp_fused_f2.hip)
     int lean;              // TN_MLP_LEAN: the training forward leaves the H rows of the workspace unwritten (mlp_wgrad_rc.hip rebuilds them)
     int f2_plane[TN_MLP_MAX_LAYERS], f2_scale;     // f16x2 heads (mlp_f2_heads.h): halfs per weight plane, float index of the (s, 1 / s) pairs
 };
@@ -214,6 +215,7 @@ inline int plan(const tn_mlp_desc *d, MlpArgs &a, int &H)
     a.x_from_rows = (d->flags & TN_MLP_X_FROM_ROWS) != 0;
     a.lean = (d->flags & TN_MLP_LEAN) != 0;
     a.skip_last = (d->flags & TN_MLP_SKIP_LAST) != 0;
+    a.layerwise = (d->flags & TN_MLP_LAYERWISE) != 0;
     a.gx_mask_rows = reinterpret_cast<const unsigned *>(d->grad_x_mask_rows); a.gx_mask_stride = d->grad_x_mask_tile_stride;
     TN_REQUIRE(!a.gx_mask_rows || (d->grad_x_rows && (((uintptr_t)a.gx_mask_rows) & 3) == 0), TN_E_CONFIG, "mlp: grad_x_mask_rows goes with grad_x_rows");
     a.x_rows = d->x_rows; a.gx_rows = d->grad_x_rows; a.x_rows_stride = d->x_rows_tile_stride; a.gx_rows_stride = d->grad_x_rows_tile_stride;

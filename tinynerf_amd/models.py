@@ -80,6 +80,8 @@ class _FusedMLP(Function):
     consumes (tn_mlp_fwd_stash), otherwise the backward recomputes the hidden activations."""
 
     stash_forward = True   # training forward writes the activation workspace (tn_mlp_fwd_stash); False: backward recomputes
+    layerwise_inference = False   # True: tn_mlp_fwd_ws one launch per layer (TN_MLP_LAYERWISE) instead of the cross-layer persistent launch --
+                                  # the parity partner of tests/test_hip_fused.py and the A side of scripts/fused_fwd_time.py
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
@@ -141,6 +143,8 @@ class _FusedMLP(Function):
             fwd_ws = L.lib().tn_mlp_fwd_workspace_bytes
             fwd_ws.restype = C.c_int64
             chunk = 1 << 22
+            if _FusedMLP.layerwise_inference:
+                desc.flags |= L.MLP_LAYERWISE
             nbytes = int(fwd_ws(C.byref(desc), C.c_int64(min(n, chunk)))) if (n > 0 and aux2 is None) else 0
             if nbytes:
                 wsi = torch.empty(nbytes // 4, device=dev)

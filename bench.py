@@ -187,7 +187,9 @@ def parse():
     ap.add_argument("--views", type=int, default=20, help="synthetic 800x800 cameras (640k rays each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rates (profiling runs)")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 19)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 20, help="packed samples per timed call of the CPU baseline (BASELINE.md: 2^20)")
+    ap.add_argument("--full-recipe", action="store_true", help="soak: the reference's whole schedule (8192 steps at B = 1024, LR milestones, "
+                    "128 occupancy refreshes) on this workload; prints its own JSON line (time to train, held-out PSNR, step-time extremes)")
     ap.add_argument("--other-steps", type=int, default=8, help="steps per window of the Vanilla / Cobafa side runs")
     ap.add_argument("--other-windows", type=int, default=3)
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the first one is the measurement")
@@ -243,57 +245,84 @@ class KernelTimer:
         return out
 
 
+def physical_cores() -> int:
+    """physical cores of the host (unique (package, core) pairs of /proc/cpuinfo); os.cpu_count() when that cannot be read"""
+    try:
+        pairs, pkg = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                pairs.add((pkg, ln.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(trainer, n_target: int):
-    """The CPU port of the same training step (render fwd + loss + bwd) on a bounded sample of the same
-    workload: the first rays of a real batch totalling ~n_target packed samples."""
+    """BASELINE.md's protocol: the CPU port of the hot path on the GPU box's host, N = 2^20 packed samples of the same workload per timed
+    call (the first rays of real dynamic batches), 1 warm-up + median of 5, the three stages -- sampler, render forward, render forward +
+    loss + backward -- timed separately at ONE stated thread count.  torch's CPU kernels stop scaling well before all hardware threads of
+    this host (256 threads ran the port 140 x slower than 32), so the count is min(physical cores, 64)."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import tinynerf_oracle as orc
     from oracle import torch_port as tp
-    packed, info, target, _ = trainer.build_batch()
-    cnt = info[:, 1].long().cumsum(0)
-    R = int((cnt <= n_target).sum().item())
-    n = int(cnt[R - 1].item())
-    packed, info, target = packed[:n].cpu(), info[:R].cpu(), target[:R].cpu()
+    phys, logical = physical_cores(), os.cpu_count() or 1
+    threads = max(1, min(phys, 64))
+    torch.set_num_threads(threads)
+    packs, infos, tgts, n, R = [], [], [], 0, 0
+    while n < n_target:                                   # a dynamic batch is ~2^20 samples: one or two of them
+        packed, info, target, _ = trainer.build_batch()
+        cnt = info[:, 1].long().cumsum(0)
+        r = int((cnt <= n_target - n).sum().item())
+        if r == 0:
+            break
+        m = int(cnt[r - 1].item())
+        inf = info[:r].clone()
+        inf[:, 0] += n
+        packs.append(packed[:m].cpu()); infos.append(inf.cpu()); tgts.append(target[:r].cpu())
+        n += m; R += r
+    packed, info, target = torch.cat(packs), torch.cat(infos), torch.cat(tgts)
     sd = {k: v.detach().cpu().contiguous() for k, v in trainer.renderer.state_dict().items()}
     bg = trainer.renderer.bg_color.cpu() if trainer.renderer.bg_color is not None else None
-    # torch's CPU kernels stop scaling well before all hardware threads of the GPU box's host (256 threads ran
-    # 140x slower than 32 on the same input): time 32 and 64 threads and report the better one
-    best, cores = None, 1
-    for threads in sorted({min(32, os.cpu_count() or 1), min(64, os.cpu_count() or 1)}):
-        torch.set_num_threads(threads)
-        times = []
-        for it in range(3):
+
+    def med5(fn):
+        fn()                                              # warm-up
+        ts = []
+        for _ in range(5):
             t0 = time.perf_counter()
-            tp.grads_of(sd, lambda p: tp.training_loss(p, packed, info, target, bg))
-            times.append(time.perf_counter() - t0)
-        t = min(times[1:])
-        if best is None or t < best:
-            best, cores = t, threads
-    # the other two stages of SURVEY 8(d), same thread count: render forward alone, and the sampler (numpy restatement of
-    # core.py:165-188, one loader batch of 1024 rays x 1024 candidates against the same occupancy grid)
-    torch.set_num_threads(cores)
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[2]
+    t_fb = med5(lambda: tp.grads_of(sd, lambda p: tp.training_loss(p, packed, info, target, bg)))
     with torch.no_grad():
-        p0 = {k: v for k, v in sd.items()}
-        tp.render(p0, packed, info, bg)
-        t0 = time.perf_counter()
-        tp.render(p0, packed, info, bg)
-        t_fwd = time.perf_counter() - t0
-    from oracle import tinynerf_oracle as orc
+        t_fwd = med5(lambda: tp.render(sd, packed, info, bg))
+    # sampler: the numpy restatement of core.py:165-188 on as many loader batches of the bench's rays as give ~N kept samples, the rays
+    # dealt to `threads` workers (numpy releases the GIL inside its kernels)
     g = trainer.occupancy_grid
-    pick = torch.randint(0, trainer.rays_o.size(0), (1024,), generator=torch.Generator().manual_seed(0)).to(trainer.rays_o.device)
-    o_cpu, d_cpu = trainer.rays_o[pick].cpu().numpy(), trainer.rays_d[pick].cpu().numpy()
     aabb = np.array([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]], np.float32)
     kw = dict(marcher="aabb", contraction="aabb", grid=g.grid.cpu().numpy(), threshold=float(g.threshold), n_samples=trainer.cfg.n_samples,
               near=0.1, aabb=aabb)
-    orc.ray_provider(o_cpu[:64], d_cpu[:64], **kw)
-    t0 = time.perf_counter()
-    pk, _ = orc.ray_provider(o_cpu, d_cpu, **kw)
-    t_samp = time.perf_counter() - t0
-    stages = {"render_fwd_samples_per_s": n / t_fwd, "sampler_samples_per_s": pk.shape[0] / t_samp,
-              "sampler_candidates_per_s": 1024 * trainer.cfg.n_samples / t_samp,
-              "note": "render forward: torch CPU ops on the same sample; sampler: numpy restatement (single thread) on 1024 rays"}
-    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port", "stages": stages,
-            "sample": f"render fwd+loss+bwd of {n} packed samples / {R} rays of the same batch (no Adam step), "
-                      f"torch {torch.__version__} CPU ops + oracle/weights_ref.c, {cores} threads (best of 32/64), best of 2 after warm-up"}
+    n_rays = max(1024, int(R))
+    pick = torch.randint(0, trainer.rays_o.size(0), (n_rays,), generator=torch.Generator().manual_seed(0)).to(trainer.rays_o.device)
+    o_cpu, d_cpu = trainer.rays_o[pick].cpu().numpy(), trainer.rays_d[pick].cpu().numpy()
+    chunks = [slice(i, min(i + 256, n_rays)) for i in range(0, n_rays, 256)]
+    kept = [0]
+
+    def sample_all():
+        with ThreadPoolExecutor(threads) as ex:
+            kept[0] = sum(ex.map(lambda sl: orc.ray_provider(o_cpu[sl], d_cpu[sl], **kw)[0].shape[0], chunks))
+    t_samp = med5(sample_all)
+    stages = {"render_fwd_samples_per_s": n / t_fwd, "render_fwd_bwd_samples_per_s": n / t_fb, "sampler_samples_per_s": kept[0] / t_samp,
+              "sampler_candidates_per_s": n_rays * trainer.cfg.n_samples / t_samp, "sampler_rays": n_rays, "sampler_kept_samples": kept[0]}
+    return {"value": n / t_fb, "unit": "samples/s", "cores": threads, "kind": "port (render forward + loss + backward; no optimizer step)",
+            "threads": threads, "physical_cores": phys, "logical_cpus": logical, "protocol": "BASELINE.md: N = 2^20, 1 warm-up + median of 5 per stage",
+            "stages": stages,
+            "sample": f"{n} packed samples / {R} rays of the bench's own dynamic batches; torch {torch.__version__} CPU kernels + oracle/weights_ref.c "
+                      f"(render), numpy restatement of core.py:165-188 over {threads} worker threads (sampler); every stage at {threads} threads"}
 
 
 def alloc_counters():
@@ -303,7 +332,21 @@ def alloc_counters():
             "segments": int(st.get("segment.all.current", 0)), "reserved_gb": st.get("reserved_bytes.all.current", 0) / 2 ** 30}
 
 
-def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=None):
+def side_profile(method):
+    """committed counter pass of a side configuration's step (scripts/pmc_config.sh -> profiles/round6_<method>_pmc_traffic.json): HBM-side bytes
+    per step and, per kernel, bytes and duration per launch -> GB/s against the HBM peak"""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", f"round6_{method}_pmc_traffic.json")))
+    except Exception:       # noqa: BLE001
+        return None
+    top = []
+    for k, v in list(p.get("kernels", {}).items())[:8]:
+        top.append({"kernel": k, "bound": "hbm", "traffic": v["bytes_per_launch"], "avg_launch_ms_profiled": (v.get("avg_us_profiled") or 0) / 1e3,
+                    "achieved": v.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": v.get("frac_of_hbm_peak"), "launches_per_step": v["launches_per_step"]})
+    return {"hbm_bytes_per_step": p["bytes_per_step"], "rooflines": top, "source": f"profiles/round6_{method}_pmc_traffic.json"}
+
+
+def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=None, held_out=None):
     """One of the reference's other model configurations on the headline's workload: warm up until the scratch arenas and the
     allocator have stopped growing, then `n_windows` windows of `steps` steps (synchronize on both sides); min / median over
     the windows, every step's time from HIP events on the launch stream, and the allocator's counters over the timed region
@@ -381,6 +424,37 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
         else:
             out["mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
             out["mfma_peak"] = {"tflops": PEAK_FP32_MFMA_TFLOPS, "what": "fp32 MFMA peak"}
+    prof = side_profile(method) if matmul is None else None
+    if prof:
+        out["hbm_bytes_per_step"] = prof["hbm_bytes_per_step"]
+        out["hbm_gbs"] = prof["hbm_bytes_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9
+        out["hbm_frac"] = out["hbm_gbs"] / PEAK_HBM_GBS
+        out["rooflines"] = prof["rooflines"]
+        out["hbm_source"] = prof["source"]
+    if held_out is not None and matmul is None:
+        # an 800 x 800 image through the inference path (run.py:15-50): the wide stacks run as ONE persistent launch per chunk (csrc/mlp_fused_f2.hip)
+        import contextlib
+        ho, hd = held_out
+        with contextlib.redirect_stdout(sys.stderr):
+            t2.render_rays(ho, hd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t2.render_rays(ho, hd)
+            torch.cuda.synchronize()
+        out["render_ms"] = (time.perf_counter() - t0) * 1e3
+        if method in ("vanilla", "cobafa"):
+            from tinynerf_amd.models import _FusedMLP
+            _FusedMLP.layerwise_inference = True
+            try:
+                with contextlib.redirect_stdout(sys.stderr):
+                    t2.render_rays(ho, hd)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    t2.render_rays(ho, hd)
+                    torch.cuda.synchronize()
+                out["render_ms_layerwise"] = (time.perf_counter() - t0) * 1e3       # (TN_MLP_LAYERWISE: the form of rounds 3 - 5, same image)
+            finally:
+                _FusedMLP.layerwise_inference = False
     del t2
     tn_models.MATMUL = prev_mode
     return out
@@ -406,6 +480,63 @@ def model_flop_per_sample(renderer):
     if cd_first is not None:
         skip += 2 * 51 * cd_first.out_features                        # d / d [PE(d), d]: not needed
     return 3 * fwd - skip
+
+
+def full_recipe(tr, rays, dev, rank, world, sync):
+    """Soak / stability record (round-5 verdict, item 8): the reference's WHOLE schedule on the bench's workload -- 2048 * 4096 / B = 8192
+    optimizer steps at B = 1024 (run.py:100-103), an occupancy refresh every 64 steps (128 of them), MultiStepLR milestones at 1/2, 3/4, 5/6
+    and 9/10 of the schedule (run.py:188-199) -- timed as a whole, with the step-time distribution from HIP events around blocks of 64 steps,
+    the learning rate at every milestone and the held-out PSNR at the quarter points.  No CPU golden exists at this length (the CPU port
+    needs ~30 s per step); what this shows is that the harness runs the recipe end to end and what it reaches."""
+    from tinynerf_amd.run import psnr as psnr_fn
+    import contextlib
+    ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=800, seed=10_007, device=str(dev))
+    total = tr.steps
+    block = tr.occupancy_grid_updates
+    stream = torch.cuda.current_stream(dev)
+    curve, lrs, evs, samples = {}, {}, [], 0.0
+
+    def heldout():
+        with contextlib.redirect_stdout(sys.stderr), torch.no_grad():
+            return float(psnr_fn(tr.render_rays(ho, hd), hrgb))
+    curve[0] = heldout()
+    sync()
+    t0 = time.perf_counter()
+    t_eval = 0.0
+    for s0 in range(0, total, block):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(min(block, total - s0)):
+            samples += tr.step()["n_samples"]
+        e1.record(stream)
+        evs.append((e0, e1, min(block, total - s0)))
+        lrs[tr.train_step] = float(tr.optimizer.param_groups[0]["lr"])
+        if tr.train_step in (total // 4, total // 2, 3 * total // 4, total):
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            curve[tr.train_step] = heldout()
+            t_eval += time.perf_counter() - te
+    sync()
+    dt = time.perf_counter() - t0 - t_eval
+    per_block = [e0.elapsed_time(e1) / k for e0, e1, k in evs]
+    changes = {}
+    prev = None
+    for st_, lr in sorted(lrs.items()):
+        if lr != prev:
+            changes[st_] = lr
+        prev = lr
+    if rank == 0:
+        print(json.dumps({"full_recipe": {"steps": total, "batch_size": tr.cfg.batch_size, "refresh_every": block, "refreshes": len(evs),
+                                          "time_to_train_s": dt, "samples": samples, "samples_per_s": samples / dt, "ms_per_step_mean": dt / total * 1e3,
+                                          "ms_per_step_blocks_of_%d" % block: {"min": min(per_block), "median": sorted(per_block)[len(per_block) // 2], "max": max(per_block),
+                                                                              "note": "each block holds one occupancy refresh"},
+                                          "heldout_psnr": {str(k): v for k, v in sorted(curve.items())}, "lr_first_seen_at_step": {str(k): v for k, v in changes.items()},
+                                          "milestones": [total // 2, total * 3 // 4, total * 5 // 6, total * 9 // 10], "final_loss": tr.loss_value(),
+                                          "occupancy": tr.occupancy_grid.occupancy(), "finite": all(bool(torch.isfinite(p).all()) for p in tr.renderer.parameters()),
+                                          "n_gpus": world}}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def launch_ranks(args) -> int:
@@ -469,6 +600,12 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+    # how many ranks the collective library actually connects (an all-reduce of ones): a scaling record can be checked against it
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
     from tinynerf_amd import rays
     from tinynerf_amd.run import TrainConfig, Trainer
 
@@ -489,6 +626,9 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.full_recipe:
+        return full_recipe(tr, rays, dev, rank, world, sync)
 
     # Event pairs around EVERY modelled launch cost the step ~0.2 ms (ten records per step, each a marker the queue drains to):
     # 3.29 against 3.10 ms on one box.  So the last warm-up steps time all of them to find the dominant launch, the measured window
@@ -541,6 +681,7 @@ def main():
     # scene -- a camera no rank trains on -- rendered with the parameters as they are after the timed steps (every rank holds the
     # same parameters; rank 0 renders)
     psnr_at_step = None
+    ho = hd = hrgb = None
     if rank == 0:
         from tinynerf_amd.run import psnr as psnr_fn
         ho, hd, hrgb, _, _ = rays.synthetic_scene(n_views=1, res=800, seed=10_007, device=str(dev))
@@ -563,7 +704,6 @@ def main():
                 psnr_at_step["replay"] = psnr_replay(o, d, rgbs, dev, tr.train_step, grid0, ho, hd, hrgb)
             except Exception as e:                                  # noqa: BLE001 -- the headline line must still be printed
                 psnr_at_step["replay"] = {"error": repr(e)}
-        del ho, hd, hrgb
     # the occupancy refresh (run.py:248-249) runs every 16 * 4096 / B steps: a window of K < 64 steps behind a short warm-up
     # never contains one, so its cost is measured here and folded into `value_with_refresh` at its amortised weight
     refresh = None
@@ -617,7 +757,8 @@ def main():
         for key, method, matmul in (("kplanes_fp32_heads", "kplanes", "fp32"), ("vanilla", "vanilla", None), ("cobafa", "cobafa", None),
                                     ("vanilla_bf16x3", "vanilla", "bf16x3"), ("vanilla_fp32_mfma", "vanilla", "fp32")):
             try:
-                others[key] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows, matmul)
+                others[key] = run_other_config(method, o, d, rgbs, tr, dev, args.other_steps, args.other_windows, matmul,
+                                               held_out=(ho, hd) if ho is not None else None)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
                 others[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
@@ -674,10 +815,14 @@ def main():
             if bound == "atomic":   # memory-side fp32 atomics: lane-atomics per launch from the PMC pass (WRITE_SIZE counts 4 B per lane-atomic)
                 lanes = pmc.get("lane_atomics_per_entry", {}).get(tag) if pmc else None
                 ach = lanes / sec / 1e9 if lanes else None
-                r["co_bound"] = {"bound": "atomic", "achieved": ach, "peak": PEAK_ATOMIC_GLANES, "unit": "G lane-atomics/s",
-                                 "frac": ach / PEAK_ATOMIC_GLANES if ach else None, "lane_atomics_per_launch": lanes,
-                                 "peak_source": "scripts/microbench/atomic_scaling.hip (this repo: 325 G/s, random full lines from >= 4096 waves; "
-                                                "history and conditions: DESIGN 4.2)"}
+                if ach:
+                    # the launch is limited by the atomic path, not by the matrix pipe: `bound` says so, the matrix-pipe view moves to `mfma`
+                    r["mfma"] = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "vs_fp32_mfma_peak") if k in r}
+                    r.update(bound="atomic", achieved=ach, peak=PEAK_ATOMIC_GLANES, unit="G lane-atomics/s", frac=ach / PEAK_ATOMIC_GLANES,
+                             lane_atomics_per_launch=lanes,
+                             peak_source="scripts/microbench/atomic_scaling.hip (this repo's measurement: 325 G lane-atomics/s on random full lines from "
+                                         ">= 4096 waves; not a figure of MI355X_MICROARCH.md; history and conditions: DESIGN 4)")
+                    r.pop("vs_fp32_mfma_peak", None)
             if traffic is not None:
                 r["hbm_gbs"] = traffic / sec / 1e9
             try:
@@ -711,19 +856,25 @@ def main():
         summary = {"value": samples / dt, "ms_per_step": step_ms, "windows_median_ms": srt[len(srt) // 2], "matmul": mode, "lean": lean,
                    "kernels_ms": {t.replace("tn_kplanes_mlp_", "").replace("tn_", ""): round(v["total_ms"] / args.steps, 4) for t, v in sorted(ks.items())},
                    "other_ms": {k: round(v["ms_per_step"], 3) for k, v in oc.items() if isinstance(v, dict) and "ms_per_step" in v},
+                   "other_render_ms": {k: round(v["render_ms"], 1) for k, v in oc.items() if isinstance(v, dict) and "render_ms" in v},
                    "render_fwd_samples_per_s": stages["render_fwd_samples_per_s"] if stages else None,
                    "sampler_samples_per_s": stages["sampler_samples_per_s"] if stages else None,
                    "psnr": ({"step": psnr_at_step["step"], "timed_run": round(psnr_at_step["psnr"], 3),
                              **({k: (round(v, 4) if isinstance(v, float) else v) for k, v in (psnr_at_step.get("replay") or {}).items()
                                  if k in ("psnr", "reference", "delta_db")})} if psnr_at_step else None),
                    "hbm_bytes_per_step": whole.get("hbm_bytes_per_step"), "dominant": roof["kernel"] if roof else None,
-                   "dominant_frac": roof["frac"] if roof else None}
+                   "dominant_bound": roof["bound"] if roof else None, "dominant_frac": roof["frac"] if roof else None,
+                   # the same step with every product on v_mfma_f32_32x32x2_f32 (other_configs.kplanes_fp32_heads): the conservative figure
+                   "value_fp32_mfma": (oc.get("kplanes_fp32_heads") or {}).get("samples_per_s"),
+                   "ms_per_step_fp32_mfma": (oc.get("kplanes_fp32_heads") or {}).get("ms_per_step"),
+                   "ranks_seen": ranks_seen}
         line = {
             "summary": summary,
             "metric": "ray-samples/sec (K-Planes training step: sampler + render fwd + bwd + Adam)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (f16x2-split products)" if mode == "f16x2" else ("f32 (bf16x3-split products)" if mode == "bf16x3" else "f32"), "data": "synthetic",
+            "ranks_seen": ranks_seen,
             "config": {"workload": "K-Planes Lego-shaped 800x800, aabb, B=1024 rays x S=1024, dynamic batches of ~2^20 packed samples, 128^3 occupancy ball",
                        # fp32 storage, accumulation and results everywhere; what the matrix products run on (parity tests at the fp32 tolerances):
                        "matmul": {"f16x2": "heads' forward (+ its rebuild inside the weight-gradient launch, TN_MLP_LEAN) as two-term fp16 splits with power-of-two "

@@ -13,6 +13,9 @@ from tinynerf_amd.run import TrainConfig, Trainer                # noqa: E402
 
 method = sys.argv[1] if len(sys.argv) > 1 else "vanilla"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+if "--layerwise" in sys.argv:                                    # A / B: the wide stacks' forward passes one launch per layer (TN_MLP_LAYERWISE)
+    from tinynerf_amd.models import _FusedMLP
+    _FusedMLP.layerwise_training = _FusedMLP.layerwise_inference = True
 dev = torch.device("cuda", 0)
 o, d, rgbs, K, _ = rays.synthetic_scene(n_views=8, res=800, seed=0, device=str(dev))
 cfg = TrainConfig(method=method, scene_type="aabb", batch_size=1024, n_samples=1024, seed=0)

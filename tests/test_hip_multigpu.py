@@ -276,7 +276,7 @@ def _rccl_main(port, method, q):
     from tinynerf_amd.run import Trainer
     o, d, rgb = _scene()
     out = {}
-    for world in (1, 2):
+    for key, world in (("control", 1), (1, 1), (2, 2)):        # "control": the plain step once more -- how far two runs of the SAME path are apart
         tr = Trainer(_cfg(method), o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev, rank=0, world_size=world)
         _no_dropout(tr)
         _half_empty_grid(tr)
@@ -295,7 +295,7 @@ def _rccl_main(port, method, q):
             st = tr.step()
             steps.append((int(st["n_samples"]), {k: v.cpu().numpy() for k, v in cap["g"].items()}, len(tr._early)))
         torch.cuda.synchronize()
-        out[world] = dict(steps=steps, params={k: p.detach().cpu().numpy() for k, p in tr.renderer.named_parameters()}, early_calls=calls[0])
+        out[key] = dict(steps=steps, params={k: p.detach().cpu().numpy() for k, p in tr.renderer.named_parameters()}, early_calls=calls[0])
     q.put(out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -311,17 +311,23 @@ def test_exchange_path_over_rccl_with_one_rank(method):
     out = q.get(timeout=500)
     p.join(timeout=60)
     assert p.exitcode == 0
-    one, two = out[1], out[2]
+    one, two, ctl = out[1], out[2], out["control"]
     for step in range(N_STEPS):
         assert one["steps"][step][0] == two["steps"][step][0]                     # same batches
         assert two["steps"][step][2] == 0                                         # every early all-reduce was awaited
         for k, ref in one["steps"][step][1].items():
             got = two["steps"][step][1][k]
-            # same kernels on the same batch; the MSE scale is a device scalar instead of a host float, plane / grid sums are atomics
+            # Same kernels on the same batch; the MSE scale is a device scalar instead of a host float, plane / grid sums are atomics in
+            # whatever order the waves arrive.  Tolerance by construction: the plain step run TWICE (`control`) says how far two
+            # evaluations of one path are apart for THIS tensor at THIS step -- a grid whose gradient is a near-cancelling sum (norm 2e-5)
+            # moves by percents of its own norm, and from step 1 on Adam (eps 1e-15) feeds that back -- and the exchange path may be
+            # 4 x that far from the plain one; where the control agrees better, 2e-5 of the tensor's norm is asked.
             nrm = float(np.linalg.norm(ref.astype(np.float64)))
-            assert float(np.linalg.norm((got - ref).astype(np.float64))) <= (2e-5 if step == 0 else 5e-3) * max(nrm, 1e-30), (k, step)
+            noise = float(np.linalg.norm((ctl["steps"][step][1][k] - ref).astype(np.float64)))
+            assert float(np.linalg.norm((got - ref).astype(np.float64))) <= max(2e-5 * nrm, 4.0 * noise) + 1e-30, (k, step, nrm, noise)
     for k, ref in one["params"].items():
-        np.testing.assert_allclose(two["params"][k], ref, rtol=0, atol=2e-2 * max(float(np.abs(ref).max()), 1e-12), err_msg=k)
+        noise = float(np.abs(ctl["params"][k] - ref).max())
+        np.testing.assert_allclose(two["params"][k], ref, rtol=0, atol=max(2e-5 * float(np.abs(ref).max()), 4.0 * noise) + 1e-12, err_msg=k)
     if method == "kplanes":
         assert two["early_calls"] == N_STEPS
 

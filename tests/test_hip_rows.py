@@ -105,7 +105,10 @@ def test_rows_view_reports_only_layer_kernel_stacks():
     assert y.value == 9 * slab and g.value == 10 * slab and st.value == 256 * 32
     fn = L.lib().tn_mlp_bwd_workspace_bytes
     fn.restype = C.c_int64
-    assert fn(C.byref(desc), C.c_int64(1000)) == 12 * slab * 4 + 256     # (+ the tail: per-layer maxima for the f16x2 weight gradient)
+    # (+ the tail: per-layer maxima for the f16x2 weight gradient; + round 6: the packed weight stream of the cross-layer forward,
+    #  csrc/mlp_fused_f2.hip -- 2.4 MB for this stack whatever n is)
+    extra = fn(C.byref(desc), C.c_int64(1000)) - (12 * slab * 4 + 256)
+    assert 2 << 20 < extra < 3 << 20 and fn(C.byref(desc), C.c_int64(2016)) - (63 * 12 * 256 * 32 * 4 + 256) == extra
     od = m.VanillaOpacityDecoder(256).to(DEV)                         # a width-64 head has no row views
     d2 = m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
     assert L.lib().tn_mlp_rows_view(C.byref(d2), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) != 0
@@ -131,7 +134,8 @@ def test_inference_through_the_layer_kernels(n):
     np.testing.assert_allclose(y_inf.cpu().numpy(), y_reg.cpu().numpy(), rtol=0, atol=2e-6 * float(y_reg.abs().max()))
     fn = L.lib().tn_mlp_fwd_workspace_bytes
     fn.restype = C.c_int64
-    assert fn(C.byref(desc), C.c_int64(n)) == ((n + 31) // 32) * (2 * 256 + 64) * 128
+    rows_bytes = ((n + 31) // 32) * (2 * 256 + 64) * 128          # the layer-wise form's ping-pong rows; behind them the packed weight stream
+    assert 2 << 20 < fn(C.byref(desc), C.c_int64(n)) - rows_bytes < 3 << 20      # of the cross-layer form (round 6), 2.4 MB whatever n is
     od = m.VanillaOpacityDecoder(256).to(DEV)
     assert fn(C.byref(m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)), C.c_int64(n)) == 0
 
@@ -248,7 +252,7 @@ def test_plain_input_stack_through_the_layer_kernels(n, matmul):
     desc = m._mlp_desc(net.params(), 36, L.ENC_NONE, 0, L.ACT_NONE, None)
     fn = L.lib().tn_mlp_fwd_workspace_bytes
     fn.restype = C.c_int64
-    assert fn(C.byref(desc), C.c_int64(n)) == ((n + 31) // 32) * (2 * 128 + 64) * 128
+    assert 0 < fn(C.byref(desc), C.c_int64(n)) - ((n + 31) // 32) * (2 * 128 + 64) * 128 < 1 << 20      # (+ the packed weight stream, 0.4 MB)
     y_reg = torch.empty(n, 128, device=DEV)
     d0 = m._mlp_desc(net.params(), 36, L.ENC_NONE, 0, L.ACT_NONE, None)
     d0.flags = 0                                                   # (fp32 MFMA, register-resident: independent of the layer kernels)

@@ -38,6 +38,9 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rows, const f32x1
 // by the f16x2 forward of layer l; [16, 32): gradients, by its data gradient) -- the scales of the f16x2 weight gradient
 constexpr int64_t WS_TAIL_BYTES = 256;
 __host__ inline float *ws_tail(float *stash, int64_t total_rows) { return stash + total_rows * 32; }
+// behind the tail: the packed weight stream of the cross-layer forward (mlp_fused_f2.hip), 256-byte aligned
+__host__ inline int64_t fused_pack_offset(int64_t total_rows) { return (total_rows * 128 + WS_TAIL_BYTES + 255) & ~(int64_t)255; }
+__host__ inline void *fused_pack_area(float *stash, int64_t total_rows) { return reinterpret_cast<unsigned char *>(stash) + fused_pack_offset(total_rows); }
 
 __host__ __device__ inline bool plain_x_rows(int H, int n_layers, int enc, int K0_pad, int out_dim) {
     return enc == TN_ENC_NONE && K0_pad <= 64 && H >= 128 && n_layers >= 3 && out_dim > 4 && out_dim <= H;     // (= layer_kernel_path)
@@ -1157,6 +1160,19 @@ int run_fwd_only(const MlpArgs &a, const float *x, const float *aux, int64_t n, 
                 void *pack = reinterpret_cast<unsigned char *>(stash) + infer_ws_rows_bytes(H, lay, n_tiles);
                 return launch_fused_fwd_f2(H, a, n, stash, y, pack, s);
             }
+            if (!inference && !a.layerwise && rm.slab && a.f2 && tail && lay.rowsE == 64 && fused_fwd_ok(H, a) &&
+                ((a.enc == TN_ENC_POSENC && a.K0_pad == 64) || plain) && (!a.skip_last || out == H)) {
+                // round 6: the training forward as ONE persistent launch (mlp_fused_f2.hip): activations stay in registers across the layers and
+                // reach the workspace as the rows, bit rows and maxima the layer-wise backward reads -- written once, never read back here
+                enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE, 64);
+                if (int rc = tn::check_launch("enc_rows_kernel")) return rc;
+                FusedStash sp;
+                sp.rows = stash; sp.rows_total = total; sp.off_e = offE; sp.n_run = L - (a.skip_last ? 1 : 0); sp.tail = tail;
+                for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) { sp.off_out[l] = 0; sp.off_bits[l] = 0; }
+                for (int l = 0; l < sp.n_run; ++l) { sp.off_out[l] = off_out(l); sp.off_bits[l] = std::max<int64_t>(off_bits(l), 0); }
+                float *y_f = (a.skip_last || (a.rows_only && out == H && a.out_act == TN_ACT_NONE)) ? nullptr : y;
+                return launch_fused_fwd_f2(H, a, n, stash, y_f, fused_pack_area(stash, ws_rows(H, L, a.enc, a.in_dim, a.K0_pad, out, n_tiles)), s, &sp);
+            }
             if ((a.enc == TN_ENC_POSENC && a.K0_pad <= 64) || plain) {      // (encoded) inputs as rows, then the first layer like any other
                 enc_rows_kernel<<<dim3((unsigned)std::min<int64_t>((n_tiles + 3) / 4, 256 * 8)), dim3(256), 0, s>>>(a, x, n, stash, total, offE,
                                                                                                                   plain ? 64 : a.K0_pad);
@@ -1356,7 +1372,9 @@ extern "C" __attribute__((visibility("hidden"))) int64_t tn_mlp_bwd_layers_works
     if (H != 32 && H != 64 && H != 128 && H != 256) return 0;
     for (int l = 1; l < L; ++l) if (desc->dims[l] != H) return 0;
     if (((desc->dims[L] + 31) / 32) * (H / 32) > 64) return 0;          // weight-gradient tiling of the output layer (run_layers)
-    return ws_rows(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L], (n + 31) / 32) * 32 * (int64_t)sizeof(float) + WS_TAIL_BYTES;
+    const int64_t rows = ws_rows(H, L, desc->encoding, desc->in_dim, (desc->dims[0] + 7) & ~7, desc->dims[L], (n + 31) / 32);
+    if (H == 128 || H == 256) return fused_pack_offset(rows) + tn::layers::fused_pack_bytes(H, L);       // (+ the packed weights of the cross-layer forward)
+    return rows * 32 * (int64_t)sizeof(float) + WS_TAIL_BYTES;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int tn_mlp_bwd_layers(const tn_mlp_desc *desc, const float *x, const float *aux,

@@ -80,8 +80,17 @@ struct FusedArgs {
     int L;                           // layers in the stream: 0 .. L - 2 hidden (ReLU), L - 1 the output layer (no activation)
     int n_chunks;                    // chunks per pass over the stream
     int out_act;
-    const float *e_rows;             // first-layer inputs as [slot][32 samples] rows, 64 rows per 32-sample tile (enc_rows_kernel)
-    float *y;                        // [n][H] row-major
+    const float *e_rows;             // first-layer inputs as [slot][32 samples] rows (enc_rows_kernel): tile t at rows t e_rows_total + e_off
+    int e_rows_total;
+    int64_t e_off;
+    float *y;                        // [n][H] row-major (nullptr: not wanted -- TN_MLP_ROWS_ONLY)
+    // training forward (STASH): what the layer-wise backward reads (mlp_bwd_layers.hip RowMap, slab layout)
+    float *rows;                     // workspace: tile t, row set at row offset `off` = rows [t rows_total + off, ...)
+    int rows_total;
+    int out_linear;                  // 1: layer L - 1 is the stack's output layer (no activation); 0: every layer of the stream is hidden (TN_MLP_SKIP_LAST)
+    int64_t off_out[TN_MLP_MAX_LAYERS];      // row offset of layer l's output (activation H_l; the output layer: buffer A)
+    int64_t off_bits[TN_MLP_MAX_LAYERS];     // ... of its ReLU bit rows (2 per 32-feature block), hidden layers only
+    float *tail;                     // tail[l] receives the largest |value| of layer l's INPUT rows, l >= 1 (scale of that layer's weight gradient)
 };
 
 struct PackArgs {
@@ -222,6 +231,7 @@ struct Pending {
     f32x16 c[2];
     f32x4 bias[2][4];                // D-layout bias of both blocks
     float cmul, s_out;
+    float *rows; unsigned *bits;     // STASH: where that layer's activation rows / bit rows of this tile go (wave-uniform)
 };
 
 template <int H> struct State {
@@ -264,7 +274,7 @@ __device__ __forceinline__ void pair_phase(PairTmp &t, float c0, float c1, float
 
 // One layer.  MODE 0: hidden (ReLU, operands of the next layer into `out`), MODE 1: the output layer (rows of y).  HAS_PREV: the last
 // two blocks of the previous layer are still pending (st.pend) and are finished behind the first k steps of this one, into `in`.
-template <int H, int KSL, int MODE, bool HAS_PREV>
+template <int H, int KSL, int MODE, bool HAS_PREV, bool STASH>
 struct Layer {
     static constexpr int NB = H / 32, NG = NB / 2, KS = H / 16;
     static constexpr int T = NG * KSL;                         // k steps of the layer (two blocks each)
@@ -279,6 +289,12 @@ struct Layer {
     float inv_in;                  // 1 / scale of `in`
     float cmul, s_out, inv_out;    // this layer's epilogue factor and output scale (s_out: known once the previous layer is finished)
     float *yrow; bool store; int h;
+    bool own_tile;                 // false: a wave without a tile of its own (it recomputes the last tile; what it would write differs for the masked samples)
+    float *rows; unsigned *bits;   // STASH: this layer's output rows / bit rows of the wave's tile (wave-uniform); lane offset below
+    unsigned lane_off;             // (4 h 32 + j) 4: byte offset of D register 0 of a block inside its 32 rows
+    int lane;
+    unsigned bitacc[2];            // ReLU bits of the two blocks being finished
+    unsigned max_addr;             // STASH: LDS address of this lane's running maximum of the layer's input (0: not wanted)
     f32x16 acc[2][2];              // [group parity][block]: the group in flight and the finished one whose epilogue runs behind it
     f32x4 bias_cur[2][4];          // of the finished group (requested at its last step)
 
@@ -286,38 +302,67 @@ struct Layer {
         const float xm = other_half_max(st.xmax) * inv_in;     // max |x| over the sample's input column
         bound_scales(fmaf(wn, xm, bmax) * 1.002f, s_out, inv_out);
         st.xmax = 0.0f;
+        if constexpr (STASH) {                                 // largest input value of this layer so far, per lane (reduced at the end of the kernel)
+            if (max_addr != 0) asm volatile("ds_max_f32 %0, %1" :: "v"(max_addr), "v"(xm) : "memory");
+        }
     }
     // pending pair Q (0 .. 15: block Q >> 3, registers 2 (Q & 7), + 1) of hidden group `grp` (blocks 2 grp, 2 grp + 1) -> dst; phase PH
     PairTmp tmp[2];
     template <int Q, int PH>
-    __device__ __forceinline__ void hidden_phase(const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp) {
+    __device__ __forceinline__ void hidden_phase(const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp,
+                                                 float *rows_, unsigned *bits_) {
         constexpr int blk = Q >> 3, r0 = 2 * (Q & 7);
         Op2 &d = dst[2 * (2 * grp + blk) + (r0 >> 3)];
         unsigned hi_ = 0, lo_ = 0;
         pair_phase<PH>(tmp[Q & 1], cc[blk][r0], cc[blk][r0 + 1], bb[blk][r0 >> 2][r0 & 3], bb[blk][r0 >> 2][(r0 & 3) + 1], cm, so, hi_, lo_, st.xmax);
         if constexpr (PH == 2) d.hi[(r0 >> 1) & 3] = hi_;
         if constexpr (PH == 4) d.lo[(r0 >> 1) & 3] = lo_;
+        if constexpr (STASH) {
+            // the activation (after the ReLU, before the scale) as two [feature][32-sample] rows; SGPR base + lane offset + immediate
+            if constexpr (PH == 2) {
+                char *p = reinterpret_cast<char *>(rows_ + 32 * (2 * grp + blk) * 32);
+                unsigned off = lane_off;
+                asm volatile("" : "+v"(off));
+                constexpr int rr0 = ((r0 & 3) + 8 * (r0 >> 2)) * 128;
+                __builtin_nontemporal_store(tmp[Q & 1].v0, reinterpret_cast<float *>(p + off + rr0));
+                __builtin_nontemporal_store(tmp[Q & 1].v1, reinterpret_cast<float *>(p + off + rr0 + 128));
+            }
+            if constexpr (PH == 3) {
+                unsigned b0 = min(__float_as_uint(tmp[Q & 1].v0), 1u), b1 = min(__float_as_uint(tmp[Q & 1].v1), 1u);
+                if constexpr ((Q & 7) == 0) bitacc[blk] = b0 | (b1 << 1);
+                else bitacc[blk] |= (b0 << r0) | (b1 << (r0 + 1));
+            }
+            if constexpr (PH == 4 && (Q & 7) == 7) bits_[(2 * (2 * grp + blk)) * 32 + lane] = bitacc[blk];
+        }
+    }
+    template <int Q> __device__ __forceinline__ void flush_pending() {     // a pending pair with nothing to hide behind (end of a TN_MLP_SKIP_LAST stack)
+        hidden_phase<Q, 0>(st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
+        hidden_phase<Q, 1>(st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
+        hidden_phase<Q, 2>(st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
+        hidden_phase<Q, 3>(st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
+        hidden_phase<Q, 4>(st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
     }
     // NPAIR pairs Q0 .. Q0 + NPAIR - 1 dealt over the six gaps of a step
     template <int Q0, int NPAIR>
-    __device__ __forceinline__ void hidden_gap(int gap, const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp) {
+    __device__ __forceinline__ void hidden_gap(int gap, const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp,
+                                               float *rows_, unsigned *bits_) {
         if constexpr (NPAIR == 1) {
-            if (gap == 0) hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp);
-            if (gap == 1) hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp);
-            if (gap == 2) hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp);
-            if (gap == 3) hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp);
-            if (gap == 4) hidden_phase<Q0, 4>(cc, bb, cm, so, dst, grp);
+            if (gap == 0) hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 1) hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 2) hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 3) hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 4) hidden_phase<Q0, 4>(cc, bb, cm, so, dst, grp, rows_, bits_);
         } else if constexpr (NPAIR == 2) {
-            if (gap == 0) { hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp); hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp); }
-            if (gap == 1) { hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp); hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp); }
-            if (gap == 2) { hidden_phase<Q0, 4>(cc, bb, cm, so, dst, grp); hidden_phase<Q0 + 1, 0>(cc, bb, cm, so, dst, grp); }
-            if (gap == 3) { hidden_phase<Q0 + 1, 1>(cc, bb, cm, so, dst, grp); hidden_phase<Q0 + 1, 2>(cc, bb, cm, so, dst, grp); }
-            if (gap == 4) { hidden_phase<Q0 + 1, 3>(cc, bb, cm, so, dst, grp); hidden_phase<Q0 + 1, 4>(cc, bb, cm, so, dst, grp); }
+            if (gap == 0) { hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp, rows_, bits_); }
+            if (gap == 1) { hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp, rows_, bits_); }
+            if (gap == 2) { hidden_phase<Q0, 4>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0 + 1, 0>(cc, bb, cm, so, dst, grp, rows_, bits_); }
+            if (gap == 3) { hidden_phase<Q0 + 1, 1>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0 + 1, 2>(cc, bb, cm, so, dst, grp, rows_, bits_); }
+            if (gap == 4) { hidden_phase<Q0 + 1, 3>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0 + 1, 4>(cc, bb, cm, so, dst, grp, rows_, bits_); }
         } else {
-            hidden_gap<Q0, 2>(gap < 3 ? 2 * gap : 9, cc, bb, cm, so, dst, grp);              // pairs 0, 1 in gaps 0 .. 2 (two of the five gap slots each)
-            hidden_gap<Q0, 2>(gap < 3 ? 2 * gap + 1 : 9, cc, bb, cm, so, dst, grp);
-            hidden_gap<Q0 + 2, 2>(gap >= 3 ? 2 * (gap - 3) : 9, cc, bb, cm, so, dst, grp);   // pairs 2, 3 in gaps 3 .. 5
-            hidden_gap<Q0 + 2, 2>(gap >= 3 ? 2 * (gap - 3) + 1 : 9, cc, bb, cm, so, dst, grp);
+            hidden_gap<Q0, 2>(gap < 3 ? 2 * gap : 9, cc, bb, cm, so, dst, grp, rows_, bits_);              // pairs 0, 1 in gaps 0 .. 2 (two of the five gap slots each)
+            hidden_gap<Q0, 2>(gap < 3 ? 2 * gap + 1 : 9, cc, bb, cm, so, dst, grp, rows_, bits_);
+            hidden_gap<Q0 + 2, 2>(gap >= 3 ? 2 * (gap - 3) : 9, cc, bb, cm, so, dst, grp, rows_, bits_);   // pairs 2, 3 in gaps 3 .. 5
+            hidden_gap<Q0 + 2, 2>(gap >= 3 ? 2 * (gap - 3) + 1 : 9, cc, bb, cm, so, dst, grp, rows_, bits_);
         }
     }
     template <int Q4>                                           // output layer: four values (registers 4 (Q4 & 3) ..) of block Q4 >> 2 of group grp
@@ -327,7 +372,14 @@ struct Layer {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = fmaf(cc[blk][4 * q + u], cmul, bb[blk][q][u]);
         if (TN_FUSED_ABL & 4) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }
-        if (store) *reinterpret_cast<f32x4 *>(yrow + 32 * (2 * grp + blk) + 8 * q + 4 * h) = v;
+        if (store && yrow != nullptr) *reinterpret_cast<f32x4 *>(yrow + 32 * (2 * grp + blk) + 8 * q + 4 * h) = v;
+        if constexpr (STASH) {               // y as rows (tn_mlp_rows_view): samples past n hold 0 as in the layer-wise form
+            char *p = reinterpret_cast<char *>(rows + 32 * (2 * grp + blk) * 32);
+            unsigned off = lane_off;
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (own_tile) *reinterpret_cast<float *>(p + off + (u + 8 * q) * 128) = store ? v[u] : 0.0f;
+        }
     }
     template <int BLK> __device__ __forceinline__ void request_bias(f32x4 (&bb)[2][4], int grp) {
         // (grp is a compile-time constant at every call site; the offset is folded into the address register once per group)
@@ -371,7 +423,7 @@ struct Layer {
         // ---- six MFMAs, the two blocks' accumulators in turn; the pending pairs of this step behind them ----
         auto fill = [&](int gap) {
             if constexpr (GI > 0) {
-                if constexpr (MODE == 0) hidden_gap<S * PPS, PPS>(gap, acc[(GI - 1) & 1], bias_cur, cmul, s_out, out, GI - 1);     // pairs S PPS .. of group GI - 1
+                if constexpr (MODE == 0) hidden_gap<S * PPS, PPS>(gap, acc[(GI - 1) & 1], bias_cur, cmul, s_out, out, GI - 1, rows, bits);     // pairs S PPS .. of group GI - 1
                 else {
                     // eight quads over the group's KSL steps
                     if constexpr (KSL >= 16) { if ((S & 1) == 0 && gap == 1) out_quad<S / 2>(acc[(GI - 1) & 1], bias_cur, GI - 1); }
@@ -380,7 +432,7 @@ struct Layer {
                 }
             } else if constexpr (HAS_PREV) {
                 // the previous layer's last group, PPS_PREV pairs per step, into THIS layer's input (k steps KS - 4 .. KS - 1: not read before step KSL - 4 >= KSL / 2)
-                if constexpr (S < KSL / 2) hidden_gap<S * PPS_PREV, PPS_PREV>(gap, st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1);
+                if constexpr (S < KSL / 2) hidden_gap<S * PPS_PREV, PPS_PREV>(gap, st.pend.c, st.pend.bias, st.pend.cmul, st.pend.s_out, in, NG - 1, st.pend.rows, st.pend.bits);
                 else if constexpr (S == KSL / 2) { if (gap == 0) scales_from_norm(); }      // the previous layer is complete: this layer's output scale
             }
         };
@@ -402,6 +454,7 @@ struct Layer {
                 st.pend.c[0] = c[0]; st.pend.c[1] = c[1];
                 request_bias<0>(st.pend.bias, GI); request_bias<1>(st.pend.bias, GI);
                 st.pend.cmul = cmul; st.pend.s_out = s_out;
+                st.pend.rows = rows; st.pend.bits = bits;
             }
         }
     }
@@ -415,27 +468,42 @@ struct Layer {
     }
 };
 
-template <int H, int KSL, int MODE, bool HAS_PREV>
-__device__ __forceinline__ float run_layer(Ring &ring, State<H> &st, Op2 (&in)[H / 16], Op2 (&out)[H / 16], unsigned bias_addr, const float *cs, float inv_in,
-                                           float *yrow, bool store, int h)
+// per-layer context of a wave's tile
+struct Tile {
+    float *yrow; bool store, own_tile; int h, lane;
+    unsigned lane_off;
+    float *rows_base;              // STASH: workspace + tile * rows_total * 32 floats (wave-uniform)
+    unsigned max0;                 // STASH: LDS address of this lane's slot in the maxima table of layer 0 (layer l: + l * 1024)
+};
+
+template <int H, int KSL, int MODE, bool HAS_PREV, bool STASH>
+__device__ __forceinline__ float run_layer(Ring &ring, State<H> &st, Op2 (&in)[H / 16], Op2 (&out)[H / 16], const FusedArgs &a, int l, unsigned bias0,
+                                           float inv_in, const Tile &tl)
 {
-    Layer<H, KSL, MODE, HAS_PREV> L{ring, st, in, out, bias_addr, cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, yrow, store, h};
+    const float *cs = a.consts + 4 * l;
+    Layer<H, KSL, MODE, HAS_PREV, STASH> L{ring, st, in, out, bias0 + (unsigned)(l * H * 4), cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, tl.h};
+    if constexpr (STASH) {
+        L.rows = urow(tl.rows_base, a.off_out[l]);
+        L.bits = reinterpret_cast<unsigned *>(urow(tl.rows_base, MODE == 0 ? a.off_bits[l] : 0));
+        L.lane_off = tl.lane_off; L.lane = tl.lane;
+        L.max_addr = (l >= 1 && a.tail != nullptr) ? tl.max0 + (unsigned)l * 1024u : 0u;
+    }
+    L.own_tile = tl.own_tile;
     L.run();
     return L.inv_out;
 }
 
-template <int H>
+template <int H, bool STASH>
 __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
 {
     constexpr int KS = H / 16, NB = H / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *bias_s = reinterpret_cast<float *>(lds_raw + NRING * CHUNK_B);
-    // (the layers' constants are read through scalar loads from global memory: an LDS access the compiler can see would make it drain
-    //  the LDS-direct requests in flight -- it cannot tell them apart from writes to the address it reads)
-    const float *consts_s = a.consts;
+    float *max_s = bias_s + a.L * H;                           // STASH: [L][256] running maxima of the layers' inputs
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int e = threadIdx.x; e < a.L * H; e += blockDim.x) bias_s[e] = a.bias[e];
+    if constexpr (STASH) for (int e = threadIdx.x; e < a.L * 256; e += blockDim.x) max_s[e] = 0.0f;
     lds_u8 *lds3 = (lds_u8 *)lds_raw;
     const unsigned lds0 = (unsigned)(uintptr_t)lds3;
     Ring ring;
@@ -469,6 +537,11 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
         st.aw[1][0].hi = lds16<2 * PAIR_B>(base); st.aw[1][0].lo = lds16<2 * PAIR_B + 1024>(base);
         st.aw[1][1].hi = lds16<3 * PAIR_B>(base); st.aw[1][1].lo = lds16<3 * PAIR_B + 1024>(base);
     }
+    Tile tl;
+    tl.h = h; tl.lane = lane;
+    tl.lane_off = (unsigned)(4 * h * 32 + j) * 4u;
+    tl.max0 = lds0 + NRING * CHUNK_B + (unsigned)(a.L * H) * 4u + (unsigned)threadIdx.x * 4u;
+    const int n_hidden = a.L - 1 - (a.out_linear ? 1 : 0);     // hidden layers behind layer 0
 #pragma clang loop unroll(disable)
     for (int64_t round = 0; round < rounds; ++round) {
         const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * 4 + wave;
@@ -476,7 +549,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
         const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
         float inv_in;
         {   // first-layer inputs: 64 rows of the tile in the D layout (mlp_f2_layers.hip fwd_first_f2_kernel), exact column maximum
-            const float *in = urow(a.e_rows, tile * 64);
+            const float *in = urow(a.e_rows, tile * a.e_rows_total + a.e_off);
             float x[2][16];
             float mx = 0.0f;
 #pragma unroll
@@ -495,25 +568,34 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
                 f2_split8(v, 1.0f, st.Q[b].hi, st.Q[b].lo);
             }
         }
-        float *yrow = a.y + (tile * 32 + j) * H;
-        const bool store = tile_ok && tile * 32 + j < n;
-        // layer 0: Q (4 operand steps) -> P; hidden layers in pairs P -> Q -> P (fused_fwd_ok: an even number of them); output layer from P
-        inv_in = run_layer<H, KS0, 0, false>(ring, st, st.Q, st.P, bias0, consts_s, inv_in, yrow, store, h);
+        tl.yrow = a.y != nullptr ? a.y + (tile * 32 + j) * H : nullptr;
+        tl.store = tile_ok && tile * 32 + j < n;
+        tl.own_tile = tile_ok;
+        // (a wave without a tile of its own recomputes the last tile and writes the same values to the same places)
+        if constexpr (STASH) tl.rows_base = urow(a.rows, tile * a.rows_total);
+        // layer 0: Q (4 operand steps) -> P; hidden layers in pairs P -> Q -> P; output layer (or the flush of the last hidden layer) from P
+        inv_in = run_layer<H, KS0, 0, false, STASH>(ring, st, st.Q, st.P, a, 0, bias0, inv_in, tl);
         int l = 1;
 #pragma clang loop unroll(disable)
-        for (; l + 2 < a.L; l += 2) {
-            inv_in = run_layer<H, KS, 0, true>(ring, st, st.P, st.Q, bias0 + l * H * 4, consts_s + 4 * l, inv_in, yrow, store, h);
-            inv_in = run_layer<H, KS, 0, true>(ring, st, st.Q, st.P, bias0 + (l + 1) * H * 4, consts_s + 4 * (l + 1), inv_in, yrow, store, h);
+        for (; l + 1 <= n_hidden; l += 2) {
+            inv_in = run_layer<H, KS, 0, true, STASH>(ring, st, st.P, st.Q, a, l, bias0, inv_in, tl);
+            inv_in = run_layer<H, KS, 0, true, STASH>(ring, st, st.Q, st.P, a, l + 1, bias0, inv_in, tl);
         }
-        if (l + 1 < a.L) {                   // an odd number of hidden layers (Cobafa: 5): the last one through a third copy of the loop body would
-            // cost 12 KB of code; instead it runs P -> Q like the others and the column moves back once per round (H / 2 register moves)
-            inv_in = run_layer<H, KS, 0, true>(ring, st, st.P, st.Q, bias0 + l * H * 4, consts_s + 4 * l, inv_in, yrow, store, h);
+        if (l <= n_hidden) {                 // an odd number of hidden layers (Cobafa: 5): a third copy of the loop body would cost 12 KB of code;
+            // instead the last one runs P -> Q like the others and the column moves back once per round (H / 2 register moves)
+            inv_in = run_layer<H, KS, 0, true, STASH>(ring, st, st.P, st.Q, a, l, bias0, inv_in, tl);
 #pragma unroll
             for (int b = 0; b < KS - 4; ++b) st.P[b] = st.Q[b];          // (the last four operand steps are still pending: st.pend writes them into P)
+            ++l;
         }
-        {
-            const int l = a.L - 1;
-            Layer<H, KS, 1, true> L{ring, st, st.P, st.Q, bias0 + l * H * 4, consts_s[4 * l], consts_s[4 * l + 1], consts_s[4 * l + 2], inv_in, 0.0f, 0.0f, 0.0f, yrow, store, h};
+        if (a.out_linear) {
+            const float *cs = a.consts + 4 * l;
+            Layer<H, KS, 1, true, STASH> L{ring, st, st.P, st.Q, bias0 + (unsigned)(l * H * 4), cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, h};
+            if constexpr (STASH) {
+                L.rows = urow(tl.rows_base, a.off_out[l]); L.bits = nullptr; L.lane_off = tl.lane_off; L.lane = lane;
+                L.max_addr = a.tail != nullptr ? tl.max0 + (unsigned)l * 1024u : 0u;
+            }
+            L.own_tile = tile_ok;
             L.run();
             // its last two blocks have nothing to hide behind
             wait_bias<0>(st.pend.bias);
@@ -521,17 +603,40 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
             L.template out_quad<2>(st.pend.c, st.pend.bias, NB / 2 - 1); L.template out_quad<3>(st.pend.c, st.pend.bias, NB / 2 - 1);
             L.template out_quad<4>(st.pend.c, st.pend.bias, NB / 2 - 1); L.template out_quad<5>(st.pend.c, st.pend.bias, NB / 2 - 1);
             L.template out_quad<6>(st.pend.c, st.pend.bias, NB / 2 - 1); L.template out_quad<7>(st.pend.c, st.pend.bias, NB / 2 - 1);
+        } else {
+            // TN_MLP_SKIP_LAST: the stack ends in a hidden activation -- its last two blocks are finished here (rows and bit rows; the
+            // operands they would become have no consumer)
+            if constexpr (STASH) {
+                Layer<H, KS, 0, true, STASH> L{ring, st, st.P, st.Q, bias0, 0.0f, 0.0f, 0.0f, inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, h};
+                L.lane_off = tl.lane_off; L.lane = lane; L.max_addr = 0; L.own_tile = tile_ok;
+                wait_bias<0>(st.pend.bias);
+                L.template flush_pending<0>(); L.template flush_pending<1>(); L.template flush_pending<2>(); L.template flush_pending<3>();
+                L.template flush_pending<4>(); L.template flush_pending<5>(); L.template flush_pending<6>(); L.template flush_pending<7>();
+                L.template flush_pending<8>(); L.template flush_pending<9>(); L.template flush_pending<10>(); L.template flush_pending<11>();
+                L.template flush_pending<12>(); L.template flush_pending<13>(); L.template flush_pending<14>(); L.template flush_pending<15>();
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the ring's last requests: nothing may land in LDS after the workgroup has gone)
+    if constexpr (STASH) {
+        if (a.tail != nullptr) {
+            __syncthreads();
+            for (int l = 1; l < a.L; ++l) {
+                float m = max_s[l * 256 + threadIdx.x];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + l), __float_as_uint(m));      // (non-negative floats order like their bits)
+            }
+        }
+    }
 }
 
-template <int H>
+template <int H, bool STASH>
 int launch(const FusedArgs &f, int64_t n, hipStream_t s)
 {
-    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * H * 4 + 64;
+    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * H * 4 + (STASH ? (size_t)f.L * 1024 : 0) + 64;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_fwd(fused): bias table does not fit LDS");
-    auto kern = fused_fwd_kernel<H>;
+    auto kern = fused_fwd_kernel<H, STASH>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_fwd(fused): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
@@ -561,11 +666,13 @@ __attribute__((visibility("hidden"))) bool fused_fwd_ok(int H, const MlpArgs &a)
     return true;
 }
 
-// e_rows: 64 rows x 32 samples per tile, contiguous over the tiles; pack_area: fused_pack_bytes(H, L), 256-byte aligned
+// Inference (spec == nullptr): e_rows = 64 rows x 32 samples per tile, contiguous over the tiles; y [n][H].  Training forward: spec says
+// where the workspace rows go.  pack_area: fused_pack_bytes(H, L), 256-byte aligned.  n_run: layers to evaluate (L, or L - 1 under
+// TN_MLP_SKIP_LAST: every evaluated layer is then a hidden one).
 __attribute__((visibility("hidden"))) int launch_fused_fwd_f2(int H, const MlpArgs &a, int64_t n, const float *e_rows, float *y, void *pack_area,
-                                                              hipStream_t s)
+                                                              hipStream_t s, const FusedStash *spec)
 {
-    const int L = a.n_layers;
+    const int L = spec ? spec->n_run : a.n_layers;
     PackArgs p;
     p.L = L; p.H = H;
     int64_t off = 0;
@@ -586,8 +693,14 @@ __attribute__((visibility("hidden"))) int launch_fused_fwd_f2(int H, const MlpAr
     if (int rc = tn::check_launch("fused_pack_kernel")) return rc;
     FusedArgs f;
     f.stream = p.stream; f.bias = p.bias; f.consts = p.consts; f.L = L; f.n_chunks = (int)chunks; f.out_act = a.out_act;
-    f.e_rows = e_rows; f.y = y;
-    return H == 256 ? launch<256>(f, n, s) : launch<128>(f, n, s);
+    f.e_rows = e_rows; f.e_rows_total = 64; f.e_off = 0; f.y = y;
+    f.rows = nullptr; f.rows_total = 0; f.out_linear = 1; f.tail = nullptr;
+    for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) { f.off_out[l] = 0; f.off_bits[l] = 0; }
+    if (spec == nullptr) return H == 256 ? launch<256, false>(f, n, s) : launch<128, false>(f, n, s);
+    f.e_rows_total = spec->rows_total; f.e_off = spec->off_e;
+    f.rows = spec->rows; f.rows_total = spec->rows_total; f.out_linear = spec->n_run == a.n_layers ? 1 : 0; f.tail = spec->tail;
+    for (int l = 0; l < L; ++l) { f.off_out[l] = spec->off_out[l]; f.off_bits[l] = spec->off_bits[l]; }
+    return H == 256 ? launch<256, true>(f, n, s) : launch<128, true>(f, n, s);
 }
 
 }  // namespace layers

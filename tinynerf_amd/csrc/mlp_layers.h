@@ -101,10 +101,18 @@ int launch_fwd_first_f2(int H, const FwdLayerArgs &f, int64_t n, float *stash, h
 int launch_dgrad_f2(int H, const DgradArgs &d, int64_t n, float *stash, hipStream_t s);
 int launch_wgrad_f2(int H, const WgradArgs &w, int64_t n, const float *stash, hipStream_t s);
 
-// ---- all layers of a wide stack in one persistent launch (mlp_fused_f2.hip, round 6): inference forward ----
+// ---- all layers of a wide stack in one persistent launch (mlp_fused_f2.hip, round 6): inference forward and training forward ----
+struct FusedStash {                 // training forward: where the rows the layer-wise backward reads go (RowMap, slab layout)
+    float *rows;                    // workspace base
+    int rows_total;
+    int64_t off_e;                  // the encoded input rows (written by enc_rows_kernel before the launch)
+    int n_run;                      // layers to evaluate: n_layers, or n_layers - 1 under TN_MLP_SKIP_LAST
+    int64_t off_out[TN_MLP_MAX_LAYERS], off_bits[TN_MLP_MAX_LAYERS];
+    float *tail;                    // tail[l]: largest |input value| of layer l (l >= 1), zeroed by the caller
+};
 int64_t fused_pack_bytes(int H, int L);
 bool fused_fwd_ok(int H, const tn::mlp::MlpArgs &a);
-int launch_fused_fwd_f2(int H, const tn::mlp::MlpArgs &a, int64_t n, const float *e_rows, float *y, void *pack_area, hipStream_t s);
+int launch_fused_fwd_f2(int H, const tn::mlp::MlpArgs &a, int64_t n, const float *e_rows, float *y, void *pack_area, hipStream_t s, const FusedStash *spec = nullptr);
 
 }  // namespace layers
 }  // namespace tn

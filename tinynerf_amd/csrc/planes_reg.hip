@@ -409,6 +409,10 @@ extern "C" int tn_adam_reg_multi(const tn_adam_reg_item *items, int32_t n_items,
                 TN_REQUIRE(t.param_out != t.param, TN_E_CONFIG, "tn_adam_reg_multi: a regularised plane needs a separate output buffer");
                 TN_REQUIRE(sums == nullptr || t.sum_slot >= 0, TN_E_SIZE, "tn_adam_reg_multi: bad sum slot");
             }
+            // sharded pass: row1 == 0 means every row; anything else must be a non-empty range inside the plane (a mis-sharded caller
+            // would otherwise train with frozen rows and no error)
+            TN_REQUIRE(t.row1 == 0 ? t.row0 == 0 : (t.H > 0 && t.row0 >= 0 && t.row0 < t.row1 && t.row1 <= t.H), TN_E_SIZE,
+                       "tn_adam_reg_multi: rows [row0, row1) must satisfy 0 <= row0 < row1 <= H (row1 == 0, row0 == 0: every row)");
             pack.it[i] = t;
             largest = std::max<int64_t>(largest, (t.n + 3) / 4);
         }

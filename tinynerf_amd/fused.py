@@ -603,7 +603,22 @@ def _mergeable(producer, sig_p, rgb_p) -> bool:
     if len(ps) < 6 or ps[-2].dim() != 2 or ps[-2].size(0) != ps[-2].size(1) or ps[-2].size(0) not in (128, 256):
         return False
     F = ps[-2].size(0)
-    return sig_p[0].size(1) == F and rgb_p[0].size(1) > F and all(p.requires_grad for p in (ps[-2], ps[-1], sig_p[0], sig_p[1], rgb_p[0], rgb_p[1]))
+    if not (sig_p[0].size(1) == F and rgb_p[0].size(1) > F and all(p.requires_grad for p in (ps[-2], ps[-1], sig_p[0], sig_p[1], rgb_p[0], rgb_p[1]))):
+        return False
+    # ... and the kernel side can actually stop this stack at its last hidden activation (slab-eligible f16x2 stack: positional encoding with
+    # <= 64 slots or <= 64 plain inputs, out == H): asked of the library itself (host-only, no launch) with the descriptor of the
+    # stack's previous forward -- shapes alone would arm TN_MLP_SKIP_LAST for stacks that then fail with TN_E_CONFIG mid-step
+    import ctypes as C
+    from . import _lib as L
+    from .models import _mlp_desc
+    sc = producer.__dict__.get("scratch")
+    cfg = sc[4].get("last_cfg") if sc is not None and len(sc) > 4 else None
+    if cfg is None:
+        return False
+    in_dim, encoding, n_freqs, out_act = cfg
+    desc = _mlp_desc([p.contiguous() for p in ps], in_dim, encoding, n_freqs, out_act, None, flags=L.MLP_SKIP_LAST | L.MLP_ROWS_ONLY)
+    a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    return L.lib().tn_mlp_rows_view_hidden(C.byref(desc), C.c_int64(32), C.byref(a), C.byref(b), C.byref(c), C.byref(d)) == 0
 
 
 def _vanilla_decoders(renderer) -> bool:

@@ -82,6 +82,7 @@ class _FusedMLP(Function):
     stash_forward = True   # training forward writes the activation workspace (tn_mlp_fwd_stash); False: backward recomputes
     layerwise_inference = False   # True: tn_mlp_fwd_ws one launch per layer (TN_MLP_LAYERWISE) instead of the cross-layer persistent launch --
                                   # the parity partner of tests/test_hip_fused.py and the A side of scripts/fused_fwd_time.py
+    layerwise_training = False    # ... the same for the training forward (tn_mlp_fwd_stash)
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
@@ -93,6 +94,8 @@ class _FusedMLP(Function):
         dev = L.require_cuda(x2, aux2, *ps)
         n = x2.size(0)
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs)
+        if scratch is not None and len(scratch) > 4:
+            scratch[4]["last_cfg"] = (x2.size(1), encoding, n_freqs, out_act)     # (fused._mergeable probes the library with it)
         y = _empty_rows(n, ps[-1].numel(), dev)
         # harness: fused.render_heads arms scratch[4]["rows_only"] for ONE forward when the render node it is about to run reads
         # this stack's output from the workspace rows (it has matched the row-view link before): the row-major y is then
@@ -114,6 +117,8 @@ class _FusedMLP(Function):
             # forward's backward before the next forward of the module, so one buffer per module is enough
             ws = scratch[0].get(scratch[1], (ws_bytes // 4,), dev) if scratch is not None else torch.empty(ws_bytes // 4, device=dev)
             link = scratch[2] if scratch is not None and len(scratch) > 2 else None
+            if _FusedMLP.layerwise_training:
+                desc.flags |= L.MLP_LAYERWISE
             if rows_only and link is not None:
                 desc.flags |= L.MLP_ROWS_ONLY
                 if skip_last:

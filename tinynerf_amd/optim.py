@@ -125,7 +125,23 @@ class FusedAdam(torch.optim.Optimizer):
                 return cnt[1:2]
         return None
 
+    partial_state_reason = None        # set by run.Trainer under TrainConfig.sharded_optimizer: state_dict() would be incomplete
+
+    def preallocate(self, params, shadow: bool = False):
+        """create the Adam moments (and, `shadow`, the double buffer of the regularised pass) of `params` now, on the current stream,
+        instead of at their first step -- which the harness may run on a side stream (run.Trainer, TN_ADAM_OVERLAP)"""
+        for p in params:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st.setdefault("step", 0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if shadow and "shadow" not in st:
+                st["shadow"] = torch.empty_like(p, memory_format=torch.preserve_format)
+
     def state_dict(self):
+        if self.partial_state_reason:
+            raise RuntimeError("tinynerf_amd.FusedAdam.state_dict(): " + self.partial_state_reason)
         self.sync_step_counts()
         return super().state_dict()
 

@@ -152,6 +152,11 @@ class Trainer:
         self._arena_grown = 0
         # torch.optim.Adam's update (run.py:186), one kernel pass per tensor, gradients zeroed in the same pass
         self.optimizer = FusedAdam(params, lr=1e-2, eps=1e-15, weight_decay=1e-5, zero_grad_in_step=True)
+        # the planes' moments and double buffer exist before the first step, allocated HERE on the main stream: the overlapped pass
+        # (TN_ADAM_OVERLAP) runs on a side stream, and blocks first allocated there would belong to that stream's pool although they
+        # become `plane.data` and are read on the main stream ever after
+        if isinstance(self.renderer.feature_module, KPlanesFeatureField):
+            self.optimizer.preallocate(self.renderer.feature_module.plane_tensors(), shadow=True)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=[self.steps // 2, self.steps * 3 // 4, self.steps * 5 // 6, self.steps * 9 // 10],
             gamma=0.33)
@@ -176,10 +181,11 @@ class Trainer:
         self._reduce_rows_prev: Optional[List[Tuple[int, int]]] = None
         if world_size > 1 and isinstance(self.renderer.feature_module, KPlanesFeatureField):
             self._plane_of = {id(p): i for i, p in enumerate(self.renderer.feature_module.plane_tensors())}
-        want = cfg.sharded_optimizer if cfg.sharded_optimizer is not None else cfg.shard >= 4
-        self._sharded = bool(want and world_size > 1 and self._plane_of and
+        self._sharded = bool(cfg.sharded_optimizer and world_size > 1 and self._plane_of and
                              all(p.size(2) % world_size == 0 for p in self.renderer.feature_module.plane_tensors()))
         self._gathers: List[object] = []
+        if self._sharded:
+            self.optimizer.partial_state_reason = Trainer._PARTIAL
         self._plan_host: Optional[torch.Tensor] = None
         self._info_turn = 0
         self._side: Optional[torch.cuda.Stream] = None
@@ -427,10 +433,17 @@ class Trainer:
         if ADAM_OVERLAP and self.world == 1 and cfg.method == "kplanes" and self.grad_hook is None:
             spec0, _ = self.renderer.feature_module.regulariser_spec(self.tv_reg_alpha, self.l1_reg_alpha)   # type: ignore
             self._early_adam = {"plane_reg": {"spec": spec0, "upstream": cfg.grad_scale, "sums": acc[1:]}, "gate": gate, "done": False}
+        early_done = False
         try:
             rendered.backward(grad)
+            early_done = bool(self._early_adam is not None and self._early_adam.get("done"))
         finally:
             stats["upstream_gated"] = False
+            if not early_done:
+                # backward raised (or the hook never ran): nothing may be left armed for a later backward.  Note that a step whose backward
+                # fails AFTER the hook ran has already moved the planes (TN_ADAM_OVERLAP): such a step is not retryable -- rebuild the Trainer
+                # from a checkpoint instead (TN_ADAM_OVERLAP=0 keeps the whole update behind the backward pass)
+                self._early_adam = None if self._early_adam is None or not self._early_adam.get("done") else self._early_adam
         reg_coef, plane_reg = None, None
         if cfg.method == "kplanes":                                               # run.py:254-256
             # the regulariser's gradient is the same on every rank (same planes): it is folded into the optimizer pass, after
@@ -573,10 +586,21 @@ class Trainer:
                     for w in works:
                         w.wait()
             return _All()
+        coalesced = getattr(torch.distributed, "all_reduce_coalesced", None)
+        if coalesced is None:                               # (a torch that has dropped the deprecated call: one async all-reduce per tensor)
+            works = [torch.distributed.all_reduce(v, async_op=True) for v in views]
+
+            class _Each:
+                def wait(self_inner):
+                    for w in works:
+                        w.wait()
+            return _Each()
         import warnings
-        with warnings.catch_warnings():                     # (the call is public; torch announces a future replacement on every use)
-            warnings.simplefilter("ignore")
-            return torch.distributed.all_reduce_coalesced(views, async_op=True)
+        with warnings.catch_warnings():                     # (the call is public; torch announces its future replacement on every use -- only that)
+            warnings.filterwarnings("ignore", message=".*all_reduce_coalesced.*", category=FutureWarning)
+            warnings.filterwarnings("ignore", message=".*all_reduce_coalesced.*", category=UserWarning)
+            warnings.filterwarnings("ignore", message=".*all_reduce_coalesced.*", category=DeprecationWarning)
+            return coalesced(views, async_op=True)
 
     # ---- sharded optimizer pass (TrainConfig.sharded_optimizer): rank r owns rows [r H / N, (r + 1) H / N) of every plane ----
     @staticmethod
@@ -602,6 +626,28 @@ class Trainer:
         if torch.distributed.get_backend() == "nccl" or not flat.is_cuda:
             return [torch.distributed.all_gather_into_tensor(flat, flat[rank * chunk:(rank + 1) * chunk], async_op=True)]
         return [torch.distributed.broadcast(flat[r * chunk:(r + 1) * chunk], src=r, async_op=True) for r in range(world)]
+
+    def optimizer_state_dict(self) -> dict:
+        """``optimizer.state_dict()`` that is complete on every rank: under ``sharded_optimizer`` each rank holds the planes' Adam moments for
+        its own rows only -- they are gathered here (in place, the same collective as the parameters' all-gather) before the dict is built"""
+        if getattr(self, "_sharded", False):
+            works = []
+            for p in self.renderer.feature_module.plane_tensors():
+                st = self.optimizer.state.get(p, {})
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key in st:
+                        works += Trainer._all_gather_rows(st[key], self.rank, self.world)
+            for w in works:
+                w.wait()
+        self.optimizer.partial_state_reason = None
+        try:
+            return self.optimizer.state_dict()
+        finally:
+            if getattr(self, "_sharded", False):
+                self.optimizer.partial_state_reason = Trainer._PARTIAL
+
+    _PARTIAL = ("sharded optimizer pass: the planes' Adam moments are valid on the owning rank's rows only -- use "
+                "Trainer.optimizer_state_dict(), which gathers them")
 
     def _planes_adam_early(self, grads) -> None:
         """N == 1 (TN_ADAM_OVERLAP, default on): the planes' gradients are final behind the chain + scatter launch -- their optimizer pass (HBM-bound, no

@@ -175,6 +175,8 @@ def psnr_replay(o, d, rgbs, dev, n_steps: int, grid0, ho, hd, hrgb):
            "golden": "tests/golden/G21_psnr_bench.json (oracle/make_psnr_curve.py --bench: CPU port of the reference's train() on this "
                      "configuration, replay streams); gate: |delta_db| < 0.1 (tests/test_hip_psnr.py)"}
     del t2
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     return out
 
@@ -761,6 +763,10 @@ def main():
                                                held_out=(ho, hd) if ho is not None else None)
             except Exception as e:                                      # noqa: BLE001 -- the headline line must still be printed
                 others[key] = {"error": repr(e)}
+            # a Trainer and its renderer reference each other (the batch hints hold bound methods): the side run's arenas -- 11 GB of Vanilla
+            # workspace -- are only released once the cycle collector has run (round 5 kept 78 GB reserved after the side runs)
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
 
     if rank == 0:

@@ -12,3 +12,6 @@ bash scripts/pmc.sh ${tag}_pmc --no-stages --steps 20 > gpurun_out/$tag/pmc.log 
 bash scripts/pmc_mfma.sh ${tag}_mfma --no-stages --steps 20 > gpurun_out/$tag/mfma.log 2>&1; tail -3 gpurun_out/$tag/mfma.log
 bash scripts/profile_config.sh vanilla 8 > gpurun_out/$tag/cfg_vanilla.log 2>&1; tail -3 gpurun_out/$tag/cfg_vanilla.log | cut -c1-160
 bash scripts/profile_config.sh cobafa 8 > gpurun_out/$tag/cfg_cobafa.log 2>&1; tail -3 gpurun_out/$tag/cfg_cobafa.log | cut -c1-160
+bash scripts/pmc_config.sh vanilla 6 > gpurun_out/$tag/pmc_vanilla.log 2>&1; tail -14 gpurun_out/$tag/pmc_vanilla.log | cut -c1-160
+bash scripts/pmc_config.sh cobafa 6 > gpurun_out/$tag/pmc_cobafa.log 2>&1; tail -14 gpurun_out/$tag/pmc_cobafa.log | cut -c1-160
+python bench.py --full-recipe > gpurun_out/$tag/full_recipe.json 2> gpurun_out/$tag/full_recipe.err; tail -c 600 gpurun_out/$tag/full_recipe.json; echo

@@ -24,6 +24,8 @@ for m in vanilla cobafa; do
   cp gpurun_out/cfg_$m/kernel_stats.csv profiles/${pre}_${m}_kernel_stats.csv
   wrap gpurun_out/cfg_$m/mfma_busy.json profiles/${pre}_${m}_mfma_busy.json "scripts/profile_config.sh $m (scripts/step_config.py $m 4) at $head"
 done
+for m in vanilla cobafa; do cp gpurun_out/pmc_$m/traffic.json profiles/${pre}_${m}_pmc_traffic.json; done
+cp gpurun_out/$tag/full_recipe.json profiles/${pre}_full_recipe.json
 python3 - <<PY
 import json
 d=json.loads(open('profiles/${pre}_bench.json').read().strip().splitlines()[-1])

@@ -192,7 +192,32 @@ def test_occupancy_update_vs_golden():
     og = c.OccupancyGrid(list(g["grid_after_1"].shape), float(g["step_size"]), float(g["base_threshold"]), float(g["decay"])).to(DEV)
     og.update(lambda x: od(fm(x)), jitters=cu(g["jitters"]))
     got = og.grid.cpu().numpy()
-    assert (got != g["grid_after_1"]).mean() < 2e-3          # a flip needs alpha within ~1e-6 of thr
+    # Which cells MAY differ from the reference's grid is computed, not typed in: a cell is decided by alpha > threshold (core.py:137-143),
+    # alpha from a 3-layer MLP in fp32.  An fp64 evaluation of the same network at the golden's jittered voxel centres gives the exact
+    # alpha; the distance of torch's own fp32 CPU evaluation from it (x 4) is how close to the threshold a cell must be for two fp32
+    # evaluations to disagree.  Every other cell must match the golden exactly.
+    from oracle import tinynerf_oracle as orc, torch_port as tp
+    D, H_, W_ = g["grid_after_1"].shape
+    thr, step = min(float(g["base_threshold"]), 1.0), float(g["step_size"])
+    sd = {"feature_module." + k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("fm.")}
+    sd.update({"sigma_decoder." + k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("od.")})
+
+    def alpha(dtype):
+        p = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        out = []
+        with torch.no_grad():
+            for i in range(D):
+                c = torch.from_numpy(orc.occupancy_voxel_coords([D, H_, W_], i, g["jitters"][i])).to(dtype)
+                f = tp.mlp(p, "feature_module.net.net.", tp.posenc(c, p["feature_module.encoding.freqs"].to(dtype)))
+                sgm = torch.exp(tp.mlp(p, "sigma_decoder.net.net.", f) - 1.0)
+                out.append((1.0 - torch.exp(-sgm * step)).reshape(H_, W_))
+        return torch.stack(out).double().numpy()
+    a64, a32 = alpha(torch.float64), alpha(torch.float32)
+    margin = 4.0 * float(np.abs(a32 - a64).max())
+    undecided = np.abs(a64 - thr) <= margin
+    flips = got != g["grid_after_1"]
+    assert not (flips & ~undecided).any(), (int((flips & ~undecided).sum()), margin)
+    assert undecided.mean() < 2e-3, (float(undecided.mean()), margin)          # (the fixture is not degenerate: few cells sit that close)
     assert og.mean == pytest.approx(float(g["mean_after_1"]), abs=2e-3)
     assert og.occupancy() == pytest.approx(float(g["occupancy_after_1"]), abs=2e-3)
     og.update(lambda x: od(fm(x)))                            # device-RNG path runs: cells are 1, decay or decay^2

@@ -43,8 +43,7 @@ SOURCES = {
     "linear.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_f2_layers.hip": FAST + ["-munsafe-fp-atomics"],
     "mlp_fused_f2.hip": FAST,
-    "mlp_b3_layers.hip": FAST + ["-munsafe-fp-atomics"] + (["-DTN_B3_ABLATE=" + os.environ["TN_B3_ABLATE"]] if os.environ.get("TN_B3_ABLATE") else [])
-                         + os.environ.get("TN_B3_EXTRA_FLAGS", "").split(),        # (timing experiments: extra hipcc flags for this file)
+    "mlp_b3_layers.hip": FAST + ["-munsafe-fp-atomics"],
 }
 
 
@@ -78,11 +77,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps.append(os.path.abspath(__file__))
     stamp = os.path.join(OBJ, "stamp")
     dig = _digest(deps, srcs)
-    # TN_B3_ABLATE builds compute WRONG results on purpose (timing experiments): such a library never gets a stamp, so the next
-    # ordinary build() replaces it instead of reusing it
-    ablation = bool(os.environ.get("TN_B3_ABLATE"))
-    if ablation and os.path.exists(stamp):
-        os.remove(stamp)
+    # (ablation builds -- TN_B3_ABLATE, TN_ABL_*, TN_FUSED_ABL: wrong results on purpose, for timing -- are made by scripts/build_dev_lib.sh
+    #  into a SECOND library; this build has no such switch)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
@@ -105,11 +101,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
-    if not ablation:
-        with open(stamp, "w") as f:
-            f.write(dig)
-    elif verbose:
-        sys.stderr.write("tinynerf_amd.build: TN_B3_ABLATE is set -- this library computes wrong results and carries no stamp\n")
+    with open(stamp, "w") as f:
+        f.write(dig)
     if verbose:
         print("built", LIB)
     return LIB

@@ -21,12 +21,13 @@ from torch.autograd import Function
 
 from . import _lib as L
 from .arena import Arena
+from .config import CONFIG
 from .models import _empty_rows, _hwc, _kplanes_desc, _mlp_desc
 
 
 # Heads behind a wide stack take their first-layer operands from the stack's workspace rows, and the stack stops writing the row-major
 # copy (TN_MLP_ROWS_ONLY / TN_MLP_X_FROM_ROWS; f16x2 heads only).  TN_ROWS_HANDOFF=0: row-major as before (A/B runs, tests).
-ROWS_HANDOFF = os.environ.get("TN_ROWS_HANDOFF", "1") != "0"
+ROWS_HANDOFF = CONFIG.rows_handoff
 
 
 def MATMUL_F16X2() -> bool:
@@ -40,20 +41,16 @@ FUSE_SCATTER = True       # backward: the plane scatter inside the data-gradient
 PAIR_BACKWARD = True      # both heads' data gradients in one launch (tn_mlp_bwd_pair); False: one tn_mlp_bwd per head
 # ... also behind the wide stacks (_RenderHeads; round 5): tn_mlp_bwd_pair takes both heads' first-layer weight gradients over the x
 # columns in ONE launch (x rows read once) and, where both first layers fit LDS (128-wide stack), both data gradients in one pass; "0": off
-HEADS_PAIR_BACKWARD = os.environ.get("TN_HEADS_PAIR", "1") != "0"
-# schedule of the K-Planes backward: "fused" = chain + scatter in one kernel, then the weight gradients; "split" = chain, then the
-# stand-alone scatter, then the weight gradients, all in line; "overlap" = chain, then the scatter (bound by the L2 atomic units) on a
-# second stream BESIDE the weight-gradient kernels (bound by HBM)
-BWD_SCHEDULE = os.environ.get("TN_BWD_SCHEDULE", "fused")
+HEADS_PAIR_BACKWARD = CONFIG.heads_pair
 # round 5 (TN_MLP_SKIP_LAST): behind a wide stack whose last layer is a plain Linear (Vanilla 256 -> 256, Cobafa 128 -> 128: reference
 # models.py:59-68,239-247) the heads' first layers are Linear too -- the harness merges the two (W_head W_last, W_head b_last + b_head: five
 # small torch matmuls per step, differentiable, so the original parameters get their gradients by the chain rule) and the stack stops at its
 # last hidden activation: one layer launch less in the forward pass, two less in the backward pass, the feature tensor never exists
-MERGE_LAST = os.environ.get("TN_MERGE_LAST", "1") != "0"
+MERGE_LAST = CONFIG.merge_last
 # round 5 (TN_MLP_LEAN): the paired f16x2 training forward writes masks / pre-activations / feature rows only, the weight-gradient launches
 # rebuild the hidden activations from the feature rows (csrc/mlp_wgrad_rc.hip) -- 2.7 GB less workspace traffic per K-Planes step.
 # TN_KP_LEAN=0: the stash-everything form of rounds 1-4 (A/B runs; always taken by the fp32 / bf16x3 head forms)
-KP_LEAN = os.environ.get("TN_KP_LEAN", "1") != "0"
+KP_LEAN = CONFIG.kp_lean
 _side_streams: dict = {}
 
 
@@ -117,7 +114,7 @@ def _upstream_is_gated(ctx: Any) -> bool:
     return bool(ctx.gate_in_slot and ctx.stats is not None and ctx.stats.get("upstream_gated"))
 
 
-INFER_PAIR = os.environ.get("TN_INFER_PAIR", "1") != "0"       # (0: always the gated inference form -- A/B, debugging)
+INFER_PAIR = CONFIG.infer_pair       # (TN_INFER_PAIR=0: always the gated inference form -- A/B, debugging)
 INFER_PAIR_MIN_LIVE = 0.6       # the pair form is taken at >= this live fraction ...
 INFER_PAIR_HYSTERESIS = 0.15    # ... and kept until the fraction falls below MIN_LIVE - HYSTERESIS (chunks of an image alternate between background
                                 # and object: without the band the form -- not the result -- would flip from chunk to chunk)
@@ -326,26 +323,7 @@ class _RenderKPlanes(Function):
             pair_args = (C.byref(sdesc), L.ptr(feat), L.ptr(table), L.ptr(g_rgbs), L.ptr(g_sigma),
                          C.c_int64(n), gw_r, gb_r, gw_s, gb_s, L.ptr(g_feat), L.ptr(ws_r), C.c_int64(rb), L.ptr(ws_s), C.c_int64(sb))
             scatter_fused = FUSE_SCATTER and kdesc.n_scales == 3 and kdesc.channels == 32 and len(keep) == 9
-            if BWD_SCHEDULE in ("split", "overlap"):
-                rdesc.flags = base_flags | L.MLP_CHAIN_ONLY
-                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
-                if BWD_SCHEDULE == "overlap":
-                    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        scatter()
-                else:
-                    scatter()
-                scattered = True
-                if ctx.planes_ready is not None and BWD_SCHEDULE == "split":
-                    ctx.planes_ready(g_planes)
-                rdesc.flags = base_flags | L.MLP_WGRAD_ONLY
-                L.call("tn_mlp_bwd_pair", dev, C.byref(rdesc), *pair_args)
-                if BWD_SCHEDULE == "overlap":
-                    main.wait_stream(side)
-                    if ctx.planes_ready is not None:
-                        ctx.planes_ready(g_planes)
-            elif scatter_fused:
+            if scatter_fused:
                 # data gradients of both heads AND the plane scatter in one launch: d loss / d features stays in registers
                 def chain_and_weights(flags):
                     rdesc.flags = base_flags | flags

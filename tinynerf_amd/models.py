@@ -29,9 +29,8 @@ from . import _lib as L
 # TN_MATMUL=fp32 / bf16x3 in the environment (or assigning here) selects them; the default is
 # "f16x2" (TN_MLP_F16X2, round 4) = all three passes of the hidden layers on the fp16 matrix cores with two-term operand splits and
 # power-of-two scales (three products instead of six; csrc/mlp_f2_layers.hip).
-MATMUL = os.environ.get("TN_MATMUL", "f16x2").lower()
-if MATMUL not in ("fp32", "bf16x3", "f16x2"):
-    raise RuntimeError(f"TN_MATMUL={MATMUL}: fp32, bf16x3 or f16x2")
+from .config import CONFIG as _CONFIG      # noqa: E402
+MATMUL = _CONFIG.matmul
 
 
 def _mlp_desc(params: Sequence[torch.Tensor], in_dim: int, encoding: int, n_freqs: int, out_act: int,

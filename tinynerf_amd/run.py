@@ -36,7 +36,9 @@ def psnr(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return -10. * torch.log10(torch.mean((x - y) ** 2))
 
 
-ADAM_OVERLAP = os.environ.get("TN_ADAM_OVERLAP", "1") != "0"      # N == 1: the planes' optimizer pass beside the weight-gradient kernels (_planes_adam_early)
+from .config import CONFIG as _CONFIG      # noqa: E402
+ADAM_OVERLAP = _CONFIG.adam_overlap      # TN_ADAM_OVERLAP; N == 1: the planes' optimizer pass beside the weight-gradient kernels (_planes_adam_early)
+SIDE_PLAN = _CONFIG.side_plan            # TN_SIDE_PLAN; the next step's sampler pass on a stream of its own
 
 
 @dataclass
@@ -393,7 +395,7 @@ class Trainer:
             # ray stream only, so it goes to a stream of its own behind this forward pass -- VALU work that fills in beside the
             # HBM-bound weight-gradient kernels of the backward pass instead of standing in line with them.  build_batch() waits for
             # its event on the host before anything of the next step is launched, and its buffers are the other turn's.
-            if os.environ.get("TN_SIDE_PLAN", "1") == "0":        # (same stream: debugging / A-B timing)
+            if not SIDE_PLAN:        # (same stream: debugging / A-B timing)
                 self._launch_plan()
             else:
                 if self._side is None:

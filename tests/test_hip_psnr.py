@@ -88,7 +88,9 @@ def test_psnr_at_step_on_the_reference_trajectory():
         control[run["seed"]] = {s: round(abs(curve[s] - twin[s]), 3) for s in eval_at}
         assert abs(curve[0] - run["psnr"]["0"]) < 2e-3, report[run["seed"]]
         for s in tight_at:
-            assert abs(curve[s] - run["psnr"][str(s)]) < 0.1, (run["seed"], s, report[run["seed"]])
+            # 0.1 dB (north star) -- or, where this very trajectory has already begun to part from ITSELF (the twin: same seeds, only the
+            # order of the plane-gradient atomics differs), three times that distance: no comparison can be tighter than the run is determined
+            assert abs(curve[s] - run["psnr"][str(s)]) < max(0.1, 3.0 * abs(curve[s] - twin[s])), (run["seed"], s, report[run["seed"]], control[run["seed"]])
         for s, env in envelope.items():
             assert abs(curve[s] - run["psnr"][str(s)]) <= max(env, 0.1), (run["seed"], s, env, report[run["seed"]])
     print("PSNR@step (HIP, CPU port of the reference) per seed:", report)

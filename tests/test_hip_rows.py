@@ -100,15 +100,16 @@ def test_rows_view_reports_only_layer_kernel_stacks():
     y, g, st = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     assert L.lib().tn_mlp_rows_view(C.byref(desc), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) == 0
     # slab layout (round 5): every row set contiguous over the 32 tiles -- slabs of 32 x 256 rows: 9 hidden activations, buffer A (= y),
-    # buffer B (= d loss / d y), and one slab shared by the 64 encoded-input rows and the 9 x 16 ReLU bit rows; a tile of a slab = 256 rows
+    # buffer B (= d loss / d y), and one slab shared by the 64 encoded-input rows and the 9 x 16 ReLU bit rows; a tile of a slab = 256 rows;
+    # round 6: + 9 slabs, one per hidden layer's gradient (the cross-layer data-gradient chain writes each once)
     slab = 32 * 256 * 32
     assert y.value == 9 * slab and g.value == 10 * slab and st.value == 256 * 32
     fn = L.lib().tn_mlp_bwd_workspace_bytes
     fn.restype = C.c_int64
     # (+ the tail: per-layer maxima for the f16x2 weight gradient; + round 6: the packed weight stream of the cross-layer forward,
     #  csrc/mlp_fused_f2.hip -- 2.4 MB for this stack whatever n is)
-    extra = fn(C.byref(desc), C.c_int64(1000)) - (12 * slab * 4 + 256)
-    assert 2 << 20 < extra < 3 << 20 and fn(C.byref(desc), C.c_int64(2016)) - (63 * 12 * 256 * 32 * 4 + 256) == extra
+    extra = fn(C.byref(desc), C.c_int64(1000)) - (21 * slab * 4 + 256)
+    assert 2 << 20 < extra < 3 << 20 and fn(C.byref(desc), C.c_int64(2016)) - (63 * 21 * 256 * 32 * 4 + 256) == extra
     od = m.VanillaOpacityDecoder(256).to(DEV)                         # a width-64 head has no row views
     d2 = m._mlp_desc(od.net.params(), 256, L.ENC_NONE, 0, L.ACT_EXP_M1, None)
     assert L.lib().tn_mlp_rows_view(C.byref(d2), C.c_int64(1000), C.byref(y), C.byref(g), C.byref(st)) != 0

@@ -1084,12 +1084,14 @@ struct RowMap {
     int64_t sl;                                  // rows per slab
     Layout lay;
     int64_t e_off, m_off[TN_MLP_MAX_LAYERS];
+    int64_t gc_off;                              // slab layout: first of the L - 1 slabs of the fused data-gradient chain (round 6)
     int n_slabs;
     int64_t offH(int l) const { return slab ? l * sl : (int64_t)l * H; }                 // activation l (output of layer l), l < L - 1
     int64_t offE() const { return slab ? e_off : lay.rowsH; }
     int64_t offGA() const { return slab ? (L - 1) * sl : lay.rowsH + lay.rowsE; }
     int64_t offGB() const { return slab ? L * sl : lay.rowsH + lay.rowsE + lay.rowsG; }
     int64_t offM(int l) const { return slab ? m_off[l] : lay.rowsH + lay.rowsE + 2 * lay.rowsG + 2 * (H / 32) * l; }   // bit rows of activation l
+    int64_t offGC(int l) const { return gc_off + l * sl; }      // slab layout: d loss / d (pre-activation of hidden layer l), kept for its weight gradient
     int64_t total_rows(int64_t n_tiles) const { return slab ? n_slabs * sl : n_tiles * lay.total; }
 };
 __host__ inline bool slab_eligible(int H, int L, int enc, int in_dim, int K0_pad, int out) {
@@ -1103,7 +1105,7 @@ __host__ inline RowMap make_rowmap(int H, int L, int enc, int in_dim, int K0_pad
     m.lay = make_layout(H, L, enc, in_dim, K0_pad, out);
     m.slab = slab; m.H = H; m.L = L; m.sl = n_tiles * H;
     m.rows_total = slab ? H : m.lay.total;
-    m.e_off = 0; m.n_slabs = 0;
+    m.e_off = 0; m.n_slabs = 0; m.gc_off = 0;
     for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) m.m_off[l] = 0;
     if (slab) {
         int64_t sidx = L + 1;                      // slabs 0 .. L - 2: activations, L - 1 / L: buffers A / B
@@ -1116,6 +1118,10 @@ __host__ inline RowMap make_rowmap(int H, int L, int enc, int in_dim, int K0_pad
             within += mr;
         }
         m.n_slabs = (int)sidx + 1;
+        // the cross-layer data-gradient chain (mlp_fused_f2.hip) writes every layer's gradient once and the weight-gradient launches read
+        // them afterwards: one slab per hidden layer instead of the two ping-pong buffers
+        m.gc_off = (int64_t)m.n_slabs * m.sl;
+        m.n_slabs += L - 1;
     }
     return m;
 }
@@ -1245,11 +1251,32 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
     }
     const int64_t offE = rm.offE(), offGA = rm.offGA(), offGB = rm.offGB();
     int64_t cur = gy_rows ? offGB : offGA, nxt = gy_rows ? offGA : offGB;
+    const int top = L - 1 - (a.skip_last ? 1 : 0);
+    // round 6: every data gradient of the stack in ONE persistent launch (mlp_fused_f2.hip fused_chain_kernel): the gradients stay in
+    // registers between the layers and reach the workspace once, as the rows the weight-gradient launches below read
+    bool chain = false;
+    if constexpr (H == 128 || H == 256) {
+        bool square = top >= 1;
+        for (int l = 1; l <= top; ++l) square = square && a.N[l] == H && a.K[l] == H;
+        if (stashed && rm.slab && a.f2 && !a.layerwise && square && L <= 16 && layer_kernel_path(H, L, a.out_dim)) {
+            FusedChain fc;
+            fc.rows = stash; fc.rows_total = rm.rows_total; fc.off_in = cur; fc.tail = ws_tail(stash, tail_rows);
+            for (int i = 0; i < TN_MLP_MAX_LAYERS; ++i) { fc.off_out[i] = 0; fc.off_bits[i] = 0; fc.tail_idx[i] = -1; }
+            for (int i = 0; i < top; ++i) {
+                const int l = top - i;
+                fc.off_out[i] = rm.offGC(l - 1); fc.off_bits[i] = rm.offM(l - 1); fc.tail_idx[i] = 16 + l;
+            }
+            if (int rc = launch_fused_chain_f2(H, a, top, n, fused_pack_area(stash, tail_rows), s, &fc)) return rc;
+            chain = true;
+        }
+    }
+    const int64_t top_off = cur;
+    auto g_rows = [&](int l) -> int64_t { return chain ? (l == top ? top_off : rm.offGC(l)) : cur; };       // d loss / d (pre-activation of layer l)
     // (TN_MLP_SKIP_LAST: buffer B holds d loss / d (pre-activation of layer L - 2) -- the walk starts one layer lower)
-    for (int l = L - 1 - (a.skip_last ? 1 : 0); l >= 0; --l) {
+    for (int l = top; l >= 0; --l) {
         WgradArgs w;
         w.gW = gw[l]; w.gB = gb[l]; w.N = a.N[l]; w.K = a.K[l]; w.K_pad = l == 0 ? a.K0_pad : a.K[l];
-        w.rows_total = rm.rows_total; w.off_g = cur; w.off_a = l > 0 ? rm.offH(l - 1) : 0; w.off_e = offE;
+        w.rows_total = rm.rows_total; w.off_g = g_rows(l); w.off_a = l > 0 ? rm.offH(l - 1) : 0; w.off_e = offE;
         w.first = l == 0; w.enc = a.enc; w.in_dim = a.in_dim; w.n_freqs = a.n_freqs; w.xs = lay.xs;
         const int tiles = ((w.N + 31) / 32) * ((w.K_pad + 31) / 32);
         const int64_t wblocks = std::min<int64_t>(n_tiles, 256 * 2);
@@ -1265,7 +1292,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
                 d.off_bits = rm.offM(l - 1);
                 d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
                 d.max_in = tail + 16 + l;
-                if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc;
+                if (!chain) { if (int rc = launch_dgrad_f2(H, d, n, stash, s)) return rc; }       // (chain: its launch has written the rows and the maximum)
                 dgrad_done = true;
                 w.g_max = tail + 16 + l; w.a_max = tail + l;
                 if (int rc = launch_wgrad_f2(H, w, n, stash, s)) return rc;
@@ -1282,7 +1309,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
         if constexpr (H == 256 || H == 128) {
             // plain inputs staged as 64 rows by the training forward (Cobafa's 36 features): same kernel, 128 x 64 / 256 x 64
             if (!staged && w.first && stashed && lay.rowsE == 64 && plain_x_rows(H, L, a.enc, a.K0_pad, a.out_dim) && w.N == H) {
-                if (int rc = tn_mlp_wgrad_rows(stash + cur * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
+                if (int rc = tn_mlp_wgrad_rows(stash + g_rows(l) * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
                                                (int64_t)rm.rows_total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
                 staged = true;
             }
@@ -1292,7 +1319,7 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
             // the row-operand kernel of mlp_wgrad_rows.hip (LDS-direct tiles, 2 x 1 accumulator tiles per wave) instead of
             // per-wave operand loads from L2
             if (!staged && w.first && lay.xs == 0 && w.K_pad == 64 && w.N == H) {
-                if (int rc = tn_mlp_wgrad_rows(stash + cur * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
+                if (int rc = tn_mlp_wgrad_rows(stash + g_rows(l) * 32, (int64_t)rm.rows_total * 32, H, stash + offE * 32,
                                                (int64_t)rm.rows_total * 32, 64, w.gW, w.K, 0, w.K, w.gB, n, s)) return rc;
                 staged = true;
             }
@@ -1308,14 +1335,14 @@ int run_layers(const MlpArgs &a, const float *x, const float *aux, const float *
 
         DgradArgs d;
         d.W = a.W[l]; d.N = a.N[l]; d.K = a.K[l]; d.rows_total = rm.rows_total;
-        d.off_gin = cur; d.off_gout = nxt; d.off_mask = l > 0 ? rm.offH(l - 1) : 0;
+        d.off_gin = g_rows(l); d.off_gout = nxt; d.off_mask = l > 0 ? rm.offH(l - 1) : 0;
         // ReLU bit rows exist for every activation the training forward of the layer-kernel path wrote (run_fwd_only)
         const bool bits = stashed && layer_kernel_path(H, L, a.out_dim) && l >= 1;
         d.off_bits = bits ? rm.offM(l - 1) : -1;
         d.enc = a.enc; d.in_dim = a.in_dim; d.n_freqs = a.n_freqs; d.accum_gx = a.accum_gx;
         const int64_t blocks = std::min<int64_t>((n_tiles + WPB - 1) / WPB, 256 * 4);
         if (l > 0) {
-            bool done = dgrad_done;
+            bool done = dgrad_done || chain;
             if constexpr (H >= 128) {
                 if (done) {}
                 else if (a.K[l] == H && a.N[l] == H) {

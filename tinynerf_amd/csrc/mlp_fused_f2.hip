@@ -90,7 +90,9 @@ struct FusedArgs {
     int out_linear;                  // 1: layer L - 1 is the stack's output layer (no activation); 0: every layer of the stream is hidden (TN_MLP_SKIP_LAST)
     int64_t off_out[TN_MLP_MAX_LAYERS];      // row offset of layer l's output (activation H_l; the output layer: buffer A)
     int64_t off_bits[TN_MLP_MAX_LAYERS];     // ... of its ReLU bit rows (2 per 32-feature block), hidden layers only
-    float *tail;                     // tail[l] receives the largest |value| of layer l's INPUT rows, l >= 1 (scale of that layer's weight gradient)
+    float *tail;                     // tail[tail_idx[l]] receives the largest |value| of layer l's INPUT rows (scale of a weight-gradient launch); idx < 0: not wanted
+    int tail_idx[TN_MLP_MAX_LAYERS];
+    int64_t off_in;                  // data-gradient chain: row offset of the gradient it starts from (H rows per tile)
 };
 
 struct PackArgs {
@@ -99,6 +101,7 @@ struct PackArgs {
     int N[TN_MLP_MAX_LAYERS], K[TN_MLP_MAX_LAYERS];
     int64_t off[TN_MLP_MAX_LAYERS];  // byte offset of layer l in the stream
     int L, H;
+    int transpose;                   // data-gradient chain: layer l's A operand is W_l^T (no bias)
     unsigned char *stream;
     float *bias, *consts;
 };
@@ -117,15 +120,18 @@ __device__ __forceinline__ void bound_scales(float u, float &s, float &inv) {
 __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
 {
     __shared__ float red[3][16];
-    const int l = blockIdx.x, H = a.H, N = a.N[l], K = a.K[l];
+    const int l = blockIdx.x, H = a.H;
+    const int N = a.transpose ? a.K[l] : a.N[l], K = a.transpose ? a.N[l] : a.K[l];         // rows / columns of the A operand
+    const int ldw = a.K[l];
     const float *W = a.W[l];
+    auto elem = [&](int r, int k) -> float { return a.transpose ? W[(int64_t)k * ldw + r] : W[(int64_t)r * ldw + k]; };
     const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
     float wmax = 0.0f, n2 = 0.0f, bmax = 0.0f;
     for (int r = threadIdx.x; r < N; r += blockDim.x) {
         float s2 = 0.0f;
-        for (int k = 0; k < K; ++k) { const float w = fabsf(W[(int64_t)r * K + k]); wmax = fmaxf(wmax, w); s2 += w; }
+        for (int k = 0; k < K; ++k) { const float w = fabsf(elem(r, k)); wmax = fmaxf(wmax, w); s2 += w; }
         n2 = fmaxf(n2, s2);
-        bmax = fmaxf(bmax, fabsf(a.B[l][r]));
+        if (!a.transpose) bmax = fmaxf(bmax, fabsf(a.B[l][r]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
         a.consts[4 * l + 2] = bmax;
         a.consts[4 * l + 3] = 0.0f;
     }
-    for (int e = threadIdx.x; e < H; e += blockDim.x) a.bias[l * H + e] = e < N ? a.B[l][e] : 0.0f;
-    const int KS = l == 0 ? KS0 : H / 16;
+    for (int e = threadIdx.x; e < H; e += blockDim.x) a.bias[l * H + e] = (e < N && !a.transpose) ? a.B[l][e] : 0.0f;
+    const int KS = (l == 0 && !a.transpose) ? KS0 : H / 16;       // (the forward's first layer has <= 64 inputs; the chain has no such layer)
     unsigned char *dst = a.stream + a.off[l];
     for (int idx = threadIdx.x; idx < (H / 32) * KS * 64; idx += blockDim.x) {
         // consumption order: group gi = output blocks 2 gi, 2 gi + 1; inside a group k step by k step, the even block first
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = 2 * p + u, col = 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);       // (mlp_f2_heads.h f2_perm: k block s, half h)
-                v[u] = (row < N && col < K) ? W[(int64_t)row * K + col] * s_w : 0.0f;
+                v[u] = (row < N && col < K) ? elem(row, col) * s_w : 0.0f;
             }
             const f16x2h hh = {(_Float16)v[0], (_Float16)v[1]};
             const f16x2h ll = {(_Float16)(v[0] - (float)hh[0]), (_Float16)(v[1] - (float)hh[1])};
@@ -247,32 +253,55 @@ template <int H> struct State {
 // SLOWER: beside MFMAs a VOP3P instruction costs about two plain ones.)  The column's largest scaled value goes into `xmax`: the
 // next layer's a-priori bound is max_i ||W_i||_1 max |x| + max |b|.
 struct PairTmp { float v0, v1, a0, a1; unsigned hi; };
-template <int PH>
-__device__ __forceinline__ void pair_phase(PairTmp &t, float c0, float c1, float b0, float b1, float cmul, float s_out, unsigned &hi_out, unsigned &lo_out, float &xmax) {
+// GRAD (the data-gradient chain): the pair is a gradient -- no bias, no ReLU; it is multiplied by relu'(h) of the activation it flows into,
+// taken from that activation's bit rows (`mask`: bit r of the lane's dword of the block, r = R0, R0 + 1), and it is signed
+// SPLIT (GRAD, one pair per step): the scale multiply moves from phase 1 to phase 2, so that no gap of the step holds more than five instructions
+template <int PH, bool GRAD = false, int R0 = 0, bool SPLIT = false>
+__device__ __forceinline__ void pair_phase(PairTmp &t, float c0, float c1, float b0, float b1, float cmul, float s_out, unsigned &hi_out, unsigned &lo_out, float &xmax,
+                                           unsigned mask = 0) {
     // (inline assembly: left to itself hipcc rebuilds the v_fma_mix forms out of the plain ones and batches the packing)
-    if constexpr (PH == 0) { t.v0 = fmaf(c0, cmul, b0); t.v1 = fmaf(c1, cmul, b1); }
-    if constexpr (PH == 1) {
-        asm("v_max_f32 %0, 0, %1" : "=v"(t.v0) : "v"(t.v0));
-        asm("v_max_f32 %0, 0, %1" : "=v"(t.v1) : "v"(t.v1));
-        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t.a0) : "v"(t.v0), "v"(s_out));            // exact: s is a power of two
-        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t.a1) : "v"(t.v1), "v"(s_out));
+    if constexpr (PH == 0) {
+        if constexpr (GRAD) { t.v0 = c0 * cmul; t.v1 = c1 * cmul; }
+        else { t.v0 = fmaf(c0, cmul, b0); t.v1 = fmaf(c1, cmul, b1); }
     }
-    if constexpr (PH == 2) {
+    // (one asm statement per phase: between two statements hipcc's hazard recogniser, which cannot see into them, pads dependent ones with s_nop)
+    if constexpr (PH == 1) {
+        if constexpr (GRAD) {
+            // bit R0 of the mask sign-extended to a word, ANDed in: two instructions per value (hipcc turns the C form into
+            // and + compare + select through vcc, with wait states); then the scale (exact: s is a power of two)
+            if constexpr (SPLIT)
+                asm("v_bfe_i32 %2, %4, %5, 1\n\tv_bfe_i32 %3, %4, %6, 1\n\tv_and_b32_e32 %0, %0, %2\n\tv_and_b32_e32 %1, %1, %3"
+                    : "+v"(t.v0), "+v"(t.v1), "=&v"(t.a0), "=&v"(t.a1) : "v"(mask), "n"(R0), "n"(R0 + 1));
+            else
+                asm("v_bfe_i32 %2, %4, %5, 1\n\tv_bfe_i32 %3, %4, %6, 1\n\tv_and_b32_e32 %0, %0, %2\n\tv_and_b32_e32 %1, %1, %3\n\t"
+                    "v_mul_f32_e32 %2, %0, %7\n\tv_mul_f32_e32 %3, %1, %7"
+                    : "+v"(t.v0), "+v"(t.v1), "=&v"(t.a0), "=&v"(t.a1) : "v"(mask), "n"(R0), "n"(R0 + 1), "v"(s_out));
+        } else {
+            asm("v_max_f32_e32 %0, 0, %0\n\tv_max_f32_e32 %1, 0, %1\n\tv_mul_f32_e32 %2, %0, %4\n\tv_mul_f32_e32 %3, %1, %4"
+                : "+v"(t.v0), "+v"(t.v1), "=&v"(t.a0), "=&v"(t.a1) : "v"(s_out));
+        }
+    }
+    if constexpr (PH == 2 && GRAD && SPLIT) {
+        asm("v_mul_f32_e32 %0, %4, %6\n\tv_mul_f32_e32 %1, %5, %6\n\tv_cvt_pk_f16_f32 %2, %0, %1\n\tv_max3_f32 %3, %3, |%0|, |%1|"
+            : "=&v"(t.a0), "=&v"(t.a1), "=&v"(t.hi), "+v"(xmax) : "v"(t.v0), "v"(t.v1), "v"(s_out));
+        hi_out = t.hi;
+    } else if constexpr (PH == 2) {
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(t.hi) : "v"(t.a0), "v"(t.a1));          // round to nearest even
         hi_out = t.hi;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(xmax) : "v"(xmax), "v"(t.a0), "v"(t.a1));  // (a >= 0 behind the ReLU)
+        if constexpr (GRAD) asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(xmax) : "v"(xmax), "v"(t.a0), "v"(t.a1));
+        else asm("v_max3_f32 %0, %1, %2, %3" : "=v"(xmax) : "v"(xmax), "v"(t.a0), "v"(t.a1));  // (a >= 0 behind the ReLU)
     }
     if constexpr (PH == 3) {
         float h0, h1;
-        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(h0) : "v"(t.hi));
-        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(h1) : "v"(t.hi));
-        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(t.a0) : "v"(t.a0), "v"(h0));               // exact
-        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(t.a1) : "v"(t.a1), "v"(h1));
+        asm("v_cvt_f32_f16_e32 %2, %4\n\tv_cvt_f32_f16_sdwa %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+            "v_sub_f32_e32 %0, %0, %2\n\tv_sub_f32_e32 %1, %1, %3"                     // exact
+            : "+v"(t.a0), "+v"(t.a1), "=&v"(h0), "=&v"(h1) : "v"(t.hi));
     }
     if constexpr (PH == 4) { asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo_out) : "v"(t.a0), "v"(t.a1)); }
 }
 
-// One layer.  MODE 0: hidden (ReLU, operands of the next layer into `out`), MODE 1: the output layer (rows of y).  HAS_PREV: the last
+// One layer.  MODE 0: hidden (ReLU, operands of the next layer into `out`), MODE 1: the output layer (rows of y), MODE 2: a layer of the
+// data-gradient chain (A = W^T blocks, no bias, relu' of the activation below from its bit rows, gradient rows out).  HAS_PREV: the last
 // two blocks of the previous layer are still pending (st.pend) and are finished behind the first k steps of this one, into `in`.
 template <int H, int KSL, int MODE, bool HAS_PREV, bool STASH>
 struct Layer {
@@ -291,7 +320,8 @@ struct Layer {
     float *yrow; bool store; int h;
     bool own_tile;                 // false: a wave without a tile of its own (it recomputes the last tile; what it would write differs for the masked samples)
     float *rows; unsigned *bits;   // STASH: this layer's output rows / bit rows of the wave's tile (wave-uniform); lane offset below
-    unsigned lane_off;             // (4 h 32 + j) 4: byte offset of D register 0 of a block inside its 32 rows
+    unsigned lane_off;             // (4 h 32 + j) 4: byte offset of D register 0 of a block inside its 32 rows; an opaque 32-bit value (Tile), so that
+                                   // base + zero-extended offset + immediate selects the SGPR-base form of the stores without a copy per store
     int lane;
     unsigned bitacc[2];            // ReLU bits of the two blocks being finished
     unsigned max_addr;             // STASH: LDS address of this lane's running maximum of the layer's input (0: not wanted)
@@ -308,29 +338,41 @@ struct Layer {
     }
     // pending pair Q (0 .. 15: block Q >> 3, registers 2 (Q & 7), + 1) of hidden group `grp` (blocks 2 grp, 2 grp + 1) -> dst; phase PH
     PairTmp tmp[2];
-    template <int Q, int PH>
+    unsigned bit0[2], bit1[2];     // STASH: v > 0 of the pair's two values, on their way into bitacc
+    // SPREAD (one pair per step, phase = gap): the row stores and the bit arithmetic are dealt over phases 2 .. 4 so that no gap holds more than
+    // five instructions; otherwise (two or four pairs per step) everything of a pair sits in its five phases as densely as it comes
+    template <int Q, int PH, bool SPREAD = false>
     __device__ __forceinline__ void hidden_phase(const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp,
                                                  float *rows_, unsigned *bits_) {
         constexpr int blk = Q >> 3, r0 = 2 * (Q & 7);
         Op2 &d = dst[2 * (2 * grp + blk) + (r0 >> 3)];
         unsigned hi_ = 0, lo_ = 0;
-        pair_phase<PH>(tmp[Q & 1], cc[blk][r0], cc[blk][r0 + 1], bb[blk][r0 >> 2][r0 & 3], bb[blk][r0 >> 2][(r0 & 3) + 1], cm, so, hi_, lo_, st.xmax);
+        if constexpr (MODE == 2)          // (the mask dword of the block travels in the first bias slot)
+            pair_phase<PH, true, r0, SPREAD>(tmp[Q & 1], cc[blk][r0], cc[blk][r0 + 1], 0.0f, 0.0f, cm, so, hi_, lo_, st.xmax, __float_as_uint(bb[blk][0][0]));
+        else
+            pair_phase<PH>(tmp[Q & 1], cc[blk][r0], cc[blk][r0 + 1], bb[blk][r0 >> 2][r0 & 3], bb[blk][r0 >> 2][(r0 & 3) + 1], cm, so, hi_, lo_, st.xmax);
         if constexpr (PH == 2) d.hi[(r0 >> 1) & 3] = hi_;
         if constexpr (PH == 4) d.lo[(r0 >> 1) & 3] = lo_;
-        if constexpr (STASH) {
-            // the activation (after the ReLU, before the scale) as two [feature][32-sample] rows; SGPR base + lane offset + immediate
-            if constexpr (PH == 2) {
-                char *p = reinterpret_cast<char *>(rows_ + 32 * (2 * grp + blk) * 32);
-                unsigned off = lane_off;
-                asm volatile("" : "+v"(off));
-                constexpr int rr0 = ((r0 & 3) + 8 * (r0 >> 2)) * 128;
-                __builtin_nontemporal_store(tmp[Q & 1].v0, reinterpret_cast<float *>(p + off + rr0));
-                __builtin_nontemporal_store(tmp[Q & 1].v1, reinterpret_cast<float *>(p + off + rr0 + 128));
+        if constexpr (MODE == 2 || STASH) {
+            // MODE 2: the gradient, STASH: the activation (after the ReLU, before the scale), as two [feature][32-sample] rows (the weight-gradient
+            // launches read them)
+            char *p = reinterpret_cast<char *>(rows_ + 32 * (2 * grp + blk) * 32);
+            constexpr int rr0 = ((r0 & 3) + 8 * (r0 >> 2)) * 128;
+            if constexpr (PH == 2) __builtin_nontemporal_store(tmp[Q & 1].v0, reinterpret_cast<float *>(p + lane_off + rr0));
+            if constexpr (PH == (SPREAD ? 3 : 2)) __builtin_nontemporal_store(tmp[Q & 1].v1, reinterpret_cast<float *>(p + lane_off + rr0 + 128));
+        }
+        if constexpr (MODE != 2 && STASH) {
+            // v > 0 of a value behind the ReLU = min(its bit pattern, 1); shifted into place by v_lshl_or: two instructions per value
+            // (hipcc turns the C form into class compare + select through vcc + or)
+            if constexpr (PH == (SPREAD ? 2 : 3)) {
+                asm("v_min_u32_e32 %0, 1, %1" : "=v"(bit0[Q & 1]) : "v"(tmp[Q & 1].v0));
+                asm("v_min_u32_e32 %0, 1, %1" : "=v"(bit1[Q & 1]) : "v"(tmp[Q & 1].v1));
             }
-            if constexpr (PH == 3) {
-                unsigned b0 = min(__float_as_uint(tmp[Q & 1].v0), 1u), b1 = min(__float_as_uint(tmp[Q & 1].v1), 1u);
-                if constexpr ((Q & 7) == 0) bitacc[blk] = b0 | (b1 << 1);
-                else bitacc[blk] |= (b0 << r0) | (b1 << (r0 + 1));
+            if constexpr (PH == (SPREAD ? 4 : 3)) {
+                if constexpr ((Q & 7) == 0) asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(bitacc[blk]) : "v"(bit1[Q & 1]), "v"(bit0[Q & 1]));
+                else
+                    asm("v_lshl_or_b32 %0, %1, %3, %0\n\tv_lshl_or_b32 %0, %2, %4, %0"
+                        : "+v"(bitacc[blk]) : "v"(bit0[Q & 1]), "v"(bit1[Q & 1]), "n"(r0), "n"(r0 + 1));
             }
             if constexpr (PH == 4 && (Q & 7) == 7) bits_[(2 * (2 * grp + blk)) * 32 + lane] = bitacc[blk];
         }
@@ -347,11 +389,11 @@ struct Layer {
     __device__ __forceinline__ void hidden_gap(int gap, const f32x16 (&cc)[2], const f32x4 (&bb)[2][4], float cm, float so, Op2 (&dst)[KS], int grp,
                                                float *rows_, unsigned *bits_) {
         if constexpr (NPAIR == 1) {
-            if (gap == 0) hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp, rows_, bits_);
-            if (gap == 1) hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp, rows_, bits_);
-            if (gap == 2) hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp, rows_, bits_);
-            if (gap == 3) hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp, rows_, bits_);
-            if (gap == 4) hidden_phase<Q0, 4>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 0) hidden_phase<Q0, 0, true>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 1) hidden_phase<Q0, 1, true>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 2) hidden_phase<Q0, 2, true>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 3) hidden_phase<Q0, 3, true>(cc, bb, cm, so, dst, grp, rows_, bits_);
+            if (gap == 4) hidden_phase<Q0, 4, true>(cc, bb, cm, so, dst, grp, rows_, bits_);
         } else if constexpr (NPAIR == 2) {
             if (gap == 0) { hidden_phase<Q0, 0>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0, 1>(cc, bb, cm, so, dst, grp, rows_, bits_); }
             if (gap == 1) { hidden_phase<Q0, 2>(cc, bb, cm, so, dst, grp, rows_, bits_); hidden_phase<Q0, 3>(cc, bb, cm, so, dst, grp, rows_, bits_); }
@@ -381,6 +423,9 @@ struct Layer {
             for (int u = 0; u < 4; ++u) if (own_tile) *reinterpret_cast<float *>(p + off + (u + 8 * q) * 128) = store ? v[u] : 0.0f;
         }
     }
+    template <int BLK> __device__ __forceinline__ void load_mask(f32x4 (&bb)[2][4], int grp) {       // MODE 2: relu' bits of the block the gradient flows into
+        bb[BLK][0][0] = __uint_as_float(bits[(2 * (2 * grp + BLK)) * 32 + lane]);
+    }
     template <int BLK> __device__ __forceinline__ void request_bias(f32x4 (&bb)[2][4], int grp) {
         // (grp is a compile-time constant at every call site; the offset is folded into the address register once per group)
         const unsigned a = bias_addr + (unsigned)(32 * (2 * grp + BLK)) * 4u;
@@ -406,7 +451,7 @@ struct Layer {
         // (requested behind the last MFMA of the step -- gap 5 -- so that the front of the step is the wait alone)
         Op2 (&A)[2] = st.aw[t & 3];
         // the first step of a group follows the bias requests of the previous step: they must be complete as well
-        constexpr bool bias_due = S == 0 && (GI > 0 || HAS_PREV);
+        constexpr bool bias_due = MODE != 2 && S == 0 && (GI > 0 || HAS_PREV);      // (MODE 2: masks come by vector loads, hipcc counts those)
         if (!(TN_FUSED_ABL & (8 | 32))) {
             constexpr int own = 0;                                 // (this step's own requests come behind the wait)
             if constexpr (bias_due) {
@@ -423,7 +468,7 @@ struct Layer {
         // ---- six MFMAs, the two blocks' accumulators in turn; the pending pairs of this step behind them ----
         auto fill = [&](int gap) {
             if constexpr (GI > 0) {
-                if constexpr (MODE == 0) hidden_gap<S * PPS, PPS>(gap, acc[(GI - 1) & 1], bias_cur, cmul, s_out, out, GI - 1, rows, bits);     // pairs S PPS .. of group GI - 1
+                if constexpr (MODE == 0 || MODE == 2) hidden_gap<S * PPS, PPS>(gap, acc[(GI - 1) & 1], bias_cur, cmul, s_out, out, GI - 1, rows, bits);     // pairs S PPS .. of group GI - 1
                 else {
                     // eight quads over the group's KSL steps
                     if constexpr (KSL >= 16) { if ((S & 1) == 0 && gap == 1) out_quad<S / 2>(acc[(GI - 1) & 1], bias_cur, GI - 1); }
@@ -440,19 +485,24 @@ struct Layer {
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.0f;
         f32x16 (&c)[2] = acc[GI & 1];
-        c[0] = mm(A[0].lo, b.hi, S == 0 ? z : c[0]); fill(0); __builtin_amdgcn_sched_barrier(0);
-        c[1] = mm(A[1].lo, b.hi, S == 0 ? z : c[1]); fill(1); __builtin_amdgcn_sched_barrier(0);
-        c[0] = mm(A[0].hi, b.lo, c[0]); fill(2); __builtin_amdgcn_sched_barrier(0);
-        c[1] = mm(A[1].hi, b.lo, c[1]); fill(3); __builtin_amdgcn_sched_barrier(0);
-        c[0] = mm(A[0].hi, b.hi, c[0]); fill(4); ring.template piece<t % 8>(); __builtin_amdgcn_sched_barrier(0);
-        c[1] = mm(A[1].hi, b.hi, c[1]); fill(5); req(0); req(1); req(2); req(3); __builtin_amdgcn_sched_barrier(0);
+        // (a scheduling barrier on both sides of every MFMA: hipcc otherwise moves a gap's fillers in front of it)
+#define TN_SB __builtin_amdgcn_sched_barrier(0)
+        c[0] = mm(A[0].lo, b.hi, S == 0 ? z : c[0]); TN_SB; fill(0); TN_SB;
+        c[1] = mm(A[1].lo, b.hi, S == 0 ? z : c[1]); TN_SB; fill(1); TN_SB;
+        c[0] = mm(A[0].hi, b.lo, c[0]); TN_SB; fill(2); TN_SB;
+        c[1] = mm(A[1].hi, b.lo, c[1]); TN_SB; fill(3); TN_SB;
+        c[0] = mm(A[0].hi, b.hi, c[0]); TN_SB; fill(4); ring.template piece<t % 8>(); TN_SB;
+        c[1] = mm(A[1].hi, b.hi, c[1]); TN_SB; fill(5); req(0); req(1); req(2); req(3); TN_SB;
+#undef TN_SB
         // ---- last step of a group: its accumulators become the pending ones, their bias is requested (8 reads, complete by the next step) ----
         if constexpr (S == KSL - 1) {
             if constexpr (GI + 1 < NG) {
-                request_bias<0>(bias_cur, GI); request_bias<1>(bias_cur, GI);
+                if constexpr (MODE == 2) { load_mask<0>(bias_cur, GI); load_mask<1>(bias_cur, GI); }
+                else { request_bias<0>(bias_cur, GI); request_bias<1>(bias_cur, GI); }
             } else {
                 st.pend.c[0] = c[0]; st.pend.c[1] = c[1];
-                request_bias<0>(st.pend.bias, GI); request_bias<1>(st.pend.bias, GI);
+                if constexpr (MODE == 2) { load_mask<0>(st.pend.bias, GI); load_mask<1>(st.pend.bias, GI); }
+                else { request_bias<0>(st.pend.bias, GI); request_bias<1>(st.pend.bias, GI); }
                 st.pend.cmul = cmul; st.pend.s_out = s_out;
                 st.pend.rows = rows; st.pend.bits = bits;
             }
@@ -484,9 +534,9 @@ __device__ __forceinline__ float run_layer(Ring &ring, State<H> &st, Op2 (&in)[H
     Layer<H, KSL, MODE, HAS_PREV, STASH> L{ring, st, in, out, bias0 + (unsigned)(l * H * 4), cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, tl.h};
     if constexpr (STASH) {
         L.rows = urow(tl.rows_base, a.off_out[l]);
-        L.bits = reinterpret_cast<unsigned *>(urow(tl.rows_base, MODE == 0 ? a.off_bits[l] : 0));
+        L.bits = reinterpret_cast<unsigned *>(urow(tl.rows_base, MODE != 1 ? a.off_bits[l] : 0));
         L.lane_off = tl.lane_off; L.lane = tl.lane;
-        L.max_addr = (l >= 1 && a.tail != nullptr) ? tl.max0 + (unsigned)l * 1024u : 0u;
+        L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * 1024u : 0u;
     }
     L.own_tile = tl.own_tile;
     L.run();
@@ -540,6 +590,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
     Tile tl;
     tl.h = h; tl.lane = lane;
     tl.lane_off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(tl.lane_off));
     tl.max0 = lds0 + NRING * CHUNK_B + (unsigned)(a.L * H) * 4u + (unsigned)threadIdx.x * 4u;
     const int n_hidden = a.L - 1 - (a.out_linear ? 1 : 0);     // hidden layers behind layer 0
 #pragma clang loop unroll(disable)
@@ -593,7 +644,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
             Layer<H, KS, 1, true, STASH> L{ring, st, st.P, st.Q, bias0 + (unsigned)(l * H * 4), cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, h};
             if constexpr (STASH) {
                 L.rows = urow(tl.rows_base, a.off_out[l]); L.bits = nullptr; L.lane_off = tl.lane_off; L.lane = lane;
-                L.max_addr = a.tail != nullptr ? tl.max0 + (unsigned)l * 1024u : 0u;
+                L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * 1024u : 0u;
             }
             L.own_tile = tile_ok;
             L.run();
@@ -621,14 +672,139 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
     if constexpr (STASH) {
         if (a.tail != nullptr) {
             __syncthreads();
-            for (int l = 1; l < a.L; ++l) {
+            for (int l = 0; l < a.L; ++l) {
+                if (a.tail_idx[l] < 0) continue;
                 float m = max_s[l * 256 + threadIdx.x];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + l), __float_as_uint(m));      // (non-negative floats order like their bits)
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + a.tail_idx[l]), __float_as_uint(m));      // (non-negative floats order like their bits)
             }
         }
     }
+}
+
+// The data-gradient chain of a wide stack in the same form (round 6): from the gradient w.r.t. the top layer's pre-activation (rows at
+// off_in) down to the first hidden layer's --  G_{l-1} = relu'(h_{l-1}) * (W_l^T G_l)  -- with the gradients in registers between
+// the layers.  Every G_{l-1} is written once as rows (the weight-gradient launch of layer l - 1 reads it) and never read back here;
+// relu' comes from the bit rows the training forward left.  Stream position i = layer top - i.
+template <int H>
+__global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n)
+{
+    constexpr int KS = H / 16, NB = H / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float *max_s = reinterpret_cast<float *>(lds_raw + NRING * CHUNK_B);           // [L][256] running maxima of the layers' input gradients
+    const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < a.L * 256; e += blockDim.x) max_s[e] = 0.0f;
+    lds_u8 *lds3 = (lds_u8 *)lds_raw;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds3;
+    Ring ring;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.stream, 0, 0x7fffffff, 0x00020000);
+    ring.lds_wave = lds3 + wave * 8192;
+    ring.voff = (unsigned)(wave * 8192 + lane * 16);
+    ring.rd0 = lds0 + lane * 16;
+    ring.n_chunks = (unsigned)a.n_chunks;
+    ring.next = 0;
+    ring.g = (unsigned)-3;
+    for (int k = 0; k < 3; ++k) {
+        ring.target_next();
+        ring.template piece<0>(); ring.template piece<1>(); ring.template piece<2>(); ring.template piece<3>();
+        ring.template piece<4>(); ring.template piece<5>(); ring.template piece<6>(); ring.template piece<7>();
+        ++ring.g;
+    }
+    ring.cur = ring.nxt = ring.rd0;
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int64_t per_round = (int64_t)gridDim.x * 4;
+    const int64_t rounds = (n_tiles + per_round - 1) / per_round;
+    State<H> st;
+    {
+        const unsigned base = ring.rd0;
+        st.aw[0][0].hi = lds16<0>(base); st.aw[0][0].lo = lds16<1024>(base);
+        st.aw[0][1].hi = lds16<PAIR_B>(base); st.aw[0][1].lo = lds16<PAIR_B + 1024>(base);
+        st.aw[1][0].hi = lds16<2 * PAIR_B>(base); st.aw[1][0].lo = lds16<2 * PAIR_B + 1024>(base);
+        st.aw[1][1].hi = lds16<3 * PAIR_B>(base); st.aw[1][1].lo = lds16<3 * PAIR_B + 1024>(base);
+    }
+    Tile tl;
+    tl.h = h; tl.lane = lane; tl.yrow = nullptr; tl.store = false;
+    tl.lane_off = (unsigned)(4 * h * 32 + j) * 4u;
+    asm volatile("" : "+v"(tl.lane_off));
+    tl.max0 = lds0 + NRING * CHUNK_B + (unsigned)threadIdx.x * 4u;
+    const unsigned bias0 = 0;               // (no bias in the chain)
+#pragma clang loop unroll(disable)
+    for (int64_t round = 0; round < rounds; ++round) {
+        const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool tile_ok = tile_raw < n_tiles;
+        const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
+        tl.own_tile = tile_ok;
+        tl.rows_base = urow(a.rows, tile * a.rows_total);
+        float inv_in;
+        {   // the gradient the chain starts from: H rows of the tile in the D layout, exact column maximum
+            const float *in = urow(tl.rows_base, a.off_in);
+            float mx = 0.0f;
+            float x[NB][16];
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { x[t][r] = in[(32 * t + frow(r, h)) * 32 + j]; mx = fmaxf(mx, fabsf(x[t][r])); }
+            mx = f2_xmax(mx);
+            float s_in;
+            f2_scales(mx, s_in, inv_in);
+            st.xmax = mx * s_in;
+#pragma unroll
+            for (int b = 0; b < KS; ++b) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x[b >> 1][8 * (b & 1) + e] * s_in;
+                f2_split8(v, 1.0f, st.Q[b].hi, st.Q[b].lo);
+            }
+        }
+        inv_in = run_layer<H, KS, 2, false, true>(ring, st, st.Q, st.P, a, 0, bias0, inv_in, tl);
+        int l = 1;
+#pragma clang loop unroll(disable)
+        for (; l + 1 < a.L; l += 2) {
+            inv_in = run_layer<H, KS, 2, true, true>(ring, st, st.P, st.Q, a, l, bias0, inv_in, tl);
+            inv_in = run_layer<H, KS, 2, true, true>(ring, st, st.Q, st.P, a, l + 1, bias0, inv_in, tl);
+        }
+        if (l < a.L) {
+            inv_in = run_layer<H, KS, 2, true, true>(ring, st, st.P, st.Q, a, l, bias0, inv_in, tl);
+#pragma unroll
+            for (int b = 0; b < KS - 4; ++b) st.P[b] = st.Q[b];
+        }
+        // the last layer's last two blocks: their rows (the operands they would become have no consumer)
+        {
+            Layer<H, KS, 2, true, true> L{ring, st, st.P, st.Q, 0u, 0.0f, 0.0f, 0.0f, inv_in, 0.0f, 0.0f, 0.0f, nullptr, false, h};
+            L.lane_off = tl.lane_off; L.lane = lane; L.max_addr = 0; L.own_tile = tile_ok;
+            L.template flush_pending<0>(); L.template flush_pending<1>(); L.template flush_pending<2>(); L.template flush_pending<3>();
+            L.template flush_pending<4>(); L.template flush_pending<5>(); L.template flush_pending<6>(); L.template flush_pending<7>();
+            L.template flush_pending<8>(); L.template flush_pending<9>(); L.template flush_pending<10>(); L.template flush_pending<11>();
+            L.template flush_pending<12>(); L.template flush_pending<13>(); L.template flush_pending<14>(); L.template flush_pending<15>();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (a.tail != nullptr) {
+        __syncthreads();
+        for (int l = 0; l < a.L; ++l) {
+            if (a.tail_idx[l] < 0) continue;
+            float m = max_s[l * 256 + threadIdx.x];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + a.tail_idx[l]), __float_as_uint(m));
+        }
+    }
+}
+
+template <int H>
+int launch_chain(const FusedArgs &f, int64_t n, hipStream_t s)
+{
+    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * 1024 + 64;
+    auto kern = fused_chain_kernel<H>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { tn::set_error("mlp_bwd(fused chain): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 256));
+    kern<<<dim3((unsigned)bl), dim3(256), lds_bytes, s>>>(f, n);
+    return tn::check_launch("fused_chain_kernel");
 }
 
 template <int H, bool STASH>
@@ -674,7 +850,7 @@ __attribute__((visibility("hidden"))) int launch_fused_fwd_f2(int H, const MlpAr
 {
     const int L = spec ? spec->n_run : a.n_layers;
     PackArgs p;
-    p.L = L; p.H = H;
+    p.L = L; p.H = H; p.transpose = 0;
     int64_t off = 0;
     for (int l = 0; l < L; ++l) {
         p.W[l] = a.W[l]; p.B[l] = a.B[l]; p.N[l] = a.N[l]; p.K[l] = l == 0 ? a.K0 : a.K[l];
@@ -695,12 +871,44 @@ __attribute__((visibility("hidden"))) int launch_fused_fwd_f2(int H, const MlpAr
     f.stream = p.stream; f.bias = p.bias; f.consts = p.consts; f.L = L; f.n_chunks = (int)chunks; f.out_act = a.out_act;
     f.e_rows = e_rows; f.e_rows_total = 64; f.e_off = 0; f.y = y;
     f.rows = nullptr; f.rows_total = 0; f.out_linear = 1; f.tail = nullptr;
-    for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) { f.off_out[l] = 0; f.off_bits[l] = 0; }
+    f.off_in = 0;
+    for (int l = 0; l < TN_MLP_MAX_LAYERS; ++l) { f.off_out[l] = 0; f.off_bits[l] = 0; f.tail_idx[l] = l >= 1 ? l : -1; }
     if (spec == nullptr) return H == 256 ? launch<256, false>(f, n, s) : launch<128, false>(f, n, s);
     f.e_rows_total = spec->rows_total; f.e_off = spec->off_e;
     f.rows = spec->rows; f.rows_total = spec->rows_total; f.out_linear = spec->n_run == a.n_layers ? 1 : 0; f.tail = spec->tail;
     for (int l = 0; l < L; ++l) { f.off_out[l] = spec->off_out[l]; f.off_bits[l] = spec->off_bits[l]; }
     return H == 256 ? launch<256, true>(f, n, s) : launch<128, true>(f, n, s);
+}
+
+// The data-gradient chain of layers `top` .. 1 (all H x H) in one launch: starts from the gradient rows at spec->off_in (w.r.t. layer
+// top's pre-activation), writes the gradient w.r.t. layer l - 1's pre-activation to spec->off_out[top - l] using the bit rows
+// spec->off_bits[top - l] of activation l - 1, and reports max |gradient w.r.t. layer l| to tail[spec->tail_idx[top - l]].
+__attribute__((visibility("hidden"))) int launch_fused_chain_f2(int H, const MlpArgs &a, int top, int64_t n, void *pack_area, hipStream_t s, const FusedChain *spec)
+{
+    const int L = top;                      // chain positions 0 .. top - 1 = layers top .. 1
+    if (L < 1 || L > TN_MLP_MAX_LAYERS) return tn::fail(TN_E_CONFIG, "mlp_bwd(fused chain): nothing to do");
+    PackArgs p;
+    p.L = L; p.H = H; p.transpose = 1;
+    int64_t off = 0;
+    for (int i = 0; i < L; ++i) {
+        const int l = top - i;
+        p.W[i] = a.W[l]; p.B[i] = a.B[l]; p.N[i] = a.N[l]; p.K[i] = a.K[l];
+        p.off[i] = off;
+        off += (int64_t)(H / 32) * (H / 16) * PAIR_B;
+    }
+    const int64_t chunks = off / CHUNK_B;
+    p.stream = reinterpret_cast<unsigned char *>(pack_area);
+    p.bias = reinterpret_cast<float *>(p.stream + chunks * CHUNK_B);
+    p.consts = p.bias + (int64_t)L * H;
+    fused_pack_kernel<<<dim3((unsigned)L), dim3(1024), 0, s>>>(p);
+    if (int rc = tn::check_launch("fused_pack_kernel(chain)")) return rc;
+    FusedArgs f;
+    f.stream = p.stream; f.bias = p.bias; f.consts = p.consts; f.L = L; f.n_chunks = (int)chunks; f.out_act = TN_ACT_NONE;
+    f.e_rows = nullptr; f.e_rows_total = 0; f.e_off = 0; f.y = nullptr;
+    f.rows = spec->rows; f.rows_total = spec->rows_total; f.out_linear = 0; f.tail = spec->tail; f.off_in = spec->off_in;
+    for (int i = 0; i < TN_MLP_MAX_LAYERS; ++i) { f.off_out[i] = 0; f.off_bits[i] = 0; f.tail_idx[i] = -1; }
+    for (int i = 0; i < L; ++i) { f.off_out[i] = spec->off_out[i]; f.off_bits[i] = spec->off_bits[i]; f.tail_idx[i] = spec->tail_idx[i]; }
+    return H == 256 ? launch_chain<256>(f, n, s) : launch_chain<128>(f, n, s);
 }
 
 }  // namespace layers

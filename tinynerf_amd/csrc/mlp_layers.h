@@ -110,6 +110,14 @@ struct FusedStash {                 // training forward: where the rows the laye
     int64_t off_out[TN_MLP_MAX_LAYERS], off_bits[TN_MLP_MAX_LAYERS];
     float *tail;                    // tail[l]: largest |input value| of layer l (l >= 1), zeroed by the caller
 };
+struct FusedChain {                 // data-gradient chain: chain position i = layer top - i
+    float *rows; int rows_total;
+    int64_t off_in;                 // the gradient it starts from
+    int64_t off_out[TN_MLP_MAX_LAYERS], off_bits[TN_MLP_MAX_LAYERS];
+    int tail_idx[TN_MLP_MAX_LAYERS];
+    float *tail;
+};
+int launch_fused_chain_f2(int H, const tn::mlp::MlpArgs &a, int top, int64_t n, void *pack_area, hipStream_t s, const FusedChain *spec);
 int64_t fused_pack_bytes(int H, int L);
 bool fused_fwd_ok(int H, const tn::mlp::MlpArgs &a);
 int launch_fused_fwd_f2(int H, const tn::mlp::MlpArgs &a, int64_t n, const float *e_rows, float *y, void *pack_area, hipStream_t s, const FusedStash *spec = nullptr);

@@ -81,7 +81,7 @@ class _FusedMLP(Function):
     stash_forward = True   # training forward writes the activation workspace (tn_mlp_fwd_stash); False: backward recomputes
     layerwise_inference = False   # True: tn_mlp_fwd_ws one launch per layer (TN_MLP_LAYERWISE) instead of the cross-layer persistent launch --
                                   # the parity partner of tests/test_hip_fused.py and the A side of scripts/fused_fwd_time.py
-    layerwise_training = False    # ... the same for the training forward (tn_mlp_fwd_stash)
+    layerwise_training = False    # ... the same for the training forward (tn_mlp_fwd_stash) and the data-gradient chain (tn_mlp_bwd)
 
     @staticmethod
     def forward(ctx: Any, x: torch.Tensor, aux: Optional[torch.Tensor], freqs: Optional[torch.Tensor], encoding: int,
@@ -181,7 +181,7 @@ class _FusedMLP(Function):
         gy = None if delivered else grad_y.reshape(n, -1).to(torch.float32).contiguous()
         desc = _mlp_desc(ps, x2.size(1), encoding, n_freqs, out_act, freqs,
                          (L.MLP_STASHED if ws_fwd is not None else 0) | (L.MLP_GRAD_Y_ROWS if delivered else 0) |
-                         (L.MLP_SKIP_LAST if ctx.skip_last else 0))
+                         (L.MLP_SKIP_LAST if ctx.skip_last else 0) | (L.MLP_LAYERWISE if _FusedMLP.layerwise_training else 0))
         if ctx.skip_last and not delivered:
             raise RuntimeError("tinynerf_amd: this stack ran without its last layer (TN_MLP_SKIP_LAST) but its consumer did not deliver "
                                "d loss / d (hidden activation) as workspace rows")

@@ -40,8 +40,8 @@ PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s a
 PEAK_ATOMIC_GLANES = 325.0         # scripts/microbench/atomic_scaling.hip: full-line global_atomic_add_f32 from >= 4096 waves on random lines, G lane-atomics/s
                                    # (atomic_patterns.hip: 272 on random lines with its heavier index stream, 160 on runs of neighbouring lines)
 # counter passes cannot be collected live (rocprofv3 wraps the process): the committed summaries of the same command
-PMC_PROFILES = ["profiles/round5_pmc_traffic.json", "profiles/round4_pmc_traffic.json", "profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
-MFMA_PROFILES = ["profiles/round5_mfma_busy.json", "profiles/round4_mfma_busy.json", "profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
+PMC_PROFILES = ["profiles/round6_pmc_traffic.json", "profiles/round5_pmc_traffic.json", "profiles/round4_pmc_traffic.json", "profiles/round3_pmc_traffic.json", "profiles/round2_pmc_traffic.json"]   # scripts/pmc.sh + scripts/pmc_to_json.py
+MFMA_PROFILES = ["profiles/round6_mfma_busy.json", "profiles/round5_mfma_busy.json", "profiles/round4_mfma_busy.json", "profiles/round3_mfma_busy.json", "profiles/round2_mfma_busy.json"]      # scripts/pmc_mfma.sh
 
 # algorithmic work per unit of the kernels that can dominate
 FLOP_SIGMA_FWD = 2 * (96 * 64 + 64)                                   # 12 416   

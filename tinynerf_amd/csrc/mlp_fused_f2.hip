@@ -71,6 +71,12 @@ constexpr int PAIR_B = 2048;                 // one A operand: 64 lanes x 16 B o
 constexpr int CHUNK_PAIRS = 16;
 constexpr int CHUNK_B = CHUNK_PAIRS * PAIR_B;
 constexpr int NRING = 4;
+// Waves per workgroup (one workgroup per CU).  H = 256: one per SIMD -- a sample column and its successor fill the 512-register budget.
+// H = 128: two per SIMD (256 registers each) where the kernel fits them -- the inference forward (222 registers) and the gradient chain (188);
+// the training forward would spill 75.  The epilogue of a 128-wide layer is twice as long relative to its MFMAs, and a second wave's MFMAs
+// run behind it: measured 0.86 -> 0.76 ms (Cobafa forward, 2^20 samples), chain 0.89 -> 0.84 ms.  All waves share the ring; a wave
+// fetches 32 / NW of a chunk's 32 pieces.  CHAIN_OR_INFER: the kernel is fused_chain_kernel or fused_fwd_kernel<H, false>.
+template <int H, bool CHAIN_OR_INFER> constexpr int NWAVES = (H == 128 && CHAIN_OR_INFER) ? 8 : 4;
 constexpr int KS0 = 4;                       // k steps of the first layer (<= 64 input rows)
 
 struct FusedArgs {
@@ -221,9 +227,9 @@ struct Ring {
         next = next + 1 == n_chunks ? 0 : next + 1;
     }
     // between the last MFMA on chunk g - 1 and the first on chunk g
-    __device__ __forceinline__ void boundary() {
+    template <int NW> __device__ __forceinline__ void boundary() {   // (vmcnt: the wave's pieces of one chunk -- the newest -- may still be in flight)
         if (!(TN_FUSED_ABL & 2)) {
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(32 / NW) : "memory");
         }
         target_next();
         ++g;
@@ -436,7 +442,8 @@ struct Layer {
     __device__ __forceinline__ void step() {
         constexpr int t = GI * KSL + S;
         // ---- front matter: chunk boundary, one LDS-direct piece, the operands of step t + 2, wait for those of step t ----
-        if constexpr (t % 8 == 0) ring.boundary();
+        constexpr int NW = NWAVES<H, MODE == 2 || !STASH>;
+        if constexpr (t % 8 == 0) ring.template boundary<NW>();
         // operands of step t + 2 of the STREAM (the next layer's, the next round's: the ring does not care); pair offset inside its chunk
         constexpr int pt = (2 * (t + 2)) % CHUNK_PAIRS;
         const unsigned base = ((t % 8) + 2 >= 8) ? ring.nxt : ring.cur;
@@ -491,7 +498,7 @@ struct Layer {
         c[1] = mm(A[1].lo, b.hi, S == 0 ? z : c[1]); TN_SB; fill(1); TN_SB;
         c[0] = mm(A[0].hi, b.lo, c[0]); TN_SB; fill(2); TN_SB;
         c[1] = mm(A[1].hi, b.lo, c[1]); TN_SB; fill(3); TN_SB;
-        c[0] = mm(A[0].hi, b.hi, c[0]); TN_SB; fill(4); ring.template piece<t % 8>(); TN_SB;
+        c[0] = mm(A[0].hi, b.hi, c[0]); TN_SB; fill(4); if constexpr ((t % 8) % (NW / 4) == 0) ring.template piece<(t % 8) / (NW / 4)>(); TN_SB;
         c[1] = mm(A[1].hi, b.hi, c[1]); TN_SB; fill(5); req(0); req(1); req(2); req(3); TN_SB;
 #undef TN_SB
         // ---- last step of a group: its accumulators become the pending ones, their bias is requested (8 reads, complete by the next step) ----
@@ -536,7 +543,7 @@ __device__ __forceinline__ float run_layer(Ring &ring, State<H> &st, Op2 (&in)[H
         L.rows = urow(tl.rows_base, a.off_out[l]);
         L.bits = reinterpret_cast<unsigned *>(urow(tl.rows_base, MODE != 1 ? a.off_bits[l] : 0));
         L.lane_off = tl.lane_off; L.lane = tl.lane;
-        L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * 1024u : 0u;
+        L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * (256u * NWAVES<H, MODE == 2 || !STASH>) : 0u;
     }
     L.own_tile = tl.own_tile;
     L.run();
@@ -544,7 +551,7 @@ __device__ __forceinline__ float run_layer(Ring &ring, State<H> &st, Op2 (&in)[H
 }
 
 template <int H, bool STASH>
-__global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
+__global__ __launch_bounds__((64 * NWAVES<H, !STASH>)) void fused_fwd_kernel(FusedArgs a, int64_t n)
 {
     constexpr int KS = H / 16, NB = H / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -553,13 +560,14 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int e = threadIdx.x; e < a.L * H; e += blockDim.x) bias_s[e] = a.bias[e];
-    if constexpr (STASH) for (int e = threadIdx.x; e < a.L * 256; e += blockDim.x) max_s[e] = 0.0f;
+    if constexpr (STASH) for (int e = threadIdx.x; e < a.L * 64 * NWAVES<H, !STASH>; e += blockDim.x) max_s[e] = 0.0f;
     lds_u8 *lds3 = (lds_u8 *)lds_raw;
     const unsigned lds0 = (unsigned)(uintptr_t)lds3;
     Ring ring;
     ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.stream, 0, 0x7fffffff, 0x00020000);
-    ring.lds_wave = lds3 + wave * 8192;
-    ring.voff = (unsigned)(wave * 8192 + lane * 16);
+    constexpr int NW = NWAVES<H, !STASH>;
+    ring.lds_wave = lds3 + wave * (CHUNK_B / NW);
+    ring.voff = (unsigned)(wave * (CHUNK_B / NW) + lane * 16);
     ring.rd0 = lds0 + lane * 16;
     ring.n_chunks = (unsigned)a.n_chunks;
     ring.next = 0;
@@ -569,14 +577,14 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
     for (int k = 0; k < 3; ++k) {
         ring.target_next();
         ring.template piece<0>(); ring.template piece<1>(); ring.template piece<2>(); ring.template piece<3>();
-        ring.template piece<4>(); ring.template piece<5>(); ring.template piece<6>(); ring.template piece<7>();
+        if constexpr (NW == 4) { ring.template piece<4>(); ring.template piece<5>(); ring.template piece<6>(); ring.template piece<7>(); }
         ++ring.g;
     }
     ring.cur = ring.nxt = ring.rd0;
     __syncthreads();                         // (vmcnt(0): all three chunks have landed; bias staged)
     const unsigned bias0 = lds0 + NRING * CHUNK_B + 16 * h;
     const int64_t n_tiles = (n + 31) >> 5;
-    const int64_t per_round = (int64_t)gridDim.x * 4;
+    const int64_t per_round = (int64_t)gridDim.x * NW;
     const int64_t rounds = (n_tiles + per_round - 1) / per_round;
     State<H> st;
     // (operands of stream steps 0 and 1 -- chunk 0 -- for the window)
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
     const int n_hidden = a.L - 1 - (a.out_linear ? 1 : 0);     // hidden layers behind layer 0
 #pragma clang loop unroll(disable)
     for (int64_t round = 0; round < rounds; ++round) {
-        const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * NW + wave;
         const bool tile_ok = tile_raw < n_tiles;
         const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
         float inv_in;
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
             Layer<H, KS, 1, true, STASH> L{ring, st, st.P, st.Q, bias0 + (unsigned)(l * H * 4), cs[0], cs[1], cs[2], inv_in, 0.0f, 0.0f, 0.0f, tl.yrow, tl.store, h};
             if constexpr (STASH) {
                 L.rows = urow(tl.rows_base, a.off_out[l]); L.bits = nullptr; L.lane_off = tl.lane_off; L.lane = lane;
-                L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * 1024u : 0u;
+                L.max_addr = (a.tail != nullptr && a.tail_idx[l] >= 0) ? tl.max0 + (unsigned)l * (256u * NWAVES<H, !STASH>) : 0u;
             }
             L.own_tile = tile_ok;
             L.run();
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
             __syncthreads();
             for (int l = 0; l < a.L; ++l) {
                 if (a.tail_idx[l] < 0) continue;
-                float m = max_s[l * 256 + threadIdx.x];
+                float m = max_s[l * 64 * NW + threadIdx.x];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
                 if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + a.tail_idx[l]), __float_as_uint(m));      // (non-negative floats order like their bits)
@@ -688,20 +696,21 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(FusedArgs a, int64_t n)
 // the layers.  Every G_{l-1} is written once as rows (the weight-gradient launch of layer l - 1 reads it) and never read back here;
 // relu' comes from the bit rows the training forward left.  Stream position i = layer top - i.
 template <int H>
-__global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n)
+__global__ __launch_bounds__((64 * NWAVES<H, true>)) void fused_chain_kernel(FusedArgs a, int64_t n)
 {
     constexpr int KS = H / 16, NB = H / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *max_s = reinterpret_cast<float *>(lds_raw + NRING * CHUNK_B);           // [L][256] running maxima of the layers' input gradients
     const int lane = tn::lane_id(), j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int e = threadIdx.x; e < a.L * 256; e += blockDim.x) max_s[e] = 0.0f;
+    for (int e = threadIdx.x; e < a.L * 64 * NWAVES<H, true>; e += blockDim.x) max_s[e] = 0.0f;
     lds_u8 *lds3 = (lds_u8 *)lds_raw;
     const unsigned lds0 = (unsigned)(uintptr_t)lds3;
     Ring ring;
     ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.stream, 0, 0x7fffffff, 0x00020000);
-    ring.lds_wave = lds3 + wave * 8192;
-    ring.voff = (unsigned)(wave * 8192 + lane * 16);
+    constexpr int NW = NWAVES<H, true>;
+    ring.lds_wave = lds3 + wave * (CHUNK_B / NW);
+    ring.voff = (unsigned)(wave * (CHUNK_B / NW) + lane * 16);
     ring.rd0 = lds0 + lane * 16;
     ring.n_chunks = (unsigned)a.n_chunks;
     ring.next = 0;
@@ -709,13 +718,13 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n
     for (int k = 0; k < 3; ++k) {
         ring.target_next();
         ring.template piece<0>(); ring.template piece<1>(); ring.template piece<2>(); ring.template piece<3>();
-        ring.template piece<4>(); ring.template piece<5>(); ring.template piece<6>(); ring.template piece<7>();
+        if constexpr (NW == 4) { ring.template piece<4>(); ring.template piece<5>(); ring.template piece<6>(); ring.template piece<7>(); }
         ++ring.g;
     }
     ring.cur = ring.nxt = ring.rd0;
     __syncthreads();
     const int64_t n_tiles = (n + 31) >> 5;
-    const int64_t per_round = (int64_t)gridDim.x * 4;
+    const int64_t per_round = (int64_t)gridDim.x * NW;
     const int64_t rounds = (n_tiles + per_round - 1) / per_round;
     State<H> st;
     {
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n
     const unsigned bias0 = 0;               // (no bias in the chain)
 #pragma clang loop unroll(disable)
     for (int64_t round = 0; round < rounds; ++round) {
-        const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t tile_raw = (round * gridDim.x + blockIdx.x) * NW + wave;
         const bool tile_ok = tile_raw < n_tiles;
         const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
         tl.own_tile = tile_ok;
@@ -786,7 +795,7 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n
         __syncthreads();
         for (int l = 0; l < a.L; ++l) {
             if (a.tail_idx[l] < 0) continue;
-            float m = max_s[l * 256 + threadIdx.x];
+            float m = max_s[l * 64 * NW + threadIdx.x];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.tail + a.tail_idx[l]), __float_as_uint(m));
@@ -797,27 +806,30 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs a, int64_t n
 template <int H>
 int launch_chain(const FusedArgs &f, int64_t n, hipStream_t s)
 {
-    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * 1024 + 64;
+    constexpr int NW = NWAVES<H, true>;
+    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * 256 * NW + 64;
+    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_bwd(fused chain): maxima table does not fit LDS");
     auto kern = fused_chain_kernel<H>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_bwd(fused chain): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
-    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 256));
-    kern<<<dim3((unsigned)bl), dim3(256), lds_bytes, s>>>(f, n);
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + NW - 1) / NW, 256));
+    kern<<<dim3((unsigned)bl), dim3(64 * NW), lds_bytes, s>>>(f, n);
     return tn::check_launch("fused_chain_kernel");
 }
 
 template <int H, bool STASH>
 int launch(const FusedArgs &f, int64_t n, hipStream_t s)
 {
-    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * H * 4 + (STASH ? (size_t)f.L * 1024 : 0) + 64;
+    constexpr int NW = NWAVES<H, !STASH>;
+    const size_t lds_bytes = (size_t)NRING * CHUNK_B + (size_t)f.L * H * 4 + (STASH ? (size_t)f.L * 256 * NW : 0) + 64;
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return tn::fail(TN_E_CONFIG, "mlp_fwd(fused): bias table does not fit LDS");
     auto kern = fused_fwd_kernel<H, STASH>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { tn::set_error("mlp_fwd(fused): cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     const int64_t n_tiles = (n + 31) / 32;
-    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 256));
-    kern<<<dim3((unsigned)bl), dim3(256), lds_bytes, s>>>(f, n);
+    const int64_t bl = std::max<int64_t>(1, std::min<int64_t>((n_tiles + NW - 1) / NW, 256));
+    kern<<<dim3((unsigned)bl), dim3(64 * NW), lds_bytes, s>>>(f, n);
     return tn::check_launch("fused_fwd_kernel");
 }
 

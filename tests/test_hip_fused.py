@@ -123,7 +123,7 @@ def test_rows_of_one_tile_orders_of_magnitude_apart():
 
 
 @pytest.mark.parametrize("shape", ["vanilla", "cobafa"])
-@pytest.mark.parametrize("n", [33, 4097, 70001])
+@pytest.mark.parametrize("n", [1, 33, 4097, 70001])
 def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n):
     """The cross-layer training forward (tn_mlp_fwd_stash without TN_MLP_LAYERWISE) must leave what the layer-wise backward reads:
     activations as rows (1e-5 of each layer's largest value against the layer-wise launches' rows), ReLU bit rows (equal except where an
@@ -138,7 +138,7 @@ def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n)
         x = torch.rand(n, 3, device=DEV) * 2 - 1
     else:
         m = models.MLP(36, 128, 5).to(DEV)
-        x = torch.randn(n, 36, device=DEV) * 0.3
+        x = (torch.randn(n, 36, device=DEV) * 0.3).requires_grad_(True)      # (d loss / d x: what the gradient chain hands to the first layer)
     gy = torch.randn(n, m(x[:1]).shape[-1], device=DEV)
     res = {}
     for mode in ("fused", "layerwise"):
@@ -146,9 +146,12 @@ def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n)
         try:
             for p in m.parameters():
                 p.grad = None
+            x.grad = None
             y = m(x)
             y.backward(gy)
             res[mode] = (y.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()})
+            if x.requires_grad:
+                res[mode][1]["x"] = x.grad.detach().cpu().numpy()
         finally:
             _FusedMLP.layerwise_training = False
     yf, gf = res["fused"]
@@ -161,11 +164,11 @@ def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n)
     md = type(m)(*((10, 256, 8) if shape == "vanilla" else (36, 128, 5)))
     md.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
     sd = {"m." + k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and not k.endswith("freqs")) for k, v in m.state_dict().items()}
-    xin = x.cpu().double()
+    xin = x.detach().cpu().double().requires_grad_(x.requires_grad)
     inp = tp.posenc(xin, sd["m.encoding.freqs"]) if shape == "vanilla" else xin
     (tp.mlp(sd, "m.net.net." if shape == "vanilla" else "m.net.", inp) * gy.cpu().double()).sum().backward()
     for k in gl:
-        ref = sd["m." + k].grad.numpy()
-        scale = np.abs(ref).max()
+        ref = (xin.grad if k == "x" else sd["m." + k].grad).numpy()
+        scale = max(np.abs(ref).max(), 1e-300)
         e_f, e_l = np.abs(gf[k] - ref).max() / scale, np.abs(gl[k] - ref).max() / scale
         assert e_f <= max(1e-5, 3.0 * e_l), (k, e_f, e_l)

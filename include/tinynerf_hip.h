@@ -220,10 +220,12 @@ enum { TN_ENC_NONE = 0,
                                  * TN_MLP_GRAD_Y_ROWS) starts from that gradient and leaves the last layer's parameter gradients untouched
                                  * (they follow from the merged parameters' gradients by the chain rule).  One layer launch less in the
                                  * forward pass, two less in the backward pass, and the feature tensor never exists. */
-#define TN_MLP_LAYERWISE 2048   /* tn_mlp_fwd_ws of a TN_MLP_F16X2 stack: one launch per layer with the activations crossing HBM as workspace rows
-                                 * (the form of rounds 3 - 5) instead of the cross-layer persistent launch of round 6 (csrc/mlp_fused_f2.hip:
-                                 * activations in registers for the whole stack, weights streamed through LDS).  Same results to fp32
-                                 * rounding; kept as the parity partner of the fused launch in tests and for A / B timing. */
+#define TN_MLP_LAYERWISE 2048   /* a TN_MLP_F16X2 stack in tn_mlp_fwd_ws / tn_mlp_fwd_stash / tn_mlp_bwd_layers: one launch per layer and direction
+                                 * with the activations / gradients crossing HBM as workspace rows (the form of rounds 3 - 5) instead of the
+                                 * cross-layer persistent launches of round 6 (csrc/mlp_fused_f2.hip: inference forward, training forward and
+                                 * data-gradient chain with the sample columns in registers for the whole stack, weights streamed through
+                                 * LDS).  Same results to fp32 rounding, same workspace layout; kept as the parity partner of the fused
+                                 * launches in tests and for A / B timing.  The weight-gradient launches are per layer in both forms. */
 #define TN_MLP_LEAN 512        /* the paired width-64 heads (tn_mlp_fwd_stash_pair / tn_kplanes_mlp_fwd_pair and their backward twins), round 5:
                                  * the training forward writes only the ReLU bit masks, the last pre-activation and the feature rows --
                                  * NOT the hidden activations H_l (1.3 KB per sample that crossed HBM twice) -- and the weight-gradient

@@ -276,7 +276,8 @@ def _rccl_main(port, method, q):
     from tinynerf_amd.run import Trainer
     o, d, rgb = _scene()
     out = {}
-    for key, world in (("control", 1), (1, 1), (2, 2)):        # "control": the plain step once more -- how far two runs of the SAME path are apart
+    # "control*": the plain step three more times -- how far runs of the SAME path are apart
+    for key, world in (("control0", 1), ("control1", 1), ("control2", 1), (1, 1), (2, 2)):
         tr = Trainer(_cfg(method), o.to(dev), d.to(dev), rgb.to(dev), torch.ones(3, device=dev), dev, rank=0, world_size=world)
         _no_dropout(tr)
         _half_empty_grid(tr)
@@ -311,7 +312,7 @@ def test_exchange_path_over_rccl_with_one_rank(method):
     out = q.get(timeout=500)
     p.join(timeout=60)
     assert p.exitcode == 0
-    one, two, ctl = out[1], out[2], out["control"]
+    one, two, ctls = out[1], out[2], [out["control0"], out["control1"], out["control2"]]
     for step in range(N_STEPS):
         assert one["steps"][step][0] == two["steps"][step][0]                     # same batches
         assert two["steps"][step][2] == 0                                         # every early all-reduce was awaited
@@ -321,12 +322,13 @@ def test_exchange_path_over_rccl_with_one_rank(method):
             # whatever order the waves arrive.  Tolerance by construction: the plain step run TWICE (`control`) says how far two
             # evaluations of one path are apart for THIS tensor at THIS step -- a grid whose gradient is a near-cancelling sum (norm 2e-5)
             # moves by percents of its own norm, and from step 1 on Adam (eps 1e-15) feeds that back -- and the exchange path may be
-            # 4 x that far from the plain one; where the control agrees better, 2e-5 of the tensor's norm is asked.
+            # 4 x the largest of three such distances from the plain one (one control run was a one-sample estimate of a spread: on one
+            # box in twenty the exchange run landed 4.x of it away); where the controls agree better, 2e-5 of the tensor's norm is asked.
             nrm = float(np.linalg.norm(ref.astype(np.float64)))
-            noise = float(np.linalg.norm((ctl["steps"][step][1][k] - ref).astype(np.float64)))
+            noise = max(float(np.linalg.norm((c["steps"][step][1][k] - ref).astype(np.float64))) for c in ctls)
             assert float(np.linalg.norm((got - ref).astype(np.float64))) <= max(2e-5 * nrm, 4.0 * noise) + 1e-30, (k, step, nrm, noise)
     for k, ref in one["params"].items():
-        noise = float(np.abs(ctl["params"][k] - ref).max())
+        noise = max(float(np.abs(c["params"][k] - ref).max()) for c in ctls)
         np.testing.assert_allclose(two["params"][k], ref, rtol=0, atol=max(2e-5 * float(np.abs(ref).max()), 4.0 * noise) + 1e-12, err_msg=k)
     if method == "kplanes":
         assert two["early_calls"] == N_STEPS

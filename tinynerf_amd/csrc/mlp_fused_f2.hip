@@ -121,7 +121,8 @@ __device__ __forceinline__ void bound_scales(float u, float &s, float &inv) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// one workgroup per layer: the layer's scale, row-norm / bias bounds, and its weights as the kernel's operand stream
+// gridDim.y workgroups per layer: the layer's scale, row-norm / bias bounds (every workgroup computes them: 256 KB out of L2; the first one
+// stores them), and a gridDim.y-th of its weights as the kernel's operand stream
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
 {
@@ -131,13 +132,27 @@ __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
     const int ldw = a.K[l];
     const float *W = a.W[l];
     auto elem = [&](int r, int k) -> float { return a.transpose ? W[(int64_t)k * ldw + r] : W[(int64_t)r * ldw + k]; };
-    const int lane = tn::lane_id(), wave = threadIdx.x >> 6;
+    const int lane = tn::lane_id(), wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
     float wmax = 0.0f, n2 = 0.0f, bmax = 0.0f;
-    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    // row sums of |A|, every load coalesced.  A = W: a wave per row, lanes along it.  A = W^T: a row of A is a column of W -- lanes along
+    // the rows of A, the waves share the columns and meet in LDS.  (The first form walked a row per thread: 0.07 - 0.10 ms per call.)
+    if (!a.transpose) {
+        for (int r = wave; r < N; r += n_waves) {
+            float s2 = 0.0f;
+            for (int k = lane; k < K; k += 64) { const float w = fabsf(W[(int64_t)r * ldw + k]); wmax = fmaxf(wmax, w); s2 += w; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            n2 = fmaxf(n2, s2);
+        }
+        for (int r = threadIdx.x; r < N; r += blockDim.x) bmax = fmaxf(bmax, fabsf(a.B[l][r]));
+    } else {
+        __shared__ float colsum[4][256 + 1];
+        const int rb = threadIdx.x & 255, part = threadIdx.x >> 8, parts = (int)(blockDim.x >> 8);      // (N <= H <= 256)
         float s2 = 0.0f;
-        for (int k = 0; k < K; ++k) { const float w = fabsf(elem(r, k)); wmax = fmaxf(wmax, w); s2 += w; }
-        n2 = fmaxf(n2, s2);
-        if (!a.transpose) bmax = fmaxf(bmax, fabsf(a.B[l][r]));
+        if (rb < N) for (int k = part; k < K; k += parts) { const float w = fabsf(W[(int64_t)k * ldw + rb]); wmax = fmaxf(wmax, w); s2 += w; }
+        colsum[part][rb] = s2;
+        __syncthreads();
+        if (part == 0 && rb < N) { float t = 0.0f; for (int q = 0; q < parts; ++q) t += colsum[q][rb]; n2 = t; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -149,16 +164,16 @@ __global__ __launch_bounds__(1024) void fused_pack_kernel(PackArgs a)
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { wmax = fmaxf(wmax, red[0][w]); n2 = fmaxf(n2, red[1][w]); bmax = fmaxf(bmax, red[2][w]); }
     float s_w, inv_w;
     f2_scales(wmax, s_w, inv_w);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         a.consts[4 * l + 0] = inv_w;
         a.consts[4 * l + 1] = n2 * 1.0005f;             // largest row sum of |w| (fp32 rounding of the sum)
         a.consts[4 * l + 2] = bmax;
         a.consts[4 * l + 3] = 0.0f;
     }
-    for (int e = threadIdx.x; e < H; e += blockDim.x) a.bias[l * H + e] = (e < N && !a.transpose) ? a.B[l][e] : 0.0f;
+    if (blockIdx.y == 0) for (int e = threadIdx.x; e < H; e += blockDim.x) a.bias[l * H + e] = (e < N && !a.transpose) ? a.B[l][e] : 0.0f;
     const int KS = (l == 0 && !a.transpose) ? KS0 : H / 16;       // (the forward's first layer has <= 64 inputs; the chain has no such layer)
     unsigned char *dst = a.stream + a.off[l];
-    for (int idx = threadIdx.x; idx < (H / 32) * KS * 64; idx += blockDim.x) {
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < (H / 32) * KS * 64; idx += blockDim.x * gridDim.y) {
         // consumption order: group gi = output blocks 2 gi, 2 gi + 1; inside a group k step by k step, the even block first
         const int pair = idx >> 6, ln = idx & 63, gi = pair / (2 * KS), s = (pair - gi * 2 * KS) >> 1, ob = 2 * gi + (pair & 1), i = ln & 31, h = ln >> 5;
         const int row = 32 * ob + i;
@@ -877,7 +892,7 @@ __attribute__((visibility("hidden"))) int launch_fused_fwd_f2(int H, const MlpAr
         hipError_t me = hipMemsetAsync(p.stream + off, 0, (size_t)(chunks * CHUNK_B - off), s);
         if (me != hipSuccess) { tn::set_error("mlp_fwd(fused): memset: %s", hipGetErrorString(me)); return (int)me; }
     }
-    fused_pack_kernel<<<dim3((unsigned)L), dim3(1024), 0, s>>>(p);
+    fused_pack_kernel<<<dim3((unsigned)L, 4), dim3(1024), 0, s>>>(p);
     if (int rc = tn::check_launch("fused_pack_kernel")) return rc;
     FusedArgs f;
     f.stream = p.stream; f.bias = p.bias; f.consts = p.consts; f.L = L; f.n_chunks = (int)chunks; f.out_act = a.out_act;
@@ -912,7 +927,7 @@ __attribute__((visibility("hidden"))) int launch_fused_chain_f2(int H, const Mlp
     p.stream = reinterpret_cast<unsigned char *>(pack_area);
     p.bias = reinterpret_cast<float *>(p.stream + chunks * CHUNK_B);
     p.consts = p.bias + (int64_t)L * H;
-    fused_pack_kernel<<<dim3((unsigned)L), dim3(1024), 0, s>>>(p);
+    fused_pack_kernel<<<dim3((unsigned)L, 4), dim3(1024), 0, s>>>(p);
     if (int rc = tn::check_launch("fused_pack_kernel(chain)")) return rc;
     FusedArgs f;
     f.stream = p.stream; f.bias = p.bias; f.consts = p.consts; f.L = L; f.n_chunks = (int)chunks; f.out_act = TN_ACT_NONE;

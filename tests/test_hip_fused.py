@@ -122,8 +122,8 @@ def test_rows_of_one_tile_orders_of_magnitude_apart():
     assert (fused[5] == 0).all()
 
 
-@pytest.mark.parametrize("shape", ["vanilla", "cobafa"])
-@pytest.mark.parametrize("n", [1, 33, 4097, 70001])
+@pytest.mark.parametrize("shape,n", [(s_, n_) for s_ in ("vanilla", "cobafa") for n_ in (1, 33, 4097, 70001)]
+                         + [("vanilla7", 4097), ("cobafa4", 4097), ("cobafa2", 333)])     # (the other parity of the hidden-layer count: the P / Q column swap)
 def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n):
     """The cross-layer training forward (tn_mlp_fwd_stash without TN_MLP_LAYERWISE) must leave what the layer-wise backward reads:
     activations as rows (1e-5 of each layer's largest value against the layer-wise launches' rows), ReLU bit rows (equal except where an
@@ -133,11 +133,13 @@ def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n)
     if models.MATMUL != "f16x2":
         pytest.skip("the cross-layer launch is the f16x2 form")
     torch.manual_seed(7)
+    depth = int(shape[-1]) if shape[-1].isdigit() else (8 if shape == "vanilla" else 5)
+    shape = shape.rstrip("0123456789")
     if shape == "vanilla":
-        m = models.VanillaFeatureMLP(10, 256, 8).to(DEV)
+        m = models.VanillaFeatureMLP(10, 256, depth).to(DEV)
         x = torch.rand(n, 3, device=DEV) * 2 - 1
     else:
-        m = models.MLP(36, 128, 5).to(DEV)
+        m = models.MLP(36, 128, depth).to(DEV)
         x = (torch.randn(n, 36, device=DEV) * 0.3).requires_grad_(True)      # (d loss / d x: what the gradient chain hands to the first layer)
     gy = torch.randn(n, m(x[:1]).shape[-1], device=DEV)
     res = {}
@@ -161,8 +163,6 @@ def test_training_forward_in_one_launch_leaves_the_layerwise_workspace(shape, n)
     # its whole backward contribution moves ("ReLU ties"): with 70 001 samples x 2 304 units a handful do.  The yardstick is
     # therefore an fp64 evaluation of the same stack (torch autograd on the CPU): the cross-layer form may be no further from it than
     # 3 x the layer-wise launches are (or 1e-5 of the tensor's largest entry where they agree better than that).
-    md = type(m)(*((10, 256, 8) if shape == "vanilla" else (36, 128, 5)))
-    md.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
     sd = {"m." + k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and not k.endswith("freqs")) for k, v in m.state_dict().items()}
     xin = x.detach().cpu().double().requires_grad_(x.requires_grad)
     inp = tp.posenc(xin, sd["m.encoding.freqs"]) if shape == "vanilla" else xin

@@ -78,14 +78,16 @@ def test_vanilla_stack_scales(scale):
     assert e_fused <= max(1e-5, 4 * e_torch)
 
 
-def test_cobafa_stack_in_one_launch():
-    """Cobafa's 128-wide stack (models.py:247: MLP(36, 128, 5)) on plain inputs"""
+@pytest.mark.parametrize("depth,n", [(5, 70001), (5, 1), (5, 255), (5, 257), (4, 4097), (2, 513), (1, 100)])
+def test_cobafa_stack_in_one_launch(depth, n):
+    """Cobafa's 128-wide stack (models.py:247: MLP(36, 128, 5)) on plain inputs; eight waves of a workgroup share the weight ring here
+    (one tile each: n around 8 x 32 = fewer / more tiles than waves); other depths: both parities of the hidden-layer count"""
     from tinynerf_amd import models
     if models.MATMUL != "f16x2":
         pytest.skip("the cross-layer launch is the f16x2 form")
     torch.manual_seed(11)
-    m = models.MLP(36, 128, 5).to(DEV)
-    x = torch.randn(70001, 36, device=DEV) * 0.3
+    m = models.MLP(36, 128, depth).to(DEV)
+    x = torch.randn(n, 36, device=DEV) * 0.3
     fused, layer = _both(m, x)
     sd = {"m." + k: v.detach().cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():

@@ -487,7 +487,6 @@ __global__ __launch_bounds__(WPB * 64) void wgrad_rc_kernel(RcArgs p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights_f2(p.a, lds);
     stage_weights_f2(p.b, lds + p.a.lds_floats);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     wgrad_rc_body<WPB, AUX, OA, OB, NGA, NBA>(p, lds, lds + p.a.lds_floats, nullptr, p.x, p.aux,
                                               p.a.aux_index, p.ws_a, p.ws_b);
 }

@@ -341,11 +341,27 @@ def side_profile(method):
         p = json.load(open(os.path.join(ROOT, "profiles", f"round6_{method}_pmc_traffic.json")))
     except Exception:       # noqa: BLE001
         return None
+    try:        # the matrix-pipe counters of the same step (scripts/profile_config.sh): busy fraction and the clock the launch ran at
+        busy = json.load(open(os.path.join(ROOT, "profiles", f"round6_{method}_mfma_busy.json"))).get("per_kernel", {})
+    except Exception:       # noqa: BLE001
+        busy = {}
     top = []
     for k, v in list(p.get("kernels", {}).items())[:8]:
-        top.append({"kernel": k, "bound": "hbm", "traffic": v["bytes_per_launch"], "avg_launch_ms_profiled": (v.get("avg_us_profiled") or 0) / 1e3,
-                    "achieved": v.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": v.get("frac_of_hbm_peak"), "launches_per_step": v["launches_per_step"]})
-    return {"hbm_bytes_per_step": p["bytes_per_step"], "rooflines": top, "source": f"profiles/round6_{method}_pmc_traffic.json"}
+        r = {"kernel": k, "bound": "hbm", "traffic": v["bytes_per_launch"], "avg_launch_ms_profiled": (v.get("avg_us_profiled") or 0) / 1e3,
+             "achieved": v.get("gbs"), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": v.get("frac_of_hbm_peak"), "launches_per_step": v["launches_per_step"]}
+        b = busy.get(k)
+        if b and b.get("GRBM_GUI_ACTIVE") and v.get("avg_us_profiled"):
+            f = b.get("mfma_pipe_busy_frac", 0.0)
+            ghz = b["GRBM_GUI_ACTIVE"] / 8.0 / (v["avg_us_profiled"] * 1e3)
+            r["mfma"] = {"pipe_busy_frac": f, "clock_ghz": ghz, "busy_x_clock_over_2p4_ghz": f * ghz / 2.4}
+            if f > (r["frac"] or 0.0):
+                r["bound"], r["hbm"] = "mfma", {"achieved": r["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac"]}
+                r["achieved"], r["peak"], r["unit"], r["frac"] = f * ghz / 2.4, 1.0, "fraction of the f16 MFMA peak at 2.4 GHz (pipe busy x clock)", f * ghz / 2.4
+        top.append(r)
+    return {"hbm_bytes_per_step": p["bytes_per_step"], "rooflines": top, "source": f"profiles/round6_{method}_pmc_traffic.json",
+            "mfma_note": "rooflines[].mfma: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of profiles/round6_<method>_mfma_busy.json; clock = "
+                         "GRBM_GUI_ACTIVE / 8 / launch duration -- the chip lowers it under matrix load (DESIGN 4.1), so busy x clock / 2.4 GHz is the "
+                         "fraction of the guide's MFMA peak; a launch whose pipe-busy fraction exceeds its HBM fraction is labelled bound = mfma"}
 
 
 def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=None, held_out=None):
@@ -433,6 +449,7 @@ def run_other_config(method, o, d, rgbs, tr_main, dev, steps, n_windows, matmul=
         out["hbm_frac"] = out["hbm_gbs"] / PEAK_HBM_GBS
         out["rooflines"] = prof["rooflines"]
         out["hbm_source"] = prof["source"]
+        out["rooflines_note"] = prof["mfma_note"]
     if held_out is not None and matmul is None:
         # an 800 x 800 image through the inference path (run.py:15-50): the wide stacks run as ONE persistent launch per chunk (csrc/mlp_fused_f2.hip)
         import contextlib
